@@ -1,0 +1,211 @@
+/*
+ * pcs_hip.h — C ABI of libpcs_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame hot path of conix-center/pointcloud_stitching:
+ *
+ *     Z16 depth raster ──deproject──► XYZ (camera frame) ──4x4 rigid──► world
+ *     RGB8 colour raster ──texcoord gather──► RGB
+ *     ──► [x_mm y_mm z_mm R|G<<8 B] int16 x5 records (10 B / point)
+ *     ──► N cameras concatenated in camera order (the "stitched" buffer)
+ *
+ * Citations are relative to the reference checkout (read for behaviour only):
+ *   a1  sendXYZRGBPointcloud                 src/pcs-camera-optimized.cpp:669-723
+ *   a2  copyPointCloudXYZRGBToBufferSIMD     src/pcs-camera-optimized.cpp:363-616   (-m path = parity target)
+ *   a4  tf_mat / transform[i]                src/pcs-camera-optimized.cpp:64-72,
+ *                                            src/pcs-multicamera-optimized.cpp:417-455
+ *   a5  rs2::pointcloud::calculate / map_to  call sites src/pcs-camera-optimized.cpp:198-199, 288-289
+ *       (third-party librealsense2; arithmetic restated in DESIGN.md "Deprojection contract")
+ *   a6  buffer layout: BUF_SIZE, header      src/pcs-camera-optimized.cpp:27, 690, 715-720
+ *   a7  sendStitchToUnity (concatenate)      src/pcs-multicamera-client.cpp:373-409
+ *
+ * The reference has no FFI; its seam is the C++ function pair a1/a2, which reads its inputs
+ * through six rs2:: accessors and takes the extrinsic, thread count and flags from globals.
+ * This header is what a maintainer would bind instead: plain pointers and
+ * sizes, no C++ types, no exceptions across the boundary, every call returns a pcs_status.
+ *
+ * Conventions
+ *   - All entry points return PCS_OK (0) or a negative pcs_status. Nothing calls exit().
+ *   - The caller owns every buffer it passes. The context owns its device staging buffers,
+ *     its per-stream constant tables and its HIP stream.
+ *   - One context per host thread (the reference's kernel is not re-entrant either,
+ *     src/pcs-camera-optimized.cpp:349-360). Contexts are independent of each other.
+ *   - Functions suffixed _device take DEVICE pointers, enqueue on the context's HIP stream and
+ *     return without synchronising (use pcs_synchronize). All others take HOST pointers and
+ *     are synchronous.
+ *   - There is no CPU fallback: without a usable HIP device pcs_create fails with
+ *     PCS_ERR_NO_DEVICE.
+ */
+#ifndef PCS_HIP_H
+#define PCS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCS_ABI_VERSION 1
+
+/* a6: the wire/buffer constants of the reference (src/pcs-camera-optimized.cpp:27-30). */
+#define PCS_POINT_SHORTS   5          /* x y z (R|G<<8) B                                   */
+#define PCS_POINT_BYTES    10
+#define PCS_HEADER_SHORTS  2          /* payload starts at buffer + 2 shorts = byte 4  :690  */
+#define PCS_REF_BUF_SIZE   5000000    /* BUF_SIZE: shorts malloc'd, BYTES memset        :27,157,673 */
+#define PCS_MAX_STREAMS    64
+
+typedef enum pcs_status {
+    PCS_OK               =  0,
+    PCS_ERR_INVALID_ARG  = -1,
+    PCS_ERR_NO_DEVICE    = -2,   /* no HIP device / device index out of range */
+    PCS_ERR_HIP          = -3,   /* a HIP runtime call failed; see pcs_last_error */
+    PCS_ERR_UNSUPPORTED  = -4,   /* e.g. distortion model not covered, bpp < 3 */
+    PCS_ERR_CAPACITY     = -5,   /* caller's buffer too small for the result */
+    PCS_ERR_NOMEM        = -6
+} pcs_status;
+
+/* Same numbering as rs2_distortion for the models covered. */
+typedef enum pcs_distortion {
+    PCS_DISTORTION_NONE                   = 0,
+    PCS_DISTORTION_MODIFIED_BROWN_CONRADY = 1,
+    PCS_DISTORTION_INVERSE_BROWN_CONRADY  = 2,
+    PCS_DISTORTION_FTHETA                 = 3,  /* unsupported unless coeffs are all zero */
+    PCS_DISTORTION_BROWN_CONRADY          = 4   /* unsupported unless coeffs are all zero */
+} pcs_distortion;
+
+/* Field order of rs2_intrinsics so a binding can memcpy one into the other. */
+typedef struct pcs_intrinsics {
+    int32_t width, height;
+    float   ppx, ppy;
+    float   fx, fy;
+    int32_t model;          /* pcs_distortion */
+    float   coeffs[5];      /* k1 k2 p1 p2 k3 */
+} pcs_intrinsics;
+
+/* rs2_extrinsics: rotation is a COLUMN-major 3x3, translation in metres. */
+typedef struct pcs_extrinsics {
+    float rotation[9];
+    float translation[3];
+} pcs_extrinsics;
+
+/* Everything the reference takes from librealsense profile queries and from its globals,
+ * for one camera stream. */
+typedef struct pcs_stream_config {
+    pcs_intrinsics depth;            /* depth stream geometry + pinhole model                    */
+    pcs_intrinsics color;            /* colour stream geometry + pinhole model (map_to target)   */
+    pcs_extrinsics depth_to_color;   /* rs2 get_extrinsics(depth -> colour)                      */
+    float          depth_scale;      /* metres per Z16 unit; 0.001f on D400                      */
+    int32_t        color_bpp;        /* video_frame::get_bytes_per_pixel      (>= 3)     :374    */
+    int32_t        color_stride;     /* video_frame::get_stride_in_bytes                 :375    */
+    float          cam_to_world[16]; /* row-major 4x4, metres, last row unused = tf_mat  :64-67  */
+} pcs_stream_config;
+
+/* pcs_config.flags */
+#define PCS_FLAG_CUTOFF         0x1u  /* -c: keep iff 0<z<=1.5 && -2<x<=2 (camera frame), compacted in
+                                         ascending point order (= the reference's -c -m -t1 order) :499-577 */
+#define PCS_FLAG_CUTOFF_COMPAT  0x2u  /* with CUTOFF: reproduce the reference's lane-reversed mask (point k of
+                                         each aligned group of 4 is gated by point 3-k)  :501-502,519 */
+#define PCS_FLAG_DROP_INVALID   0x4u  /* drop depth==0 pixels (not in the reference; north-star compaction) */
+
+typedef struct pcs_config {
+    int32_t                  device;      /* HIP device ordinal */
+    int32_t                  n_streams;   /* 1..PCS_MAX_STREAMS */
+    const pcs_stream_config* streams;     /* n_streams entries, copied by pcs_create */
+    uint32_t                 flags;       /* PCS_FLAG_* */
+    int32_t                  downsample;  /* a7: keep every downsample-th kept point per stream; >= 1
+                                             (src/pcs-multicamera-client.cpp:375,388) */
+} pcs_config;
+
+typedef struct pcs_ctx pcs_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int          pcs_abi_version(void);
+int          pcs_device_count(void);                 /* >= 0, or a negative pcs_status */
+int          pcs_create(pcs_ctx** out, const pcs_config* cfg);
+void         pcs_destroy(pcs_ctx* ctx);
+const char*  pcs_strerror(int status);
+const char*  pcs_last_error(const pcs_ctx* ctx);     /* detail of the last failure on this ctx */
+
+/* Replace one stream's camera->world matrix (the reference edits tf_mat in source, :64-67). */
+int          pcs_set_cam_to_world(pcs_ctx* ctx, int stream, const float m16[16]);
+
+/* Number of points one frame of `stream` deprojects to (= depth width*height). */
+int          pcs_stream_points(const pcs_ctx* ctx, int stream);
+/* Upper bound of the stitched payload in shorts for the current config (no header). */
+size_t       pcs_max_payload_shorts(const pcs_ctx* ctx);
+
+/* ---- a2 twin: bit-exact replacement of copyPointCloudXYZRGBToBufferSIMD (:363-616) ------ *
+ * vertices  = pts.get_vertices()            n_points x {float x,y,z}
+ * texcoords = pts.get_texture_coordinates() n_points x {float u,v}
+ * color     = color.get_data(); geometry (w,h,bpp,stride) and tf_mat come from stream's config
+ * pc_buffer = the reference's `buffer + 2` (payload pointer); needs 5*n_points shorts
+ * returns the number of points written in *out_points (n_points, or the kept count under -c).
+ * Any n_points >= 0 is accepted (the reference needs n % 4 == 0, :414).                      */
+int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* ctx, int stream,
+                                         const float* vertices, const float* texcoords, int n_points,
+                                         const uint8_t* color, int16_t* pc_buffer, int* out_points);
+int pcs_copy_pointcloud_xyzrgb_to_buffer_device(pcs_ctx* ctx, int stream,
+                                         const float* d_vertices, const float* d_texcoords, int n_points,
+                                         const uint8_t* d_color, int16_t* d_pc_buffer, int* d_out_points);
+
+/* ---- a1 twin: sendXYZRGBPointcloud (:669-723) without the socket ----------------------- *
+ * buffer must hold buffer_shorts shorts (the reference mallocs PCS_REF_BUF_SIZE). On return:
+ * payload at buffer+2 shorts; if write_header, int32 LE payload byte count at byte 0 (:718);
+ * every other byte below min(PCS_REF_BUF_SIZE, 2*buffer_shorts) is zero (:673).
+ * *out_size_bytes = 5*count*sizeof(short) (:697).                                            */
+int pcs_send_xyzrgb_pointcloud(pcs_ctx* ctx, int stream,
+                               const float* vertices, const float* texcoords, int n_points,
+                               const uint8_t* color, int16_t* buffer, size_t buffer_shorts,
+                               int write_header, int* out_size_bytes);
+
+/* ---- fused a5+a2 for all streams, output in a7's stitched layout ------------------------ *
+ * depth[s]  : stream s Z16 raster, depth.width*depth.height uint16, row-major, tightly packed
+ * color[s]  : stream s colour raster, color.height rows of color_stride bytes
+ * stitched  : [int32 payload bytes][stream 0 points][stream 1 points]...   (header only if write_header;
+ *             payload always starts at stitched + 2 shorts)
+ * points_per_stream[s] (optional) = points stream s contributed; *out_size_bytes = payload bytes. */
+int pcs_process_frames(pcs_ctx* ctx, const uint16_t* const* depth, const uint8_t* const* color,
+                       int16_t* stitched, size_t stitched_shorts, int write_header,
+                       int* points_per_stream, int* out_size_bytes);
+
+/* Device-resident form: pointers are device pointers, d_payload is the PAYLOAD pointer
+ * (no header), payload_shorts its capacity. d_counts (optional) receives n_streams+1 int32:
+ * per-stream point counts followed by the total. Asynchronous on the context stream.
+ * Without CUTOFF/DROP_INVALID the counts are known on the host (pcs_stream_points) and
+ * d_counts may be NULL.                                                                       */
+int pcs_process_frames_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                              int16_t* d_payload, size_t payload_shorts, int32_t* d_counts);
+
+/* Deprojection only (a5 restated): Z16 -> vertices (N x 3 float) and texcoords (N x 2 float),
+ * i.e. what rs2::pointcloud::calculate + map_to hand to a2. Host pointers. For parity tests
+ * and for callers that still want the intermediate rs2::points arrays.                       */
+int pcs_deproject(pcs_ctx* ctx, int stream, const uint16_t* depth, float* vertices, float* texcoords);
+
+/* ---- a7: stitch already-packed per-camera payloads (sendStitchToUnity, :373-409) -------- *
+ * Keeps every downsample-th 10-byte point of each camera, cameras in index order.
+ * Device pointers; *total_points is written on the HOST (counts are host-known).             */
+int pcs_stitch_device(pcs_ctx* ctx, const int16_t* const* d_cam_payload, const int* cam_points, int n_cams,
+                      int downsample, int16_t* d_stitched_payload, size_t stitched_shorts, int* total_points);
+
+/* ---- stream / timing plumbing ----------------------------------------------------------- */
+int   pcs_set_stream(pcs_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL = own stream) */
+void* pcs_get_stream(pcs_ctx* ctx);
+int   pcs_synchronize(pcs_ctx* ctx);
+/* hipEvent bracket on the context stream: begin; enqueue work; end; elapsed = GPU ms between them. */
+int   pcs_timer_begin(pcs_ctx* ctx);
+int   pcs_timer_end(pcs_ctx* ctx);
+int   pcs_timer_elapsed_ms(pcs_ctx* ctx, float* ms);    /* synchronises on the end event */
+/* Per-launch kernel timing: when enabled every fused-kernel launch is bracketed by its own
+ * event pair; pcs_kernel_times_ms drains them (synchronising) into ms[0..*n).                 */
+int   pcs_kernel_timing(pcs_ctx* ctx, int enable);
+int   pcs_kernel_times_ms(pcs_ctx* ctx, float* ms, int capacity, int* n);
+
+/* Thin device-memory helpers so a C/C++ host needs no HIP headers. */
+int   pcs_device_malloc(pcs_ctx* ctx, void** d_ptr, size_t bytes);
+int   pcs_device_free(pcs_ctx* ctx, void* d_ptr);
+int   pcs_memcpy_h2d(pcs_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int   pcs_memcpy_d2h(pcs_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCS_HIP_H */
