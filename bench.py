@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — Mpoints/s stitched for 8 x 1280x720 synthetic streams per GPU (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the fused deproject -> transform -> RGB attach -> pack kernel over one
+frame-set (8 streams x 921 600 pixels) already resident in HBM, cycling through a ring of frame-sets
+whose footprint exceeds the 256 MiB Infinity Cache so the kernel really streams from HBM.
+N > 1: every rank processes its own 8 streams per step (weak scaling) and the packed payloads are
+gathered to rank 0 over RCCL (double-buffered so the gather of step k overlaps the kernel of k+1).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_POINT = 15            # 2 B Z16 + 3 B RGB8 + 10 B packed record
+HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--streams", type=int, default=8, help="camera streams per GPU")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--ring", type=int, default=6, help="frame-sets resident in HBM (ring)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfgs, depth, color, budget_s):
+    """The reference's `-m -t<N>` path restated (oracle/pcs_oracle_simd.c), timed on this host.
+    Bracket A = the reference's own timed region (memset + pack, deprojection excluded, :291-293).
+    Bracket B adds the CPU deprojection, i.e. what the fused GPU kernel does."""
+    from oracle import pcs_oracle as O
+    L = O.lib()
+    ncores = os.cpu_count() or 1
+    S = len(cfgs)
+    npts = cfgs[0].n_points
+    vt = [O.deproject(cfgs[s], depth[s]) for s in range(S)]
+    buf = np.zeros(5_000_000, np.int16)          # the reference's 10 MB buffer
+
+    def run_a(threads):
+        for s in range(S):
+            v, t = vt[s]
+            L.pcs_oracle_send_simd_omp(C.byref(cfgs[s]), v.ctypes.data, t.ctypes.data, npts,
+                                       color[s].ctypes.data, buf.ctypes.data, threads)
+
+    vv = np.empty((npts, 3), np.float32); tt = np.empty((npts, 2), np.float32)
+
+    def run_b(threads):
+        for s in range(S):
+            d = np.ascontiguousarray(depth[s]).reshape(-1)
+            L.pcs_oracle_deproject_omp(C.byref(cfgs[s]), d.ctypes.data, vv.ctypes.data, tt.ctypes.data, threads)
+            L.pcs_oracle_send_simd_omp(C.byref(cfgs[s]), vv.ctypes.data, tt.ctypes.data, npts,
+                                       color[s].ctypes.data, buf.ctypes.data, threads)
+
+    def best(fn, threads, share):
+        fn(threads)                                # warm
+        t_end = time.perf_counter() + share
+        b = float("inf"); reps = 0
+        while time.perf_counter() < t_end or reps < 2:
+            t0 = time.perf_counter(); fn(threads); b = min(b, time.perf_counter() - t0); reps += 1
+        return b, reps
+
+    share = budget_s / 4.0
+    a_all, r1 = best(run_a, ncores, share)
+    a_one, r2 = best(run_a, 1, share)
+    b_all, r3 = best(run_b, ncores, share)
+    b_one, r4 = best(run_b, 1, share)
+    pts = S * npts
+    return {
+        "value": round(pts / a_all / 1e6, 2), "unit": "Mpoints/s", "cores": ncores, "kind": "port",
+        "sample": f"{S} x {cfgs[0].depth.width}x{cfgs[0].depth.height} frames back-to-back, best of {r1} passes; "
+                  f"bracket A = reference timed region (memset+pack, no deprojection), SSE/FMA+OpenMP port, -t{ncores}",
+        "ms_per_frame_set": round(a_all * 1e3, 3),
+        "theoretical_fps_per_stream": round(S / a_all, 1),
+        "t1_value": round(pts / a_one / 1e6, 2),
+        "with_deprojection_value": round(pts / b_all / 1e6, 2),
+        "with_deprojection_t1_value": round(pts / b_one / 1e6, 2),
+        "cpu_model": _cpu_model(),
+    }
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 through python -m torch.distributed.run (one rank per GPU)")
+
+    import torch
+    import torch.distributed as dist
+    from pointcloud_stitching_amd import synthetic as Syn
+    from pointcloud_stitching_amd.api import PcsContext
+    from pointcloud_stitching_amd.types import POINT_SHORTS
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    S, W, H, R = args.streams, args.width, args.height, max(args.ring, 2)
+    npts = W * H
+    set_points = S * npts
+    # global camera index = rank*S + s  -> extrinsic transform[(rank*S+s) % 8], distinct seeds per camera
+    cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
+    ctx = PcsContext(cfgs, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    # ring of frame-sets resident in HBM
+    d_depth, d_color, host0 = [], [], None
+    for slot in range(R):
+        dep = [Syn.synth_depth(W, H, rank * S + s, seed=Syn.SEED + 7919 * slot) for s in range(S)]
+        col = [Syn.synth_color(W, H, rank * S + s, seed=Syn.SEED + 7919 * slot) for s in range(S)]
+        if slot == 0:
+            host0 = (dep, col)
+        d_depth.append([torch.from_numpy(d.view(np.int16).reshape(-1)).to(dev) for d in dep])
+        d_color.append([torch.from_numpy(c).to(dev) for c in col])
+    payload_shorts = set_points * POINT_SHORTS
+    d_out = [torch.empty(payload_shorts, dtype=torch.int16, device=dev) for _ in range(R)]
+    ring_bytes = R * (set_points * ALGO_BYTES_PER_POINT)
+
+    gather = world > 1 and not args.no_gather
+    stitched = None
+    if gather:
+        from pointcloud_stitching_amd.stitch import RankStitcher
+        st = RankStitcher()
+        if rank == 0:
+            stitched = [torch.empty(payload_shorts * world, dtype=torch.int16, device=dev) for _ in range(2)]
+
+    lib = ctx._lib
+    h = ctx._h
+    VP = C.c_void_p
+    call_args = []
+    for slot in range(R):
+        dp = (VP * S)(*[t.data_ptr() for t in d_depth[slot]])
+        cp = (VP * S)(*[t.data_ptr() for t in d_color[slot]])
+        call_args.append((dp, cp, VP(d_out[slot].data_ptr())))
+
+    def launch(slot):
+        dp, cp, out = call_args[slot]
+        rc = lib.pcs_process_frames_device(h, dp, cp, out, payload_shorts, None)
+        if rc:
+            raise RuntimeError(lib.pcs_last_error(h).decode())
+
+    pending = [None, None]
+
+    def step(k):
+        slot = k % R
+        if gather:
+            if pending[k & 1] is not None:       # the buffer pair (slot's out, stitched[k&1]) is free again
+                pending[k & 1].wait()
+            launch(slot)
+            pending[k & 1] = st.gather_fixed(d_out[slot], stitched[k & 1] if rank == 0 else None, async_op=True)
+        else:
+            launch(slot)
+
+    def drain():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait(); pending[i] = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # parity spot-check of slot 0 against the oracle before timing (bench must not time a wrong kernel)
+    launch(0); torch.cuda.synchronize(dev)
+    if rank == 0:
+        from oracle import pcs_oracle as O
+        want, _ = O.process_frames(cfgs[:1], host0[0][:1], host0[1][:1])
+        got = d_out[0][:npts * POINT_SHORTS].cpu().numpy().reshape(-1, 5)
+        if (got != want).any():
+            raise SystemExit("bench aborted: HIP output differs from the oracle")
+
+    for k in range(args.warmup):
+        step(k)
+    drain(); barrier()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    ctx.timer_end()
+    drain(); barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ctx.timer_elapsed_ms()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_points = set_points * world * args.steps
+        ms_per_step = elapsed * 1e3 / args.steps
+        kern_ms = gpu_ms / args.steps          # HIP-event bracket on the launch stream / launches
+        achieved = set_points * ALGO_BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpoints/s stitched (8x1280x720 streams per GPU: deproject+transform+RGB+pack)",
+            "value": round(total_points / elapsed / 1e6, 1),
+            "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 affine -> int16 records (u16 depth, u8 colour)", "data": "synthetic",
+            "config": {"workload": f"{S} synthetic {W}x{H} Z16+RGB8 streams per GPU, batched fused kernel, "
+                                   f"one extrinsic per stream (BASELINE.json configs[2])",
+                       "streams_per_gpu": S, "width": W, "height": H, "points_per_step_per_gpu": set_points,
+                       "ring_frame_sets": R, "ring_mbytes": round(ring_bytes / 1e6, 1),
+                       "gather_to_rank0": bool(gather), "parallelism": f"streams sharded {S}/GPU x {world}"},
+            "per_stream_fps": round(args.steps / elapsed, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
+                         "kernel": "pcs_fused_dense_kernel<false,false>", "avg_launch_ms": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": set_points * ALGO_BYTES_PER_POINT,
+                         "timing": "hipEvent pair on the launch stream around the timed region / steps"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's operator surface, over the C ABI (include/pcs_hip.h).
+
+Reference seam (src/pcs-camera-optimized.cpp):
+    copyPointCloudXYZRGBToBufferSIMD(pts, color, pc_buffer)  :363  -> PcsContext.copy_pointcloud_xyzrgb_to_buffer
+    sendXYZRGBPointcloud(pts, color, buffer)                 :669  -> PcsContext.send_xyzrgb_pointcloud
+    rs2::pointcloud::calculate / map_to                      :288  -> PcsContext.deproject
+    (edge + central collapsed)                                      -> PcsContext.process_frames
+and src/pcs-multicamera-client.cpp: sendStitchToUnity :373   -> PcsContext.stitch_device
+
+Everything here is plumbing: argument marshalling and error mapping. The arithmetic lives in the
+HIP kernels (csrc/pcs_kernels.hip); there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as _libmod
+from .types import (Config, StreamConfig, STATUS_NAMES, POINT_SHORTS, POINT_BYTES, HEADER_SHORTS,
+                    REF_BUF_SIZE, stream_array)
+
+
+class PcsError(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = status
+        name = STATUS_NAMES.get(status, str(status))
+        super().__init__(f"{name}: {detail}" if detail else name)
+
+
+def device_count() -> int:
+    return int(_libmod.load().pcs_device_count())
+
+
+def _ptr(a: np.ndarray) -> int:
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    return a.ctypes.data
+
+
+class PcsContext:
+    """One context per host thread; owns device constants, staging buffers and a HIP stream."""
+
+    def __init__(self, streams: Sequence[StreamConfig], device: int = 0, flags: int = 0, downsample: int = 1):
+        self._lib = _libmod.load()
+        self._h = C.c_void_p()
+        self.streams = list(streams)
+        self.n_streams = len(self.streams)
+        self.flags = int(flags)
+        self.downsample = int(downsample)
+        self.device = int(device)
+        self._arr = stream_array(self.streams) if self.streams else None
+        cfg = Config()
+        cfg.device = device
+        cfg.n_streams = self.n_streams
+        cfg.streams = C.cast(self._arr, C.POINTER(StreamConfig)) if self._arr is not None else None
+        cfg.flags = self.flags
+        cfg.downsample = self.downsample
+        rc = self._lib.pcs_create(C.byref(self._h), C.byref(cfg))
+        if rc != 0:
+            detail = self._lib.pcs_last_error(None)
+            self._h = C.c_void_p()
+            raise PcsError(rc, detail.decode() if detail else "")
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pcs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            d = self._lib.pcs_last_error(self._h)
+            raise PcsError(rc, d.decode() if d else "")
+
+    # -- queries -----------------------------------------------------------------------------
+    def stream_points(self, stream: int) -> int:
+        return int(self._lib.pcs_stream_points(self._h, stream))
+
+    @property
+    def max_payload_shorts(self) -> int:
+        return int(self._lib.pcs_max_payload_shorts(self._h))
+
+    def set_cam_to_world(self, stream: int, m16) -> None:
+        m = np.ascontiguousarray(m16, np.float32).reshape(16)
+        self._check(self._lib.pcs_set_cam_to_world(self._h, stream, m.ctypes.data_as(C.POINTER(C.c_float))))
+
+    # -- a2 twin -----------------------------------------------------------------------------
+    def copy_pointcloud_xyzrgb_to_buffer(self, stream: int, vertices, texcoords, color,
+                                         pc_buffer: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int]:
+        """copyPointCloudXYZRGBToBufferSIMD (:363-616): returns (payload int16[count,5], count)."""
+        vtx = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        tex = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+        col = np.ascontiguousarray(color, np.uint8).reshape(-1)
+        n = vtx.shape[0]
+        if tex.shape[0] != n:
+            raise ValueError("vertices and texcoords disagree on the point count")
+        if col.size < self.streams[stream].color_bytes:
+            raise ValueError("colour raster smaller than stride*height")
+        out = pc_buffer if pc_buffer is not None else np.zeros((max(n, 1), POINT_SHORTS), np.int16)
+        cnt = C.c_int(0)
+        self._check(self._lib.pcs_copy_pointcloud_xyzrgb_to_buffer(
+            self._h, stream, _ptr(vtx), _ptr(tex), n, _ptr(col), _ptr(out), C.byref(cnt)))
+        return (out.reshape(-1, POINT_SHORTS)[:cnt.value] if pc_buffer is None else out), cnt.value
+
+    # -- a1 twin -----------------------------------------------------------------------------
+    def send_xyzrgb_pointcloud(self, stream: int, vertices, texcoords, color, buffer: np.ndarray,
+                               write_header: bool = True) -> int:
+        """sendXYZRGBPointcloud (:669-723) minus the socket; returns the payload size in bytes."""
+        vtx = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        tex = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+        col = np.ascontiguousarray(color, np.uint8).reshape(-1)
+        if buffer.dtype != np.int16 or not buffer.flags["C_CONTIGUOUS"]:
+            raise ValueError("buffer must be a contiguous int16 array (the reference's short* buffer)")
+        size = C.c_int(0)
+        self._check(self._lib.pcs_send_xyzrgb_pointcloud(
+            self._h, stream, _ptr(vtx), _ptr(tex), vtx.shape[0], _ptr(col), _ptr(buffer), buffer.size,
+            int(write_header), C.byref(size)))
+        return size.value
+
+    # -- fused ---------------------------------------------------------------------------------
+    def process_frames(self, depth: Sequence[np.ndarray], color: Sequence[np.ndarray],
+                       write_header: bool = True) -> Tuple[np.ndarray, List[int], int]:
+        """Deproject + transform + pack every stream; returns (stitched int16 buffer incl. 2 header
+        shorts, per-stream point counts, payload bytes)."""
+        if len(depth) != self.n_streams or len(color) != self.n_streams:
+            raise ValueError("need one depth and one colour raster per stream")
+        d = [np.ascontiguousarray(x, np.uint16).reshape(-1) for x in depth]
+        c = [np.ascontiguousarray(x, np.uint8).reshape(-1) for x in color]
+        for s in range(self.n_streams):
+            if d[s].size != self.streams[s].n_points:
+                raise ValueError(f"stream {s}: depth raster has {d[s].size} pixels, expected {self.streams[s].n_points}")
+            if c[s].size < self.streams[s].color_bytes:
+                raise ValueError(f"stream {s}: colour raster smaller than stride*height")
+        dp = (C.c_void_p * self.n_streams)(*[_ptr(x) for x in d])
+        cp = (C.c_void_p * self.n_streams)(*[_ptr(x) for x in c])
+        buf = np.zeros(HEADER_SHORTS + self.max_payload_shorts, np.int16)
+        counts = (C.c_int * self.n_streams)()
+        size = C.c_int(0)
+        self._check(self._lib.pcs_process_frames(self._h, dp, cp, _ptr(buf), buf.size, int(write_header),
+                                                 counts, C.byref(size)))
+        return buf, [int(x) for x in counts], size.value
+
+    def process_frames_device(self, d_depth: Sequence[int], d_color: Sequence[int], d_payload: int,
+                              payload_shorts: int, d_counts: int = 0) -> None:
+        """Asynchronous launch on device pointers (ints). See pcs_process_frames_device."""
+        dp = (C.c_void_p * self.n_streams)(*d_depth)
+        cp = (C.c_void_p * self.n_streams)(*d_color)
+        self._check(self._lib.pcs_process_frames_device(self._h, dp, cp, d_payload, payload_shorts,
+                                                        d_counts or None))
+
+    def deproject(self, stream: int, depth) -> Tuple[np.ndarray, np.ndarray]:
+        d = np.ascontiguousarray(depth, np.uint16).reshape(-1)
+        n = self.streams[stream].n_points
+        if d.size != n:
+            raise ValueError("depth raster size mismatch")
+        vtx = np.empty((n, 3), np.float32)
+        tex = np.empty((n, 2), np.float32)
+        self._check(self._lib.pcs_deproject(self._h, stream, _ptr(d), _ptr(vtx), _ptr(tex)))
+        return vtx, tex
+
+    # -- a7 ------------------------------------------------------------------------------------
+    def stitch_device(self, d_cam_payload: Sequence[int], cam_points: Sequence[int], downsample: int,
+                      d_stitched_payload: int, stitched_shorts: int) -> int:
+        n = len(d_cam_payload)
+        ptrs = (C.c_void_p * n)(*d_cam_payload)
+        cnts = (C.c_int * n)(*cam_points)
+        total = C.c_int(0)
+        self._check(self._lib.pcs_stitch_device(self._h, ptrs, cnts, n, downsample, d_stitched_payload,
+                                                stitched_shorts, C.byref(total)))
+        return total.value
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))
+
+    def get_stream(self) -> int:
+        return int(self._lib.pcs_get_stream(self._h) or 0)
+
+    def synchronize(self) -> None:
+        self._check(self._lib.pcs_synchronize(self._h))
+
+    def timer_begin(self) -> None:
+        self._check(self._lib.pcs_timer_begin(self._h))
+
+    def timer_end(self) -> None:
+        self._check(self._lib.pcs_timer_end(self._h))
+
+    def timer_elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        self._check(self._lib.pcs_timer_elapsed_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def kernel_timing(self, enable: bool) -> None:
+        self._check(self._lib.pcs_kernel_timing(self._h, int(enable)))
+
+    def kernel_times_ms(self, capacity: int = 65536) -> np.ndarray:
+        arr = (C.c_float * capacity)()
+        n = C.c_int(0)
+        self._check(self._lib.pcs_kernel_times_ms(self._h, arr, capacity, C.byref(n)))
+        return np.array(arr[:min(n.value, capacity)], dtype=np.float32)
+
+    def device_malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.pcs_device_malloc(self._h, C.byref(p), nbytes))
+        return int(p.value)
+
+    def device_free(self, d_ptr: int) -> None:
+        self._check(self._lib.pcs_device_free(self._h, d_ptr))
+
+    def memcpy_h2d(self, d_dst: int, src: np.ndarray) -> None:
+        src = np.ascontiguousarray(src)
+        self._check(self._lib.pcs_memcpy_h2d(self._h, d_dst, _ptr(src), src.nbytes))
+
+    def memcpy_d2h(self, dst: np.ndarray, d_src: int) -> None:
+        self._check(self._lib.pcs_memcpy_d2h(self._h, _ptr(dst), d_src, dst.nbytes))

@@ -1,0 +1,718 @@
+// pcs_capi.cpp — the C ABI of libpcs_hip.so (include/pcs_hip.h) over the gfx950 kernels.
+//
+// Host-side twin of the reference's seam: sendXYZRGBPointcloud / copyPointCloudXYZRGBToBufferSIMD
+// (src/pcs-camera-optimized.cpp:669-723, 363-616) and sendStitchToUnity's concatenate
+// (src/pcs-multicamera-client.cpp:373-395). No CPU compute fallback lives here: if HIP is not usable
+// pcs_create fails and nothing else can be called.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pcs_device.h"
+
+using namespace pcs;
+
+struct pcs_ctx {
+    int                             device = 0;
+    int                             n_streams = 0;
+    uint32_t                        flags = 0;
+    int                             downsample = 1;
+    std::vector<pcs_stream_config>  cfg;
+    std::vector<StreamParams>       h_params;
+    StreamParams*                   d_params = nullptr;
+    std::vector<float*>             d_lut;            // 2 per stream (mx, my)
+    uint32_t                        total_tiles = 0;
+    uint32_t*                       d_tile_counts = nullptr;
+    uint32_t*                       d_tile_prefix = nullptr;
+    uint32_t*                       d_stream_base = nullptr;   // n_streams + 1
+    int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
+    bool                            dense_ok = false;          // every stream has n % 8 == 0
+    bool                            any_ddist = false, any_cdist = false;
+    uint32_t                        max_points = 0;
+    size_t                          max_payload_points = 0;
+
+    hipStream_t                     own_stream = nullptr;
+    hipStream_t                     stream = nullptr;
+    hipEvent_t                      ev_begin = nullptr, ev_end = nullptr;
+    bool                            kernel_timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;    // recorded pairs awaiting drain
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+
+    // lazily sized staging for the host-pointer entry points
+    std::vector<uint16_t*>          s_depth;
+    std::vector<uint8_t*>           s_color;
+    std::vector<size_t>             s_depth_cap, s_color_cap;
+    int16_t*                        s_payload = nullptr;  size_t s_payload_cap = 0;   // bytes
+    float*                          s_vertices = nullptr; size_t s_vertices_cap = 0;
+    float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
+    uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
+
+    std::string                     err;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(pcs_ctx* c, int status, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return status;
+}
+
+#define HIPCHK(c, expr)                                                                     \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail((c), PCS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));   \
+    } while (0)
+
+bool coeffs_nonzero(const pcs_intrinsics& in)
+{
+    for (int k = 0; k < 5; k++) if (in.coeffs[k] != 0.0f) return true;
+    return false;
+}
+
+int validate_stream(const pcs_stream_config& s, int idx)
+{
+    const auto bad = [&](const char* what) {
+        return fail(nullptr, PCS_ERR_INVALID_ARG, "stream %d: %s", idx, what);
+    };
+    if (s.depth.width <= 0 || s.depth.height <= 0) return bad("depth width/height must be positive");
+    if (s.color.width <= 0 || s.color.height <= 0) return bad("colour width/height must be positive");
+    if (s.depth.width >= (1 << 24) || s.depth.height >= (1 << 24) ||
+        s.color.width >= (1 << 24) || s.color.height >= (1 << 24)) return bad("raster dimension too large");
+    if ((uint64_t)s.depth.width * (uint64_t)s.depth.height > 0x7FFFFFF8ull) return bad("too many depth pixels");
+    if (s.color_bpp < 3)
+        return fail(nullptr, PCS_ERR_UNSUPPORTED, "stream %d: colour bytes-per-pixel %d < 3 (the pack reads bytes "
+                    "idx, idx+1, idx+2 of a pixel)", idx, s.color_bpp);
+    if (s.color_bpp > 16) return bad("colour bytes-per-pixel too large");
+    if ((int64_t)s.color_stride < (int64_t)s.color_bpp * s.color.width) return bad("colour stride < bpp*width");
+    if (s.color_stride >= (1 << 24)) return bad("colour stride too large");
+    if ((uint64_t)s.color_stride * (uint64_t)s.color.height > 0xFFFFFFF0ull) return bad("colour raster too large");
+    if ((uint64_t)s.color_stride * (uint64_t)s.color.height < 4) return bad("colour raster smaller than 4 bytes");
+    if (!(s.depth.fx != 0.0f) || !(s.depth.fy != 0.0f)) return bad("depth fx/fy must be non-zero");
+    // Distortion coverage: a model with all-zero coefficients is the identity.
+    if (coeffs_nonzero(s.depth) && s.depth.model != PCS_DISTORTION_INVERSE_BROWN_CONRADY)
+        return fail(nullptr, PCS_ERR_UNSUPPORTED, "stream %d: depth distortion model %d with non-zero "
+                    "coefficients is not covered (only INVERSE_BROWN_CONRADY)", idx, s.depth.model);
+    if (coeffs_nonzero(s.color) && s.color.model != PCS_DISTORTION_MODIFIED_BROWN_CONRADY &&
+        s.color.model != PCS_DISTORTION_INVERSE_BROWN_CONRADY)
+        return fail(nullptr, PCS_ERR_UNSUPPORTED, "stream %d: colour distortion model %d with non-zero "
+                    "coefficients is not covered (only MODIFIED/INVERSE_BROWN_CONRADY)", idx, s.color.model);
+    return PCS_OK;
+}
+
+void fill_params(const pcs_stream_config& s, StreamParams& p)
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) p.M[4 * r + c] = s.cam_to_world[4 * r + c];
+    for (int k = 0; k < 9; k++) p.R[k] = s.depth_to_color.rotation[k];
+    for (int k = 0; k < 3; k++) p.t[k] = s.depth_to_color.translation[k];
+    p.depth_scale = s.depth_scale;
+    p.d_ppx = s.depth.ppx; p.d_ppy = s.depth.ppy; p.d_fx = s.depth.fx; p.d_fy = s.depth.fy;
+    p.c_fx = s.color.fx; p.c_fy = s.color.fy; p.c_ppx = s.color.ppx; p.c_ppy = s.color.ppy;
+    p.c_w_f = (float)s.color.width; p.c_h_f = (float)s.color.height;
+    for (int k = 0; k < 5; k++) { p.dk[k] = s.depth.coeffs[k]; p.ck[k] = s.color.coeffs[k]; }
+    p.W = s.depth.width; p.H = s.depth.height;
+    p.cW = s.color.width; p.cH = s.color.height;
+    p.bpp = s.color_bpp; p.stride = s.color_stride;
+    p.color_bytes = (uint32_t)((uint64_t)s.color_stride * (uint64_t)s.color.height);
+    p.n_points = (uint32_t)s.depth.width * (uint32_t)s.depth.height;
+    p.ddist = (s.depth.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.depth)) ? 1 : 0;
+    p.cdist = (s.color.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.color)) ? 1 : 0;
+}
+
+inline uint32_t tiles_of(uint32_t n) { return (n + kTilePoints - 1) / kTilePoints; }
+inline bool has_pred(uint32_t flags) { return (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0; }
+
+template <class T>
+int ensure(pcs_ctx* c, T*& p, size_t& cap, size_t bytes)
+{
+    if (bytes <= cap && p) return PCS_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 256));
+    if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    p = static_cast<T*>(q);
+    cap = std::max<size_t>(bytes, 256);
+    return PCS_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int acquire_event_pair(pcs_ctx* c, std::pair<hipEvent_t, hipEvent_t>& pr)
+{
+    if (!c->ev_free.empty()) { pr = c->ev_free.back(); c->ev_free.pop_back(); return PCS_OK; }
+    HIPCHK(c, hipEventCreate(&pr.first));
+    HIPCHK(c, hipEventCreate(&pr.second));
+    return PCS_OK;
+}
+
+// The fused path for device-resident rasters. Counts end up in d_counts (if non-null).
+int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts)
+{
+    if (payload_shorts < c->max_payload_points * PCS_POINT_SHORTS && !has_pred(c->flags))
+        return fail(c, PCS_ERR_CAPACITY, "payload buffer holds %zu shorts, %zu needed", payload_shorts,
+                    c->max_payload_points * PCS_POINT_SHORTS);
+    if (has_pred(c->flags) && payload_shorts < c->max_payload_points * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "payload buffer holds %zu shorts; with compaction the worst case "
+                    "%zu is required", payload_shorts, c->max_payload_points * PCS_POINT_SHORTS);
+    if (((uintptr_t)d_payload & 1u) != 0) return fail(c, PCS_ERR_INVALID_ARG, "payload pointer must be 2-byte aligned");
+
+    const bool pred = has_pred(c->flags);
+    const bool dense = !pred && c->downsample == 1 && c->dense_ok && (((uintptr_t)d_payload & 15u) == 0);
+    std::pair<hipEvent_t, hipEvent_t> ev{};
+    if (c->kernel_timing) {
+        int rc = acquire_event_pair(c, ev);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(ev.first, c->stream));
+    }
+    if (pred) {
+        for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
+            const int nl = std::min(kLaunchStreams, c->n_streams - s0);
+            FramePtrs fp{};
+            uint32_t mp = 0;
+            for (int k = 0; k < nl; k++) { fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k]; mp = std::max(mp, c->h_params[s0 + k].n_points); }
+            HIPCHK(c, launch_fused_count(c->d_params, s0, nl, mp, c->flags, fp, c->d_tile_counts, c->stream));
+        }
+        HIPCHK(c, launch_scan(c->d_params, c->n_streams, c->downsample, c->d_tile_counts, c->d_tile_prefix,
+                              c->d_stream_base, d_counts ? d_counts : c->d_counts, c->stream));
+    }
+    for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
+        const int nl = std::min(kLaunchStreams, c->n_streams - s0);
+        FramePtrs fp{};
+        uint32_t mp = 0;
+        for (int k = 0; k < nl; k++) { fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k]; mp = std::max(mp, c->h_params[s0 + k].n_points); }
+        if (dense)
+            HIPCHK(c, launch_fused_dense(c->d_params, s0, nl, mp, c->any_ddist, c->any_cdist, fp, d_payload, c->stream));
+        else
+            HIPCHK(c, launch_fused_emit(c->d_params, s0, nl, mp, c->flags, c->downsample, fp, c->d_tile_prefix,
+                                        c->d_stream_base, d_payload, c->stream));
+    }
+    if (!pred && d_counts) {
+        // counts are host-known; give the caller the same table the scan would have written
+        std::vector<int32_t> h(c->n_streams + 1);
+        int64_t tot = 0;
+        for (int s = 0; s < c->n_streams; s++) {
+            h[s] = (int32_t)((c->h_params[s].n_points + c->downsample - 1) / c->downsample);
+            tot += h[s];
+        }
+        h[c->n_streams] = (int32_t)tot;
+        HIPCHK(c, hipMemcpyAsync(d_counts, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+    }
+    if (c->kernel_timing) {
+        HIPCHK(c, hipEventRecord(ev.second, c->stream));
+        c->ev_pool.push_back(ev);
+    }
+    return PCS_OK;
+}
+
+int upload_params(pcs_ctx* c)
+{
+    HIPCHK(c, hipMemcpy(c->d_params, c->h_params.data(), c->h_params.size() * sizeof(StreamParams), hipMemcpyHostToDevice));
+    return PCS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcs_abi_version(void) { return PCS_ABI_VERSION; }
+
+int pcs_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return 0;
+    return n;
+}
+
+const char* pcs_strerror(int status)
+{
+    switch (status) {
+        case PCS_OK:              return "ok";
+        case PCS_ERR_INVALID_ARG: return "invalid argument";
+        case PCS_ERR_NO_DEVICE:   return "no usable HIP device (libpcs_hip has no CPU fallback)";
+        case PCS_ERR_HIP:         return "HIP runtime error";
+        case PCS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case PCS_ERR_CAPACITY:    return "caller buffer too small";
+        case PCS_ERR_NOMEM:       return "out of device memory";
+        default:                  return "unknown status";
+    }
+}
+
+const char* pcs_last_error(const pcs_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int pcs_create(pcs_ctx** out, const pcs_config* cfg)
+{
+    g_create_err.clear();
+    if (!out) return fail(nullptr, PCS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!cfg || !cfg->streams) return fail(nullptr, PCS_ERR_INVALID_ARG, "config / streams is NULL");
+    if (cfg->n_streams < 1 || cfg->n_streams > PCS_MAX_STREAMS)
+        return fail(nullptr, PCS_ERR_INVALID_ARG, "n_streams %d outside 1..%d", cfg->n_streams, PCS_MAX_STREAMS);
+    if (cfg->downsample < 1) return fail(nullptr, PCS_ERR_INVALID_ARG, "downsample %d < 1", cfg->downsample);
+    if (cfg->flags & ~(PCS_FLAG_CUTOFF | PCS_FLAG_CUTOFF_COMPAT | PCS_FLAG_DROP_INVALID))
+        return fail(nullptr, PCS_ERR_INVALID_ARG, "unknown flag bits 0x%x", cfg->flags);
+    if ((cfg->flags & PCS_FLAG_CUTOFF_COMPAT) && !(cfg->flags & PCS_FLAG_CUTOFF))
+        return fail(nullptr, PCS_ERR_INVALID_ARG, "PCS_FLAG_CUTOFF_COMPAT needs PCS_FLAG_CUTOFF");
+    for (int s = 0; s < cfg->n_streams; s++) {
+        int rc = validate_stream(cfg->streams[s], s);
+        if (rc) return rc;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PCS_ERR_NO_DEVICE, "hipGetDeviceCount: %s (%d devices) — libpcs_hip needs an AMD GPU; "
+                    "there is no CPU fallback", hipGetErrorString(e), ndev);
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, PCS_ERR_NO_DEVICE, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+
+    pcs_ctx* c = new (std::nothrow) pcs_ctx;
+    if (!c) return fail(nullptr, PCS_ERR_NOMEM, "host allocation failed");
+    c->device = cfg->device;
+    c->n_streams = cfg->n_streams;
+    c->flags = cfg->flags;
+    c->downsample = cfg->downsample;
+    c->cfg.assign(cfg->streams, cfg->streams + cfg->n_streams);
+    c->h_params.resize(c->n_streams);
+    c->d_lut.assign(2 * (size_t)c->n_streams, nullptr);
+    c->s_depth.assign(c->n_streams, nullptr); c->s_color.assign(c->n_streams, nullptr);
+    c->s_depth_cap.assign(c->n_streams, 0);   c->s_color_cap.assign(c->n_streams, 0);
+
+#define CREATE_CHK(expr)                                                                             \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            int _rc = fail(nullptr, PCS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));     \
+            pcs_destroy(c);                                                                          \
+            return _rc;                                                                              \
+        }                                                                                            \
+    } while (0)
+
+    DeviceGuard guard(c->device);
+    CREATE_CHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CREATE_CHK(hipEventCreate(&c->ev_begin));
+    CREATE_CHK(hipEventCreate(&c->ev_end));
+    CREATE_CHK(hipMalloc((void**)&c->d_params, sizeof(StreamParams) * c->n_streams));
+
+    uint32_t out_base = 0, tile_base = 0;
+    c->dense_ok = true;
+    for (int s = 0; s < c->n_streams; s++) {
+        StreamParams& p = c->h_params[s];
+        std::memset(&p, 0, sizeof p);
+        fill_params(c->cfg[s], p);
+        p.out_base = out_base;
+        p.tile_base = tile_base;
+        out_base += (p.n_points + c->downsample - 1) / c->downsample;
+        tile_base += tiles_of(p.n_points);
+        if (p.n_points % 8) c->dense_ok = false;
+        c->any_ddist |= p.ddist != 0;
+        c->any_cdist |= p.cdist != 0;
+        c->max_points = std::max(c->max_points, p.n_points);
+        // deprojection LUTs: the IEEE divisions of rs2_deproject_pixel_to_point, once per column / row
+        std::vector<float> mx(p.W), my(p.H);
+        for (int x = 0; x < p.W; x++) mx[x] = ((float)x - p.d_ppx) / p.d_fx;
+        for (int y = 0; y < p.H; y++) my[y] = ((float)y - p.d_ppy) / p.d_fy;
+        float *dmx = nullptr, *dmy = nullptr;
+        CREATE_CHK(hipMalloc((void**)&dmx, sizeof(float) * ((size_t)p.W + 8)));
+        c->d_lut[2 * s] = dmx;
+        CREATE_CHK(hipMalloc((void**)&dmy, sizeof(float) * ((size_t)p.H + 8)));
+        c->d_lut[2 * s + 1] = dmy;
+        CREATE_CHK(hipMemcpy(dmx, mx.data(), sizeof(float) * p.W, hipMemcpyHostToDevice));
+        CREATE_CHK(hipMemcpy(dmy, my.data(), sizeof(float) * p.H, hipMemcpyHostToDevice));
+        p.mx = dmx; p.my = dmy;
+    }
+    c->max_payload_points = out_base;
+    c->total_tiles = tile_base;
+    CREATE_CHK(hipMalloc((void**)&c->d_tile_counts, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
+    CREATE_CHK(hipMalloc((void**)&c->d_tile_prefix, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
+    CREATE_CHK(hipMalloc((void**)&c->d_stream_base, sizeof(uint32_t) * (c->n_streams + 1)));
+    CREATE_CHK(hipMalloc((void**)&c->d_counts, sizeof(int32_t) * (c->n_streams + 1)));
+    CREATE_CHK(hipMemcpy(c->d_params, c->h_params.data(), sizeof(StreamParams) * c->n_streams, hipMemcpyHostToDevice));
+#undef CREATE_CHK
+    *out = c;
+    return PCS_OK;
+}
+
+void pcs_destroy(pcs_ctx* c)
+{
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (float* p : c->d_lut) if (p) (void)hipFree(p);
+    for (auto* p : c->s_depth) if (p) (void)hipFree(p);
+    for (auto* p : c->s_color) if (p) (void)hipFree(p);
+    void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
+                       c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
+    for (void* p : singles) if (p) (void)hipFree(p);
+    for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : c->ev_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pcs_set_cam_to_world(pcs_ctx* c, int stream, const float m16[16])
+{
+    if (!c || !m16) return PCS_ERR_INVALID_ARG;
+    if (stream < 0 || stream >= c->n_streams) return fail(c, PCS_ERR_INVALID_ARG, "stream %d out of range", stream);
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(c->cfg[stream].cam_to_world, m16, sizeof(float) * 16);
+    for (int k = 0; k < 12; k++) c->h_params[stream].M[k] = m16[k];
+    return upload_params(c);
+}
+
+int pcs_stream_points(const pcs_ctx* c, int stream)
+{
+    if (!c || stream < 0 || stream >= c->n_streams) return PCS_ERR_INVALID_ARG;
+    return (int)c->h_params[stream].n_points;
+}
+
+size_t pcs_max_payload_shorts(const pcs_ctx* c)
+{
+    return c ? c->max_payload_points * PCS_POINT_SHORTS : 0;
+}
+
+// ---- a2 twin ---------------------------------------------------------------------------------
+int pcs_copy_pointcloud_xyzrgb_to_buffer_device(pcs_ctx* c, int stream, const float* d_vertices,
+                                                const float* d_texcoords, int n_points, const uint8_t* d_color,
+                                                int16_t* d_pc_buffer, int* d_out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (stream < 0 || stream >= c->n_streams) return fail(c, PCS_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
+    if (n_points > 0 && (!d_vertices || !d_texcoords || !d_color || !d_pc_buffer))
+        return fail(c, PCS_ERR_INVALID_ARG, "NULL device pointer");
+    if (((uintptr_t)d_pc_buffer & 1u) || ((uintptr_t)d_vertices & 3u) || ((uintptr_t)d_texcoords & 3u))
+        return fail(c, PCS_ERR_INVALID_ARG, "misaligned device pointer");
+    DeviceGuard guard(c->device);
+    if (n_points == 0) {
+        if (d_out_points) HIPCHK(c, hipMemsetAsync(d_out_points, 0, sizeof(int), c->stream));
+        return PCS_OK;
+    }
+    const bool pred = has_pred(c->flags);
+    VertexPtrs vp{d_vertices, d_texcoords, d_color, (uint32_t)n_points};
+    if (!pred) {
+        if (((uintptr_t)d_pc_buffer & 15u) == 0)
+            HIPCHK(c, launch_pack_dense(c->d_params, stream, vp, d_pc_buffer, c->stream));
+        else
+            HIPCHK(c, launch_pack_emit(c->d_params, stream, vp, 0u, nullptr, d_pc_buffer, c->stream));
+        if (d_out_points)
+            HIPCHK(c, hipMemcpyAsync(d_out_points, &vp.n_points, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (d_out_points) HIPCHK(c, hipStreamSynchronize(c->stream));
+        return PCS_OK;
+    }
+    const uint32_t tiles = std::max<uint32_t>(tiles_of((uint32_t)n_points), 1);
+    if (tiles > c->s_pack_tiles) {
+        if (c->s_pack_counts) (void)hipFree(c->s_pack_counts);
+        if (c->s_pack_prefix) (void)hipFree(c->s_pack_prefix);
+        c->s_pack_counts = c->s_pack_prefix = nullptr; c->s_pack_tiles = 0;
+        HIPCHK(c, hipMalloc((void**)&c->s_pack_counts, sizeof(uint32_t) * tiles));
+        HIPCHK(c, hipMalloc((void**)&c->s_pack_prefix, sizeof(uint32_t) * tiles));
+        c->s_pack_tiles = tiles;
+    }
+    HIPCHK(c, launch_pack_count(c->d_params, stream, vp, c->flags, c->s_pack_counts, c->stream));
+    HIPCHK(c, launch_pack_scan(tiles_of((uint32_t)n_points), c->s_pack_counts, c->s_pack_prefix, c->d_counts, c->stream));
+    HIPCHK(c, launch_pack_emit(c->d_params, stream, vp, c->flags, c->s_pack_prefix, d_pc_buffer, c->stream));
+    if (d_out_points)
+        HIPCHK(c, hipMemcpyAsync(d_out_points, c->d_counts, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    return PCS_OK;
+}
+
+int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* c, int stream, const float* vertices, const float* texcoords,
+                                         int n_points, const uint8_t* color, int16_t* pc_buffer, int* out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (stream < 0 || stream >= c->n_streams) return fail(c, PCS_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
+    if (n_points > 0 && (!vertices || !texcoords || !color || !pc_buffer))
+        return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (n_points == 0) { if (out_points) *out_points = 0; return PCS_OK; }
+    DeviceGuard guard(c->device);
+    const StreamParams& P = c->h_params[stream];
+    const size_t vb = (size_t)n_points * 3 * sizeof(float), tb = (size_t)n_points * 2 * sizeof(float);
+    const size_t ob = (size_t)n_points * PCS_POINT_BYTES;
+    int rc;
+    if ((rc = ensure(c, c->s_vertices, c->s_vertices_cap, vb))) return rc;
+    if ((rc = ensure(c, c->s_texcoords, c->s_texcoords_cap, tb))) return rc;
+    if ((rc = ensure(c, c->s_color[stream], c->s_color_cap[stream], P.color_bytes))) return rc;
+    if ((rc = ensure(c, c->s_payload, c->s_payload_cap, ob + 16))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_vertices, vertices, vb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_texcoords, texcoords, tb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_color[stream], color, P.color_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = pcs_copy_pointcloud_xyzrgb_to_buffer_device(c, stream, c->s_vertices, c->s_texcoords, n_points,
+                                                     c->s_color[stream], c->s_payload, nullptr);
+    if (rc) return rc;
+    int count = n_points;
+    if (has_pred(c->flags)) {
+        HIPCHK(c, hipMemcpyAsync(&count, c->d_counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (count > 0)
+        HIPCHK(c, hipMemcpyAsync(pc_buffer, c->s_payload, (size_t)count * PCS_POINT_BYTES, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_points) *out_points = count;
+    return PCS_OK;
+}
+
+// ---- a1 twin ---------------------------------------------------------------------------------
+int pcs_send_xyzrgb_pointcloud(pcs_ctx* c, int stream, const float* vertices, const float* texcoords, int n_points,
+                               const uint8_t* color, int16_t* buffer, size_t buffer_shorts, int write_header,
+                               int* out_size_bytes)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!buffer) return fail(c, PCS_ERR_INVALID_ARG, "buffer is NULL");
+    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
+    const size_t need = PCS_HEADER_SHORTS + (size_t)n_points * PCS_POINT_SHORTS;
+    if (buffer_shorts < need)
+        return fail(c, PCS_ERR_CAPACITY, "buffer holds %zu shorts, %zu needed (the reference's BUF_SIZE of %d shorts "
+                    "overflows beyond 999 999 points)", buffer_shorts, need, PCS_REF_BUF_SIZE);
+    int count = 0;
+    int rc = pcs_copy_pointcloud_xyzrgb_to_buffer(c, stream, vertices, texcoords, n_points, color,
+                                                  buffer + PCS_HEADER_SHORTS, &count);
+    if (rc) return rc;
+    const int32_t size = (int32_t)((size_t)count * PCS_POINT_BYTES);                     // :697
+    // :673 — everything below BUF_SIZE bytes that the payload does not cover reads as zero
+    const size_t clear_end = std::min<size_t>(PCS_REF_BUF_SIZE, buffer_shorts * sizeof(int16_t));
+    uint8_t* b = reinterpret_cast<uint8_t*>(buffer);
+    std::memset(b, 0, std::min<size_t>(4, clear_end));
+    const size_t pay_end = 4 + (size_t)size;
+    if (pay_end < clear_end) std::memset(b + pay_end, 0, clear_end - pay_end);
+    if (write_header) std::memcpy(b, &size, sizeof size);                                 // :718
+    if (out_size_bytes) *out_size_bytes = size;
+    return PCS_OK;
+}
+
+// ---- fused a5+a2(+a7) ------------------------------------------------------------------------
+int pcs_process_frames_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                              int16_t* d_payload, size_t payload_shorts, int32_t* d_counts)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!d_depth || !d_color || !d_payload) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    for (int s = 0; s < c->n_streams; s++)
+        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+    for (int s = 0; s < c->n_streams; s++)
+        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
+    DeviceGuard guard(c->device);
+    return run_fused_device(c, d_depth, d_color, d_payload, payload_shorts, d_counts);
+}
+
+int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* const* color, int16_t* stitched,
+                       size_t stitched_shorts, int write_header, int* points_per_stream, int* out_size_bytes)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!depth || !color || !stitched) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    DeviceGuard guard(c->device);
+    int rc;
+    for (int s = 0; s < c->n_streams; s++) {
+        if (!depth[s] || !color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+        const StreamParams& P = c->h_params[s];
+        const size_t db = (size_t)P.n_points * sizeof(uint16_t);
+        if ((rc = ensure(c, c->s_depth[s], c->s_depth_cap[s], db + 16))) return rc;
+        if ((rc = ensure(c, c->s_color[s], c->s_color_cap[s], P.color_bytes))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->s_depth[s], depth[s], db, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->s_color[s], color[s], P.color_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    const size_t max_bytes = c->max_payload_points * PCS_POINT_BYTES;
+    if ((rc = ensure(c, c->s_payload, c->s_payload_cap, max_bytes + 16))) return rc;
+    rc = run_fused_device(c, c->s_depth.data(), c->s_color.data(), c->s_payload, c->max_payload_points * PCS_POINT_SHORTS,
+                          c->d_counts);
+    if (rc) return rc;
+    std::vector<int32_t> h(c->n_streams + 1);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t total = (size_t)h[c->n_streams];
+    if (stitched_shorts < PCS_HEADER_SHORTS + total * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "stitched buffer holds %zu shorts, %zu needed", stitched_shorts,
+                    PCS_HEADER_SHORTS + total * PCS_POINT_SHORTS);
+    if (total)
+        HIPCHK(c, hipMemcpy(stitched + PCS_HEADER_SHORTS, c->s_payload, total * PCS_POINT_BYTES, hipMemcpyDeviceToHost));
+    const int32_t size = (int32_t)(total * PCS_POINT_BYTES);
+    if (write_header) std::memcpy(stitched, &size, sizeof size);   // src/pcs-multicamera-client.cpp:394-395
+    if (points_per_stream) for (int s = 0; s < c->n_streams; s++) points_per_stream[s] = h[s];
+    if (out_size_bytes) *out_size_bytes = size;
+    return PCS_OK;
+}
+
+int pcs_deproject(pcs_ctx* c, int stream, const uint16_t* depth, float* vertices, float* texcoords)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (stream < 0 || stream >= c->n_streams) return fail(c, PCS_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (!depth || !vertices || !texcoords) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    DeviceGuard guard(c->device);
+    const StreamParams& P = c->h_params[stream];
+    const size_t n = P.n_points;
+    int rc;
+    if ((rc = ensure(c, c->s_depth[stream], c->s_depth_cap[stream], n * sizeof(uint16_t) + 16))) return rc;
+    if ((rc = ensure(c, c->s_vertices, c->s_vertices_cap, n * 3 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->s_texcoords, c->s_texcoords_cap, n * 2 * sizeof(float)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_depth[stream], depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_deproject(c->d_params, stream, P.n_points, c->s_depth[stream], c->s_vertices, c->s_texcoords, c->stream));
+    HIPCHK(c, hipMemcpyAsync(vertices, c->s_vertices, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(texcoords, c->s_texcoords, n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PCS_OK;
+}
+
+// ---- a7 --------------------------------------------------------------------------------------
+int pcs_stitch_device(pcs_ctx* c, const int16_t* const* d_cam_payload, const int* cam_points, int n_cams,
+                      int downsample, int16_t* d_stitched_payload, size_t stitched_shorts, int* total_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_cams < 0 || (n_cams > 0 && (!d_cam_payload || !cam_points || !d_stitched_payload)))
+        return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (downsample < 1) return fail(c, PCS_ERR_INVALID_ARG, "downsample %d < 1", downsample);
+    DeviceGuard guard(c->device);
+    size_t need = 0;
+    for (int i = 0; i < n_cams; i++) {
+        if (cam_points[i] < 0) return fail(c, PCS_ERR_INVALID_ARG, "camera %d: negative point count", i);
+        need += ((size_t)cam_points[i] + downsample - 1) / downsample;
+    }
+    if (stitched_shorts < need * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "stitched payload holds %zu shorts, %zu needed", stitched_shorts, need * PCS_POINT_SHORTS);
+    size_t out = 0;
+    for (int i = 0; i < n_cams; i++) {
+        const size_t kept = ((size_t)cam_points[i] + downsample - 1) / downsample;
+        if (!kept) continue;
+        if (downsample == 1)
+            HIPCHK(c, hipMemcpyAsync(d_stitched_payload + out * PCS_POINT_SHORTS, d_cam_payload[i],
+                                     kept * PCS_POINT_BYTES, hipMemcpyDeviceToDevice, c->stream));
+        else
+            HIPCHK(c, launch_stitch(d_cam_payload[i], (uint32_t)cam_points[i], downsample,
+                                    d_stitched_payload + out * PCS_POINT_SHORTS, c->stream));
+        out += kept;
+    }
+    if (total_points) *total_points = (int)out;
+    return PCS_OK;
+}
+
+// ---- plumbing --------------------------------------------------------------------------------
+int pcs_set_stream(pcs_ctx* c, void* hip_stream)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PCS_OK;
+}
+
+void* pcs_get_stream(pcs_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int pcs_synchronize(pcs_ctx* c)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PCS_OK;
+}
+
+int pcs_timer_begin(pcs_ctx* c)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipEventRecord(c->ev_begin, c->stream));
+    return PCS_OK;
+}
+
+int pcs_timer_end(pcs_ctx* c)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipEventRecord(c->ev_end, c->stream));
+    return PCS_OK;
+}
+
+int pcs_timer_elapsed_ms(pcs_ctx* c, float* ms)
+{
+    if (!c || !ms) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipEventSynchronize(c->ev_end));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
+    return PCS_OK;
+}
+
+int pcs_kernel_timing(pcs_ctx* c, int enable)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    c->kernel_timing = enable != 0;
+    return PCS_OK;
+}
+
+int pcs_kernel_times_ms(pcs_ctx* c, float* ms, int capacity, int* n)
+{
+    if (!c || !n || (capacity > 0 && !ms)) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int k = 0;
+    for (auto& pr : c->ev_pool) {
+        if (k < capacity) HIPCHK(c, hipEventElapsedTime(&ms[k], pr.first, pr.second));
+        k++;
+        c->ev_free.push_back(pr);
+    }
+    c->ev_pool.clear();
+    *n = k;
+    return PCS_OK;
+}
+
+int pcs_device_malloc(pcs_ctx* c, void** d_ptr, size_t bytes)
+{
+    if (!c || !d_ptr) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    hipError_t e = hipMalloc(d_ptr, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return PCS_OK;
+}
+
+int pcs_device_free(pcs_ctx* c, void* d_ptr)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_ptr));
+    return PCS_OK;
+}
+
+int pcs_memcpy_h2d(pcs_ctx* c, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PCS_OK;
+}
+
+int pcs_memcpy_d2h(pcs_ctx* c, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// pcs_device.h — structures shared by the HIP kernels (pcs_kernels.hip) and the C-ABI host layer
+// (pcs_capi.cpp). Internal; the public surface is include/pcs_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcs_hip.h"
+
+namespace pcs {
+
+// Geometry of one launch tile: a 256-thread workgroup owns 2048 consecutive points of one stream,
+// 8 consecutive points per lane, 512 per wavefront.
+constexpr int      kBlockThreads   = 256;
+constexpr int      kPointsPerLane  = 8;
+constexpr uint32_t kTilePoints     = kBlockThreads * kPointsPerLane;   // 2048
+constexpr int      kLaunchStreams  = 16;                               // streams per launch (blockIdx.y)
+
+// Per-stream constants. One table entry per camera, uploaded at pcs_create / pcs_set_cam_to_world.
+// Every field is wave-uniform (indexed by blockIdx.y), so the kernels read them with scalar loads
+// and they live in SGPRs — the CDNA counterpart of the reference's broadcast __m128 globals
+// (src/pcs-camera-optimized.cpp:69-72, 390-408).
+struct alignas(16) StreamParams {
+    float    M[12];          // top three rows of cam_to_world (tf_mat), row-major
+    float    R[9];           // depth->colour rotation, column-major (rs2_extrinsics)
+    float    t[3];           // depth->colour translation
+    float    depth_scale;
+    float    d_ppx, d_ppy, d_fx, d_fy;
+    float    c_fx, c_fy, c_ppx, c_ppy;
+    float    c_w_f, c_h_f;   // (float)colour width / height
+    float    dk[5];          // depth distortion coefficients
+    float    ck[5];          // colour distortion coefficients
+    int32_t  W, H;           // depth raster
+    int32_t  cW, cH;         // colour raster
+    int32_t  bpp, stride;    // colour bytes per pixel / per row
+    uint32_t color_bytes;    // stride * cH
+    uint32_t n_points;       // W * H
+    int32_t  ddist, cdist;   // distortion active (non-zero coefficients)
+    uint32_t out_base;       // first output point of this stream in the stitched payload when no
+                             // predicate is active: sum over earlier streams of ceil(n/downsample)
+    uint32_t tile_base;      // index of this stream's first tile in the per-tile count arrays
+    const float* mx;         // [W]  (c - ppx) / fx   — IEEE division done once on the host
+    const float* my;         // [H]  (r - ppy) / fy
+};
+
+// Per-call raster pointers, passed by value in the kernarg segment (no per-frame H2D of a table).
+struct FramePtrs {
+    const uint16_t* depth[kLaunchStreams];
+    const uint8_t*  color[kLaunchStreams];
+};
+
+struct VertexPtrs {          // a2 twin: one stream per launch
+    const float*   vertices;   // n x {x,y,z}
+    const float*   texcoords;  // n x {u,v}
+    const uint8_t* color;
+    uint32_t       n_points;
+};
+
+// Launchers (defined in pcs_kernels.hip). All enqueue on `st` and return the hipError of the launch.
+hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                              bool any_ddist, bool any_cdist, const FramePtrs& fp, int16_t* d_payload,
+                              hipStream_t st);
+
+// Generic path: predicate / downsample / unaligned payload / W % 8 != 0.
+//   d_tile_counts, d_tile_prefix : one uint32 per tile of every stream (StreamParams::tile_base indexes them)
+//   d_stream_base                : n_total_streams + 1 uint32 (output point offsets; last = total)
+//   d_counts (optional)          : n_total_streams + 1 int32 handed back to the caller
+// launch_pack_scan: d_out_points receives 2 int32 (kept, total)
+hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                              uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st);
+hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsample,
+                       const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_base,
+                       int32_t* d_counts, hipStream_t st);
+hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                             uint32_t flags, int downsample, const FramePtrs& fp,
+                             const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
+                             int16_t* d_payload, hipStream_t st);
+
+// a2 twin.
+hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const VertexPtrs& vp,
+                             int16_t* d_out, hipStream_t st);
+hipError_t launch_pack_count(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
+                             uint32_t* d_tile_counts, hipStream_t st);
+hipError_t launch_pack_scan(uint32_t n_tiles, const uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
+                            int32_t* d_out_points, hipStream_t st);
+hipError_t launch_pack_emit(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
+                            const uint32_t* d_tile_prefix, int16_t* d_out, hipStream_t st);
+
+// a5 alone.
+hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n_points, const uint16_t* d_depth,
+                            float* d_vertices, float* d_texcoords, hipStream_t st);
+
+// a7 with stride.
+hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,
+                         int16_t* d_dst, hipStream_t st);
+
+}  // namespace pcs

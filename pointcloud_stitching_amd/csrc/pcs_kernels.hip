@@ -1,0 +1,772 @@
+// pcs_kernels.hip — hand-written gfx950 (CDNA4) kernels for the deproject -> rigid transform ->
+// RGB attach -> XYZRGB int16 pack hot path of conix-center/pointcloud_stitching.
+//
+// What is replaced (reference file:line, read for behaviour only):
+//   a5 rs2::pointcloud::calculate/map_to   call sites src/pcs-camera-optimized.cpp:198-199, 288-289
+//   a2 copyPointCloudXYZRGBToBufferSIMD    src/pcs-camera-optimized.cpp:363-616
+//   a7 sendStitchToUnity's concatenate     src/pcs-multicamera-client.cpp:385-392
+//
+// Shape of the work: per point ~15 algorithmic bytes (2 B Z16 in, 3 B RGB in, 10 B out) against a few
+// dozen FP32 ops -> HBM-bound, no MFMA. What matters on CDNA4:
+//   * every global access is a lane-contiguous 16 B vector access: the Z16 raster is read as uint4
+//     (8 pixels / lane, 1 KiB / wavefront-instruction); the 10-byte records, which no lane can store
+//     on its own at a 16 B boundary, are transposed through LDS so a wavefront writes 5 x 1 KiB;
+//   * per-camera constants (3x4 extrinsic, 3x3+t depth->colour, intrinsics) are wave-uniform and sit
+//     in SGPRs via scalar loads; the per-column / per-row deprojection LUTs are L2-resident;
+//   * the colour gather is one (possibly unaligned) dword per point through L1/L2;
+//   * invalid-depth / cutoff compaction is order-preserving: per-lane popcount -> wavefront scan ->
+//     4-entry LDS cross-wave scan -> tile prefix from a count pass (deterministic, = `-c -m -t1` order).
+//
+// Bit-exactness: compiled with -ffp-contract=off; every fused op is an explicit __fmaf_rn and every
+// other product/sum/quotient is individually rounded (IEEE divide), mirroring oracle/pcs_oracle_impl.h.
+// Float->int follows x86 cvttss2si including its "integer indefinite" result for NaN / out of range,
+// which v_cvt_i32_f32 (saturating) does not give by itself.
+
+#include "pcs_device.h"
+
+namespace pcs {
+
+namespace {
+
+constexpr uint32_t kDenseStageBytes = kTilePoints * PCS_POINT_BYTES;        // 20 480 B -> 8 workgroups / CU
+constexpr uint32_t kStageBytes      = kTilePoints * PCS_POINT_BYTES + 32;   // + head skew + tail pad
+
+// Pointers that reach a kernel through memory (the StreamParams table) have no address space the
+// compiler can see and would be accessed with flat_load; they are always HBM, so say so.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class T> using gptr = const __attribute__((address_space(1))) T*;
+template <class T> __device__ __forceinline__ gptr<T> as_global(const T* p)
+{
+    return (gptr<T>)(uintptr_t)p;
+}
+
+struct PointIn {
+    float X, Y, Z;   // camera-frame vertex (rs2::vertex)
+    float u, v;      // texture coordinate  (rs2::texture_coordinate)
+};
+
+// cvttss2si / _mm_cvttps_epi32: truncate; NaN or |f| >= 2^31 -> 0x80000000.
+__device__ __forceinline__ int32_t cvtt_x86(float f)
+{
+    return (__builtin_fabsf(f) < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000;
+}
+
+// a2 colour lookup (src/pcs-camera-optimized.cpp:431-452, 584-585). Returns R | G<<8 | B<<16, which is
+// exactly shorts 3 and 4 of the record as one little-endian dword.
+__device__ __forceinline__ uint32_t color_word(const StreamParams& P, const uint8_t* __restrict__ color,
+                                               float u, float v)
+{
+    const float xf = __fmaf_rn(u, P.c_w_f, 0.5f);
+    const float yf = __fmaf_rn(v, P.c_h_f, 0.5f);
+    int32_t xi = cvtt_x86(xf), yi = cvtt_x86(yf);
+    xi = min(max(xi, 0), P.cW - 1);
+    yi = min(max(yi, 0), P.cH - 1);
+    // xi < 2^24, bpp small, yi < 2^24, stride < 2^24: 24-bit multiplies are exact in 32 bits and full rate
+    const uint32_t idx = __umul24((uint32_t)xi, (uint32_t)P.bpp) + __umul24((uint32_t)yi, (uint32_t)P.stride);
+    // One dword covers R,G,B. Never read past the raster: slide the window back at the very end.
+    const uint32_t off = min(idx, P.color_bytes - 4u);
+    uint32_t w;
+    __builtin_memcpy(&w, color + off, 4);
+    return (w >> ((idx - off) * 8u)) & 0x00FFFFFFu;
+}
+
+// a2 rigid transform + scale + truncate (src/pcs-camera-optimized.cpp:455-491, 581-583).
+// Order matters: x*col0 + t first, then + y*col1, then + z*col2; then a separately rounded * 1000.0f.
+__device__ __forceinline__ uint32_t world_mm16(const float* __restrict__ Mr, float X, float Y, float Z)
+{
+    float a = __fmaf_rn(X, Mr[0], Mr[3]);
+    a = __fmaf_rn(Y, Mr[1], a);
+    a = __fmaf_rn(Z, Mr[2], a);
+    a = __fmul_rn(a, 1000.0f);
+    return (uint32_t)cvtt_x86(a) & 0xFFFFu;
+}
+
+struct Record {              // one 10-byte point as three pieces
+    uint32_t xy;             // x | y << 16
+    uint32_t zc;             // z | (R | G<<8) << 16
+    uint32_t b;              // B            (low 16 bits valid)
+};
+
+__device__ __forceinline__ Record make_record(const StreamParams& P, const uint8_t* __restrict__ color,
+                                              const PointIn& p)
+{
+    const uint32_t x = world_mm16(P.M + 0, p.X, p.Y, p.Z);
+    const uint32_t y = world_mm16(P.M + 4, p.X, p.Y, p.Z);
+    const uint32_t z = world_mm16(P.M + 8, p.X, p.Y, p.Z);
+    const uint32_t w = color_word(P, color, p.u, p.v);
+    Record r;
+    r.xy = x | (y << 16);
+    r.zc = z | (w << 16);
+    r.b  = w >> 16;
+    return r;
+}
+
+// Brown-Conrady terms shared by deprojection (inverse model) and projection (modified model);
+// evaluation order as in librealsense's rsutil.h, each op rounded.
+__device__ __forceinline__ float bc_radial(const float* k, float r2)
+{
+    // 1 + k0*r2 + k1*r2*r2 + k4*r2*r2*r2, left to right
+    float f = __fadd_rn(1.0f, __fmul_rn(k[0], r2));
+    f = __fadd_rn(f, __fmul_rn(__fmul_rn(k[1], r2), r2));
+    f = __fadd_rn(f, __fmul_rn(__fmul_rn(__fmul_rn(k[4], r2), r2), r2));
+    return f;
+}
+// a + 2*kA*x*y + kB*(r2 + 2*a_axis*a_axis)
+__device__ __forceinline__ float bc_tangential(float a, float kA, float kB, float x, float y, float r2, float axis)
+{
+    float s = __fadd_rn(a, __fmul_rn(__fmul_rn(__fmul_rn(2.0f, kA), x), y));
+    return __fadd_rn(s, __fmul_rn(kB, __fadd_rn(r2, __fmul_rn(__fmul_rn(2.0f, axis), axis))));
+}
+
+// a5 for one pixel: depth value d, normalised ray (mx,my) from the LUTs.
+template <bool DDIST, bool CDIST>
+__device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32_t d, float mx, float my)
+{
+    const float z = __fmul_rn(P.depth_scale, (float)d);
+    if (DDIST && P.ddist) {   // template gate compiles it in; the per-stream flag is wave-uniform
+        const float r2 = __fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my));
+        const float f = bc_radial(P.dk, r2);
+        const float ux = bc_tangential(__fmul_rn(mx, f), P.dk[2], P.dk[3], mx, my, r2, mx);
+        const float uy = bc_tangential(__fmul_rn(my, f), P.dk[3], P.dk[2], mx, my, r2, my);
+        mx = ux; my = uy;
+    }
+    PointIn p;
+    p.X = __fmul_rn(z, mx);
+    p.Y = __fmul_rn(z, my);
+    p.Z = z;
+    // rs2_transform_point_to_point: R column-major, sums left to right
+    const float P0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[0], p.X), __fmul_rn(P.R[3], p.Y)), __fmul_rn(P.R[6], p.Z)), P.t[0]);
+    const float P1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[1], p.X), __fmul_rn(P.R[4], p.Y)), __fmul_rn(P.R[7], p.Z)), P.t[1]);
+    const float P2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[2], p.X), __fmul_rn(P.R[5], p.Y)), __fmul_rn(P.R[8], p.Z)), P.t[2]);
+    // rs2_project_point_to_pixel
+    float x = __fdiv_rn(P0, P2), y = __fdiv_rn(P1, P2);
+    if (CDIST && P.cdist) {
+        const float r2 = __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
+        const float f = bc_radial(P.ck, r2);
+        x = __fmul_rn(x, f); y = __fmul_rn(y, f);
+        const float dx = bc_tangential(x, P.ck[2], P.ck[3], x, y, r2, x);
+        const float dy = bc_tangential(y, P.ck[3], P.ck[2], x, y, r2, y);
+        x = dx; y = dy;
+    }
+    const float px = __fadd_rn(__fmul_rn(x, P.c_fx), P.c_ppx);
+    const float py = __fadd_rn(__fmul_rn(y, P.c_fy), P.c_ppy);
+    // pixel_to_texcoord; invalid depth (z == 0) -> texcoord (0,0)
+    const bool valid = (z != 0.0f);
+    p.u = valid ? __fdiv_rn(px, P.c_w_f) : 0.0f;
+    p.v = valid ? __fdiv_rn(py, P.c_h_f) : 0.0f;
+    return p;
+}
+
+// -c predicate on camera-frame z and x (src/pcs-camera-optimized.cpp:398-401, 504-511).
+__device__ __forceinline__ bool in_range(float X, float Z)
+{
+    return Z > 0.0f && Z <= 1.5f && X > -2.0f && X <= 2.0f;
+}
+
+// Keep mask for a lane's 8 consecutive points (point index i0 + k, i0 % 8 == 0).
+__device__ __forceinline__ uint32_t keep_mask8(const PointIn (&p)[8], uint32_t i0, uint32_t n, uint32_t flags)
+{
+    uint32_t rng = 0, nz = 0, live = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        rng  |= (uint32_t)in_range(p[k].X, p[k].Z) << k;
+        nz   |= (uint32_t)(p[k].Z != 0.0f) << k;
+        live |= (uint32_t)(i0 + k < n) << k;
+    }
+    uint32_t keep = live;
+    if (flags & PCS_FLAG_CUTOFF) {
+        uint32_t gate = rng;
+        if (flags & PCS_FLAG_CUTOFF_COMPAT) {
+            // the reference gates point k of each aligned group of four with point 3-k's test
+            // (lane-reversed mask, :501-502 vs :519); groups that run past n use their own test.
+            uint32_t rev = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rev |= ((rng >> ((k & 4) | (3 - (k & 3)))) & 1u) << k;
+            const uint32_t full_lo = (i0 + 3 < n) ? 0x0Fu : 0u;
+            const uint32_t full_hi = (i0 + 7 < n) ? 0xF0u : 0u;
+            const uint32_t full = full_lo | full_hi;
+            gate = (rev & full) | (rng & ~full);
+        }
+        keep &= gate;
+    }
+    if (flags & PCS_FLAG_DROP_INVALID) keep &= nz;
+    return keep;
+}
+
+// Wavefront-wide exclusive prefix sum of a small per-lane count (64 lanes).
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t c, uint32_t& wave_total)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t inc = c;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const uint32_t t = __shfl_up(inc, ofs, 64);
+        if (lane >= ofs) inc += t;
+    }
+    wave_total = __shfl(inc, 63, 64);
+    return inc - c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Point sources. A source hands each lane its 8 consecutive points of the tile.
+// ------------------------------------------------------------------------------------------------
+
+// Z16 raster + LUTs -> points (the fused a5 stage).
+template <bool DDIST, bool CDIST>
+struct DepthSource {
+    const uint16_t* __restrict__ depth;
+
+    __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8],
+                                          void* /*lds*/) const
+    {
+        if (i0 >= n) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) p[k] = PointIn{0, 0, 0, 0, 0};
+            return;
+        }
+        if ((P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0) {
+            // all 8 pixels on one raster row; one 16-byte depth load, two 16-byte LUT loads
+            const uint32_t r = i0 / (uint32_t)P.W;
+            const uint32_t c0 = i0 - r * (uint32_t)P.W;
+            const uint4 dv = *reinterpret_cast<const uint4*>(depth + i0);
+            const gptr<float> lut_x = as_global(P.mx);
+            const f32x4 ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
+            const f32x4 mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
+            const float my = as_global(P.my)[r];
+            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float mxs[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+                p[k] = deproject_pixel<DDIST, CDIST>(P, d, mxs[k], my);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t i = min(i0 + k, n - 1);
+                const uint32_t r = i / (uint32_t)P.W;
+                const uint32_t c = i - r * (uint32_t)P.W;
+                p[k] = deproject_pixel<DDIST, CDIST>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+            }
+        }
+    }
+    static constexpr bool kUsesLdsInput = false;
+};
+
+// rs2::points arrays (vertices + texcoords) -> points (the a2 twin's input).
+// The AoS arrays are pulled in with lane-contiguous 16-byte loads and transposed through LDS; a lane
+// then picks up its 8 points (96 B + 64 B) from LDS.
+struct VertexSource {
+    const float* __restrict__ vertices;
+    const float* __restrict__ texcoords;
+
+    static constexpr bool kUsesLdsInput = true;
+    static constexpr uint32_t kLdsFloats = kTilePoints * 5;   // 40 KiB
+
+    __device__ __forceinline__ void stage_tile(uint32_t tile0, uint32_t n, float* lds) const
+    {
+        const uint32_t pts = min(kTilePoints, n - tile0);
+        float* lv = lds;                      // [pts*3]
+        float* lt = lds + kTilePoints * 3;    // [pts*2]
+        const float* gv = vertices + (size_t)tile0 * 3;
+        const float* gt = texcoords + (size_t)tile0 * 2;
+        const uint32_t nv = pts * 3, nt = pts * 2;
+        if ((((uintptr_t)gv | (uintptr_t)gt) & 15) == 0) {
+            const uint32_t nv4 = nv >> 2, nt4 = nt >> 2;
+            for (uint32_t j = threadIdx.x; j < nv4; j += kBlockThreads)
+                reinterpret_cast<float4*>(lv)[j] = reinterpret_cast<const float4*>(gv)[j];
+            for (uint32_t j = threadIdx.x; j < nt4; j += kBlockThreads)
+                reinterpret_cast<float4*>(lt)[j] = reinterpret_cast<const float4*>(gt)[j];
+            for (uint32_t j = (nv4 << 2) + threadIdx.x; j < nv; j += kBlockThreads) lv[j] = gv[j];
+            for (uint32_t j = (nt4 << 2) + threadIdx.x; j < nt; j += kBlockThreads) lt[j] = gt[j];
+        } else {
+            for (uint32_t j = threadIdx.x; j < nv; j += kBlockThreads) lv[j] = gv[j];
+            for (uint32_t j = threadIdx.x; j < nt; j += kBlockThreads) lt[j] = gt[j];
+        }
+    }
+
+    __device__ __forceinline__ void load8(const StreamParams&, uint32_t i0, uint32_t n, PointIn (&p)[8],
+                                          void* lds) const
+    {
+        const float* lv = reinterpret_cast<const float*>(lds);
+        const float* lt = lv + kTilePoints * 3;
+        const uint32_t l0 = (threadIdx.x * kPointsPerLane);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k < n) {
+                const uint32_t j = l0 + k;
+                p[k] = PointIn{lv[3 * j], lv[3 * j + 1], lv[3 * j + 2], lt[2 * j], lt[2 * j + 1]};
+            } else {
+                p[k] = PointIn{0, 0, 0, 0, 0};
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Staged store: LDS bytes [head, head+nbytes) -> global bytes [g, g+nbytes), where (g - head) is
+// 16-byte aligned. Interior goes out as lane-contiguous 16-byte stores; the ragged ends (which may
+// share a 16-byte line with a neighbouring tile's bytes) go out as 2-byte stores.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, uint32_t nbytes, uint8_t* g)
+{
+    uint8_t* g0 = g - head;                                  // 16-byte aligned
+    const uint32_t end = head + nbytes;
+    const uint32_t first_full = (head + 15u) >> 4;           // first chunk entirely inside
+    const uint32_t last_full = end >> 4;                     // one past the last chunk entirely inside
+    for (uint32_t j = first_full + threadIdx.x; j < last_full; j += kBlockThreads)
+        reinterpret_cast<uint4*>(g0)[j] = reinterpret_cast<const uint4*>(lds)[j];
+    // ragged head: shorts in [head, min(first_full*16, end)); ragged tail: [max(last_full*16, head), end)
+    const uint32_t head_end = min(first_full << 4, end);
+    for (uint32_t b = head + 2u * threadIdx.x; b < head_end; b += 2u * kBlockThreads)
+        *reinterpret_cast<uint16_t*>(g0 + b) = *reinterpret_cast<const uint16_t*>(lds + b);
+    if (last_full >= first_full) {
+        const uint32_t tail_begin = max(last_full << 4, head_end);
+        for (uint32_t b = tail_begin + 2u * threadIdx.x; b < end; b += 2u * kBlockThreads)
+            *reinterpret_cast<uint16_t*>(g0 + b) = *reinterpret_cast<const uint16_t*>(lds + b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DENSE tile kernel: no predicate, downsample 1, 16-byte aligned payload, every stream's point count
+// a multiple of 8 (so every lane's 80-byte output run starts on a 16-byte boundary).
+// Lane l of the workgroup produces 8 records = 5 x uint4 and parks them at LDS[l*80]; the workgroup
+// then streams the tile's 20 480 bytes out with lane-contiguous 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+template <class Src>
+__device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src, const uint8_t* __restrict__ color,
+                                           uint32_t tile0, uint32_t n, uint8_t* __restrict__ out_bytes,
+                                           uint4* stage, void* lds_in)
+{
+    const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
+    PointIn p[8];
+    src.load8(P, i0, n, p, lds_in);
+    if (Src::kUsesLdsInput) __syncthreads();     // staging aliases the input region
+
+    uint32_t w[20];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const Record a = make_record(P, color, p[k]);
+        const Record b = make_record(P, color, p[k + 1]);
+        uint32_t* o = w + (k >> 1) * 5;
+        o[0] = a.xy;
+        o[1] = a.zc;
+        o[2] = (a.b & 0xFFFFu) | (b.xy << 16);
+        o[3] = (b.xy >> 16) | (b.zc << 16);
+        o[4] = (b.zc >> 16) | (b.b << 16);
+    }
+    uint4* mine = stage + threadIdx.x * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) mine[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    __syncthreads();
+
+    const uint32_t pts = min(kTilePoints, n - tile0);
+    store_staged(reinterpret_cast<const uint8_t*>(stage), 0u, pts * PCS_POINT_BYTES,
+                 out_bytes + (size_t)tile0 * PCS_POINT_BYTES);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GENERIC tile: predicate and/or downsample and/or unaligned payload. Order-preserving.
+//   g0        kept-index (within the stream) of the tile's first kept point
+//   out_first output point index (within the whole payload) of kept-index 0 of this stream
+// A kept point with kept-index g is written iff g % ds == 0, to output point out_first + g / ds.
+// ------------------------------------------------------------------------------------------------
+template <class Src, bool PRED>
+__device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& src, const uint8_t* __restrict__ color,
+                                             uint32_t tile0, uint32_t n, uint32_t flags, uint32_t ds,
+                                             uint32_t g0, uint32_t out_first, uint8_t* __restrict__ payload_bytes,
+                                             uint8_t* stage, uint32_t* wsum, void* lds_in)
+{
+    const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
+    PointIn p[8];
+    src.load8(P, i0, n, p, lds_in);
+
+    uint32_t keep, lane_first, tile_kept;
+    if (PRED) {
+        keep = keep_mask8(p, i0, n, flags);
+        uint32_t wave_total;
+        const uint32_t c = __popc(keep);
+        const uint32_t ex = wave_exclusive_scan(c, wave_total);
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) wsum[wave] = wave_total;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        tile_kept = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        lane_first = before + ex;
+    } else {
+        const uint32_t pts = min(kTilePoints, n - tile0);
+        const uint32_t mine = (i0 < n) ? min(8u, n - i0) : 0u;
+        keep = (1u << mine) - 1u;
+        lane_first = min(threadIdx.x * kPointsPerLane, pts);
+        tile_kept = pts;
+        if (Src::kUsesLdsInput) __syncthreads();
+    }
+
+    // output range of the tile, in points: q = out_first + ceil(g/ds) for g in [g0, g0 + tile_kept)
+    const uint32_t q_lo = out_first + (g0 + ds - 1) / ds;
+    const uint32_t q_hi = out_first + (g0 + tile_kept + ds - 1) / ds;
+    uint8_t* gdst = payload_bytes + (size_t)q_lo * PCS_POINT_BYTES;
+    const uint32_t head = (uint32_t)((uintptr_t)gdst & 15u);
+
+    uint32_t g = g0 + lane_first;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if ((keep >> k) & 1u) {
+            if (g % ds == 0) {
+                const Record r = make_record(P, color, p[k]);
+                const uint32_t q = out_first + g / ds;
+                uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + (q - q_lo) * PCS_POINT_BYTES);
+                o[0] = (uint16_t)r.xy; o[1] = (uint16_t)(r.xy >> 16);
+                o[2] = (uint16_t)r.zc; o[3] = (uint16_t)(r.zc >> 16);
+                o[4] = (uint16_t)r.b;
+            }
+            g++;
+        }
+    }
+    __syncthreads();
+    store_staged(stage, head, (q_hi - q_lo) * PCS_POINT_BYTES, gdst);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+
+template <bool DDIST, bool CDIST>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp,
+                            uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ uint4 stage[kDenseStageBytes / 16];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[stream0 + s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    DepthSource<DDIST, CDIST> src{fp.depth[s]};
+    dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
+}
+
+template <bool DDIST, bool CDIST>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
+                            uint32_t* __restrict__ tile_counts)
+{
+    __shared__ uint32_t wsum[4];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[stream0 + s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    DepthSource<DDIST, CDIST> src{fp.depth[s]};
+    PointIn p[8];
+    const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
+    src.load8(P, i0, n, p, nullptr);
+    uint32_t c = __popc(keep_mask8(p, i0, n, flags));
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+template <bool DDIST, bool CDIST, bool PRED>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
+                           uint32_t ds, const uint32_t* __restrict__ tile_prefix,
+                           const uint32_t* __restrict__ stream_base, uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
+    __shared__ uint32_t wsum[4];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[stream0 + s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    DepthSource<DDIST, CDIST> src{fp.depth[s]};
+    const uint32_t g0 = PRED ? tile_prefix[P.tile_base + blockIdx.x] : tile0;
+    const uint32_t out_first = PRED ? stream_base[stream0 + s] : P.out_base;
+    generic_tile<DepthSource<DDIST, CDIST>, PRED>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
+                                                  payload_bytes, stage, wsum, nullptr);
+}
+
+// One workgroup of 1024 lanes: per-stream exclusive scan of the tile counts, and the running output
+// base of each stream (a7's camera-order concatenation after the per-camera stride).
+__global__ __launch_bounds__(1024)
+void pcs_scan_kernel(const StreamParams* __restrict__ params, int stream0, int n_streams, uint32_t override_n,
+                     uint32_t ds, const uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ tile_prefix,
+                     uint32_t* __restrict__ stream_base, int32_t* __restrict__ counts)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    uint32_t base = 0;
+    for (int s = 0; s < n_streams; s++) {
+        const uint32_t n = override_n ? override_n : params[stream0 + s].n_points;
+        const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
+        const uint32_t tb = override_n ? 0u : params[stream0 + s].tile_base;
+        if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < tiles; t0 += 1024) {
+            const uint32_t t = t0 + threadIdx.x;
+            const uint32_t c = (t < tiles) ? tile_counts[tb + t] : 0u;
+            uint32_t wave_total;
+            const uint32_t ex = wave_exclusive_scan(c, wave_total);
+            if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = wave_total;
+            __syncthreads();
+            uint32_t before = carry_s;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wtot[w];
+            if (t < tiles) tile_prefix[tb + t] = before + ex;
+            __syncthreads();
+            if (threadIdx.x == 1023) carry_s = before + ex + c;
+            __syncthreads();
+        }
+        const uint32_t kept = carry_s;
+        const uint32_t outc = (kept + ds - 1) / ds;
+        if (threadIdx.x == 0) {
+            if (stream_base) stream_base[stream0 + s] = base;
+            if (counts) counts[stream0 + s] = (int32_t)outc;
+        }
+        base += outc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (stream_base) stream_base[stream0 + n_streams] = base;
+        if (counts) counts[stream0 + n_streams] = (int32_t)base;
+    }
+}
+
+// ---- a2 twin -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_pack_dense_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp,
+                           uint8_t* __restrict__ out_bytes)
+{
+    __shared__ __attribute__((aligned(16))) float lds[VertexSource::kLdsFloats];   // input; output staging aliases it
+    const StreamParams& P = params[stream];
+    const uint32_t n = vp.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    VertexSource src{vp.vertices, vp.texcoords};
+    src.stage_tile(tile0, n, lds);
+    __syncthreads();
+    dense_tile(P, src, vp.color, tile0, n, out_bytes, reinterpret_cast<uint4*>(lds), lds);
+}
+
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_pack_count_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp, uint32_t flags,
+                           uint32_t* __restrict__ tile_counts)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t n = vp.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
+    // the predicate needs x and z only; read them straight from global (12-byte stride)
+    PointIn p[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t i = i0 + k;
+        p[k] = PointIn{0, 0, 0, 0, 0};
+        if (i < n) { p[k].X = vp.vertices[3 * (size_t)i]; p[k].Z = vp.vertices[3 * (size_t)i + 2]; }
+    }
+    uint32_t c = __popc(keep_mask8(p, i0, n, flags));
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    (void)params; (void)stream;
+}
+
+template <bool PRED>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_pack_emit_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp, uint32_t flags,
+                          const uint32_t* __restrict__ tile_prefix, uint8_t* __restrict__ out_bytes)
+{
+    __shared__ __attribute__((aligned(16))) float lds[VertexSource::kLdsFloats];
+    __shared__ uint32_t wsum[4];
+    const StreamParams& P = params[stream];
+    const uint32_t n = vp.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    VertexSource src{vp.vertices, vp.texcoords};
+    src.stage_tile(tile0, n, lds);
+    __syncthreads();
+    const uint32_t g0 = PRED ? tile_prefix[blockIdx.x] : tile0;
+    // staging must not alias the input here (lanes still read inputs while others stage) unless we
+    // barrier after load8 — generic_tile does (PRED path barriers in the scan; non-PRED explicitly).
+    generic_tile<VertexSource, PRED>(P, src, vp.color, tile0, n, flags, 1u, g0, 0u, out_bytes,
+                                     reinterpret_cast<uint8_t*>(lds), wsum, lds);
+}
+
+// ---- a5 alone ----------------------------------------------------------------------------------
+template <bool DDIST, bool CDIST>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_deproject_kernel(const StreamParams* __restrict__ params, int stream, const uint16_t* __restrict__ depth,
+                          float* __restrict__ vertices, float* __restrict__ texcoords)
+{
+    const StreamParams& P = params[stream];
+    const uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= P.n_points) return;
+    const uint32_t r = i / (uint32_t)P.W;
+    const uint32_t c = i - r * (uint32_t)P.W;
+    const PointIn p = deproject_pixel<DDIST, CDIST>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+    vertices[3 * (size_t)i + 0] = p.X;
+    vertices[3 * (size_t)i + 1] = p.Y;
+    vertices[3 * (size_t)i + 2] = p.Z;
+    texcoords[2 * (size_t)i + 0] = p.u;
+    texcoords[2 * (size_t)i + 1] = p.v;
+}
+
+// ---- a7 with stride ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_stitch_kernel(const uint16_t* __restrict__ src, uint32_t out_points, uint32_t ds, uint8_t* __restrict__ dst)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= out_points) return;
+    const uint32_t pts = min(kTilePoints, out_points - tile0);
+    uint8_t* gdst = dst + (size_t)tile0 * PCS_POINT_BYTES;
+    const uint32_t head = (uint32_t)((uintptr_t)gdst & 15u);
+    for (uint32_t j = threadIdx.x; j < pts; j += kBlockThreads) {
+        const uint16_t* s = src + (size_t)(tile0 + j) * ds * PCS_POINT_SHORTS;
+        uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + j * PCS_POINT_BYTES);
+#pragma unroll
+        for (int k = 0; k < PCS_POINT_SHORTS; k++) o[k] = s[k];
+    }
+    __syncthreads();
+    store_staged(stage, head, pts * PCS_POINT_BYTES, gdst);
+}
+
+inline dim3 tile_grid(uint32_t max_points, int n_launch)
+{
+    return dim3((max_points + kTilePoints - 1) / kTilePoints, (unsigned)n_launch, 1);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------
+
+#define PCS_DISPATCH_DIST(DD, CD, ...)                         \
+    do {                                                       \
+        if (DD) { if (CD) { __VA_ARGS__(true, true); } else { __VA_ARGS__(true, false); } } \
+        else    { if (CD) { __VA_ARGS__(false, true); } else { __VA_ARGS__(false, false); } } \
+    } while (0)
+
+hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                              bool any_ddist, bool any_cdist, const FramePtrs& fp, int16_t* d_payload,
+                              hipStream_t st)
+{
+    if (n_launch <= 0 || max_points == 0) return hipSuccess;
+    const dim3 grid = tile_grid(max_points, n_launch);
+#define L(DD, CD) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD>), grid, dim3(kBlockThreads), 0, st, \
+                                     d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload))
+    PCS_DISPATCH_DIST(any_ddist, any_cdist, L);
+#undef L
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                              uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st)
+{
+    if (n_launch <= 0 || max_points == 0) return hipSuccess;
+    const dim3 grid = tile_grid(max_points, n_launch);
+    // the predicate depends on depth-side distortion only through x; always run the general form
+    hipLaunchKernelGGL((pcs_fused_count_kernel<true, false>), grid, dim3(kBlockThreads), 0, st,
+                       d_params, stream0, fp, flags, d_tile_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsample,
+                       const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_base,
+                       int32_t* d_counts, hipStream_t st)
+{
+    hipLaunchKernelGGL(pcs_scan_kernel, dim3(1), dim3(1024), 0, st, d_params, 0, n_streams, 0u,
+                       (uint32_t)downsample, d_tile_counts, d_tile_prefix, d_stream_base, d_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                             uint32_t flags, int downsample, const FramePtrs& fp,
+                             const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
+                             int16_t* d_payload, hipStream_t st)
+{
+    if (n_launch <= 0 || max_points == 0) return hipSuccess;
+    const dim3 grid = tile_grid(max_points, n_launch);
+    const bool pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
+    uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
+    if (pred)
+        hipLaunchKernelGGL((pcs_fused_emit_kernel<true, true, true>), grid, dim3(kBlockThreads), 0, st,
+                           d_params, stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_base, out);
+    else
+        hipLaunchKernelGGL((pcs_fused_emit_kernel<true, true, false>), grid, dim3(kBlockThreads), 0, st,
+                           d_params, stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_base, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const VertexPtrs& vp,
+                             int16_t* d_out, hipStream_t st)
+{
+    if (vp.n_points == 0) return hipSuccess;
+    hipLaunchKernelGGL(pcs_pack_dense_kernel, tile_grid(vp.n_points, 1), dim3(kBlockThreads), 0, st,
+                       d_params, stream, vp, reinterpret_cast<uint8_t*>(d_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_count(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
+                             uint32_t* d_tile_counts, hipStream_t st)
+{
+    if (vp.n_points == 0) return hipSuccess;
+    hipLaunchKernelGGL(pcs_pack_count_kernel, tile_grid(vp.n_points, 1), dim3(kBlockThreads), 0, st,
+                       d_params, stream, vp, flags, d_tile_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_scan(uint32_t n_tiles, const uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
+                            int32_t* d_out_points, hipStream_t st)
+{
+    // override_n makes the scan kernel ignore the params table (one segment of n_tiles tiles at index 0);
+    // counts[0] = kept, counts[1] = total — d_out_points must hold 2 ints.
+    hipLaunchKernelGGL(pcs_scan_kernel, dim3(1), dim3(1024), 0, st, (const StreamParams*)nullptr, 0, 1,
+                       n_tiles * kTilePoints, 1u, d_tile_counts, d_tile_prefix, (uint32_t*)nullptr, d_out_points);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_emit(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
+                            const uint32_t* d_tile_prefix, int16_t* d_out, hipStream_t st)
+{
+    if (vp.n_points == 0) return hipSuccess;
+    const bool pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
+    uint8_t* out = reinterpret_cast<uint8_t*>(d_out);
+    if (pred)
+        hipLaunchKernelGGL((pcs_pack_emit_kernel<true>), tile_grid(vp.n_points, 1), dim3(kBlockThreads), 0, st,
+                           d_params, stream, vp, flags, d_tile_prefix, out);
+    else
+        hipLaunchKernelGGL((pcs_pack_emit_kernel<false>), tile_grid(vp.n_points, 1), dim3(kBlockThreads), 0, st,
+                           d_params, stream, vp, flags, d_tile_prefix, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n_points,
+                            const uint16_t* d_depth, float* d_vertices, float* d_texcoords, hipStream_t st)
+{
+    if (n_points == 0) return hipSuccess;
+    const dim3 grid((n_points + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL((pcs_deproject_kernel<true, true>), grid, dim3(kBlockThreads), 0, st,
+                       d_params, stream, d_depth, d_vertices, d_texcoords);
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,
+                         int16_t* d_dst, hipStream_t st)
+{
+    const uint32_t ds = downsample < 1 ? 1u : (uint32_t)downsample;
+    const uint32_t out_points = (src_points + ds - 1) / ds;
+    if (out_points == 0) return hipSuccess;
+    hipLaunchKernelGGL(pcs_stitch_kernel, tile_grid(out_points, 1), dim3(kBlockThreads), 0, st,
+                       reinterpret_cast<const uint16_t*>(d_src), out_points, ds, reinterpret_cast<uint8_t*>(d_dst));
+    return hipGetLastError();
+}
+
+}  // namespace pcs

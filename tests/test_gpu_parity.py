@@ -1,0 +1,344 @@
+"""Parity proper: the HIP path, through the C ABI, against the CPU oracle on the same seeded inputs.
+Bit-exact for the int16 records; bit-exact (NaN == NaN) for the float deprojection, which is stricter
+than the 1-ulp tolerance DESIGN.md allows against a real librealsense."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pointcloud_stitching_amd import synthetic as S
+from pointcloud_stitching_amd.api import PcsContext, PcsError
+from pointcloud_stitching_amd.types import (FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID, HEADER_SHORTS,
+                                            POINT_SHORTS, TRANSFORMS, make_intrinsics, make_stream_config)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def first_diff(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    if a.shape != b.shape:
+        return f"shape {a.shape} vs {b.shape}"
+    bad = np.argwhere(a != b)
+    if bad.size == 0:
+        return None
+    i = tuple(bad[0])
+    return f"{bad.shape[0]} mismatches; first at {i}: got {a[i]} want {b[i]}; row got {a[i[0]]} want {b[i[0]]}"
+
+
+def assert_same(got, want):
+    d = first_diff(got, want)
+    assert d is None, d
+
+
+def random_points(n, seed, cw=64, ch=48, spread=8.0):
+    rng = np.random.default_rng(seed)
+    V = (rng.standard_normal((n, 3)) * spread).astype(np.float32)
+    T = rng.uniform(-0.2, 1.2, (n, 2)).astype(np.float32)
+    col = rng.integers(0, 256, cw * ch * 3, dtype=np.uint8)
+    it = make_intrinsics(cw, ch, 40, 40, cw / 2, ch / 2)
+    return make_stream_config(it, it), V, T, col
+
+
+# ---------------------------------------------------------------------------------------------
+# a2 twin: copyPointCloudXYZRGBToBufferSIMD
+# ---------------------------------------------------------------------------------------------
+def test_pack_kat_appendix_b():
+    with open(os.path.join(GOLD, "kat_appendix_b.json")) as f:
+        k = json.load(f)
+    V = np.array([v["vertex"] for v in k["vectors"]], np.float32)
+    T = np.array([v["uv"] for v in k["vectors"]], np.float32)
+    B = np.array([[int(x, 16) for x in v["bytes"].split()] for v in k["vectors"]], np.uint8)
+    it = make_intrinsics(8, 4, 1, 1, 0, 0)
+    sc = make_stream_config(it, it, color_stride=24)
+    col = ((7 * np.arange(96) + 3) & 0xFF).astype(np.uint8)
+    with PcsContext([sc]) as ctx:
+        out, cnt = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)
+    assert cnt == 8
+    assert_same(out.view(np.uint8).reshape(8, 10), B)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 7, 8, 9, 64, 2047, 2048, 2049, 5000, 307200])
+def test_pack_random_sizes(oracle, n):
+    sc, V, T, col = random_points(n, 1000 + n)
+    with PcsContext([sc]) as ctx:
+        out, cnt = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)
+    assert cnt == n
+    assert_same(out, oracle.pack(sc, V, T, col))
+
+
+def test_pack_edge_values(oracle):
+    sc, V, T, col = random_points(4096, 77, spread=30.0)
+    edge_uv = [(-1, -1), (0, 0), (1, 1), (2, 2), (0.4999, 0.5), (0.5, 0.4999), (1e9, -1e9), (np.nan, np.inf),
+               (-np.inf, np.nan), (3e38, 3e38), (0.9999999, 0.9999999), (1e-45, -1e-45), (-0.0, 0.0),
+               (0.0078125, 0.0104166), (33554432.0, -33554432.0), (16777216.0, 0.5)]
+    T[:len(edge_uv)] = edge_uv
+    edge_v = [(40, 0, 0), (-40, 50, 60), (1e7, 0, 0), (np.nan, 0, 0), (np.inf, 1, 1), (-np.inf, 0, 0),
+              (3e38, 3e38, 3e38), (2147483.648, 0, 0), (-2147483.648, 0, 0), (1e-45, 1e-45, 1e-45),
+              (-0.0, -0.0, -0.0), (32.767, 32.768, -32.769), (65.535, 65.536, 65.537), (2.2e6, -2.2e6, 0)]
+    V[100:100 + len(edge_v)] = edge_v
+    with PcsContext([sc]) as ctx:
+        out, _ = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)
+    assert_same(out, oracle.pack(sc, V, T, col))
+
+
+def test_pack_rgba_stride_padding(oracle):
+    rng = np.random.default_rng(3)
+    cw, ch, bpp, stride = 50, 20, 4, 224
+    it = make_intrinsics(cw, ch, 30, 30, 25, 10)
+    sc = make_stream_config(it, it, color_bpp=bpp, color_stride=stride)
+    col = rng.integers(0, 256, stride * ch, dtype=np.uint8)
+    V = rng.standard_normal((3000, 3)).astype(np.float32)
+    T = rng.uniform(-0.1, 1.1, (3000, 2)).astype(np.float32)
+    with PcsContext([sc]) as ctx:
+        out, _ = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)
+    assert_same(out, oracle.pack(sc, V, T, col))
+
+
+def test_pack_last_pixel_reads_inside_raster(oracle):
+    # the colour dword window must slide back at the very last pixel (bpp 3, no padding)
+    it = make_intrinsics(5, 3, 1, 1, 0, 0)
+    sc = make_stream_config(it, it)
+    col = np.arange(45, dtype=np.uint8) + 100
+    T = np.array([(1, 1), (0.99, 0.99), (0.7, 1.0), (0, 0)], np.float32)
+    V = np.zeros((4, 3), np.float32)
+    with PcsContext([sc]) as ctx:
+        out, _ = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)
+    assert_same(out, oracle.pack(sc, V, T, col))
+    assert out[0, 3].view(np.uint16) == (142 | 143 << 8) and out[0, 4] == 144
+
+
+@pytest.mark.parametrize("flags", [FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID,
+                                   FLAG_CUTOFF | FLAG_DROP_INVALID])
+@pytest.mark.parametrize("n", [5, 2048, 10007])
+def test_pack_compaction_matches_t1_order(oracle, flags, n):
+    sc, V, T, col = random_points(n, 31 + n, spread=1.5)
+    V[:, 2] = np.abs(V[:, 2])
+    V[::5, 2] = 0.0
+    want = oracle.pack(sc, V, T, col, flags)
+    with PcsContext([sc], flags=flags) as ctx:
+        out, cnt = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)
+    assert cnt == want.shape[0]
+    assert_same(out, want)
+
+
+def test_send_xyzrgb_pointcloud_layout(oracle):
+    sc, V, T, col = random_points(1000, 5)
+    want, wsize = oracle.send_xyzrgb_pointcloud(sc, V, T, col, buffer_shorts=2_600_000, write_header=True)
+    buf = np.full(2_600_000, 0x5A5A, np.uint16).view(np.int16)
+    with PcsContext([sc]) as ctx:
+        size = ctx.send_xyzrgb_pointcloud(0, V, T, col, buf, write_header=True)
+        assert size == wsize == 10000
+        assert_same(buf, want)
+        buf2 = np.full(2_600_000, 0x5A5A, np.uint16).view(np.int16)
+        ctx.send_xyzrgb_pointcloud(0, V, T, col, buf2, write_header=False)
+        want2, _ = oracle.send_xyzrgb_pointcloud(sc, V, T, col, buffer_shorts=2_600_000, write_header=False)
+        assert_same(buf2, want2)
+        small = np.zeros(100, np.int16)
+        with pytest.raises(PcsError) as e:
+            ctx.send_xyzrgb_pointcloud(0, V, T, col, small)
+        assert e.value.status == -5
+
+
+# ---------------------------------------------------------------------------------------------
+# a5: deprojection contract
+# ---------------------------------------------------------------------------------------------
+def same_floats(a, b):
+    a = a.view(np.uint32); b = b.view(np.uint32)
+    nan_a = (a & 0x7FFFFFFF) > 0x7F800000
+    nan_b = (b & 0x7FFFFFFF) > 0x7F800000
+    return ((a == b) | (nan_a & nan_b)).all()
+
+
+@pytest.mark.parametrize("mode", ["scene", "random"])
+def test_deproject_bit_exact(oracle, mode):
+    cfgs, depth, _ = S.synth_frame_set(1, 640, 480, single=True, mode=mode)
+    with PcsContext(cfgs) as ctx:
+        v, t = ctx.deproject(0, depth[0])
+    v0, t0 = oracle.deproject(cfgs[0], depth[0])
+    assert same_floats(v, v0) and same_floats(t, t0)
+
+
+def distorted_config(w, h, cw, ch):
+    di = make_intrinsics(w, h, 0.7 * w, 0.71 * w, w / 2 + 1.3, h / 2 - 2.2, model=2,
+                         coeffs=[0.08, -0.03, 0.001, -0.002, 0.01])
+    ci = make_intrinsics(cw, ch, 0.72 * cw, 0.72 * cw, cw / 2 - 3.1, ch / 2 + 1.7, model=1,
+                         coeffs=[-0.05, 0.06, 0.0005, -0.0007, -0.02])
+    a = 0.02
+    rot = [np.cos(a), np.sin(a), 0, -np.sin(a), np.cos(a), 0, 0, 0, 1]     # column-major small roll
+    return make_stream_config(di, ci, cam_to_world=TRANSFORMS[3], rotation=rot, translation=(0.0147, 0.0003, -0.0002))
+
+
+def test_deproject_with_distortion_and_rotation(oracle):
+    sc = distorted_config(128, 96, 192, 108)
+    depth = S.synth_depth(128, 96, 2)
+    with PcsContext([sc]) as ctx:
+        v, t = ctx.deproject(0, depth)
+    v0, t0 = oracle.deproject(sc, depth)
+    assert same_floats(v, v0) and same_floats(t, t0)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused a5 + a2 (+ a7 concat)
+# ---------------------------------------------------------------------------------------------
+def run_fused(cfgs, depth, color, flags=0, downsample=1):
+    with PcsContext(cfgs, flags=flags, downsample=downsample) as ctx:
+        buf, counts, size = ctx.process_frames(depth, color, write_header=True)
+    assert int.from_bytes(buf[:2].tobytes(), "little", signed=True) == size
+    assert size == 10 * sum(counts)
+    return buf[HEADER_SHORTS:HEADER_SHORTS + 5 * sum(counts)].reshape(-1, 5), counts
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (640, 480), (1280, 720)])
+def test_fused_single_stream(oracle, shape):
+    cfgs, depth, color = S.synth_frame_set(1, *shape, single=True)
+    got, counts = run_fused(cfgs, depth, color)
+    want, wcounts = oracle.process_frames(cfgs, depth, color)
+    assert counts == wcounts
+    assert_same(got, want)
+
+
+def test_fused_random_depth_full_range(oracle):
+    cfgs, depth, color = S.synth_frame_set(2, 640, 480, mode="random")
+    got, counts = run_fused(cfgs, depth, color)
+    want, _ = oracle.process_frames(cfgs, depth, color)
+    assert_same(got, want)
+
+
+def test_fused_eight_streams_720p_full_compare(oracle):
+    cfgs, depth, color = S.synth_frame_set(8, 1280, 720)
+    got, counts = run_fused(cfgs, depth, color)
+    want, wcounts = oracle.process_frames(cfgs, depth, color)
+    assert counts == wcounts == [921600] * 8
+    assert_same(got, want)
+    # a7: camera-order concatenation — stream s occupies [s*N, (s+1)*N)
+    one, _ = oracle.process_frames(cfgs[3:4], depth[3:4], color[3:4])
+    assert_same(got[3 * 921600:4 * 921600], one)
+
+
+def test_fused_mixed_geometry_streams(oracle):
+    # different rasters per stream, colour at another resolution, one stream with distortion,
+    # one with W % 8 != 0 and N % 8 != 0 (forces the generic path for the whole set)
+    cfgs = [S.synth_stream_config(640, 480, 0),
+            S.synth_stream_config(1280, 720, 1, color_size=(1920, 1080)),
+            distorted_config(128, 96, 192, 108),
+            S.synth_stream_config(100, 37, 3)]
+    depth = [S.synth_depth(c.depth.width, c.depth.height, i) for i, c in enumerate(cfgs)]
+    color = [S.synth_color(c.color.width, c.color.height, i) for i, c in enumerate(cfgs)]
+    got, counts = run_fused(cfgs, depth, color)
+    want, wcounts = oracle.process_frames(cfgs, depth, color)
+    assert counts == wcounts
+    assert_same(got, want)
+    # and the dense path on the first three only
+    got3, _ = run_fused(cfgs[:3], depth[:3], color[:3])
+    want3, _ = oracle.process_frames(cfgs[:3], depth[:3], color[:3])
+    assert_same(got3, want3)
+
+
+def test_fused_more_streams_than_one_launch(oracle):
+    cfgs, depth, color = S.synth_frame_set(19, 64, 48)
+    got, counts = run_fused(cfgs, depth, color)
+    want, _ = oracle.process_frames(cfgs, depth, color)
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("flags", [FLAG_DROP_INVALID, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT,
+                                   FLAG_CUTOFF | FLAG_DROP_INVALID])
+@pytest.mark.parametrize("downsample", [1, 3])
+def test_fused_compaction_and_stride(oracle, flags, downsample):
+    cfgs, depth, color = S.synth_frame_set(3, 640, 480)
+    for d in depth:
+        d[100:140, :] //= 4          # bring part of the scene inside the 1.5 m cutoff
+    got, counts = run_fused(cfgs, depth, color, flags, downsample)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags, downsample)
+    assert counts == wcounts
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("downsample", [2, 5, 8, 2049])
+def test_fused_stride_only(oracle, downsample):
+    cfgs, depth, color = S.synth_frame_set(2, 640, 480)
+    got, counts = run_fused(cfgs, depth, color, 0, downsample)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, 0, downsample)
+    assert counts == wcounts
+    assert_same(got, want)
+
+
+def test_fused_all_invalid_and_all_dropped(oracle):
+    cfgs, depth, color = S.synth_frame_set(2, 64, 48)
+    depth[0][:] = 0
+    got, counts = run_fused(cfgs, depth, color, FLAG_DROP_INVALID)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+    assert counts == wcounts and counts[0] == 0
+    assert_same(got, want)
+    depth[1][:] = 0
+    got, counts = run_fused(cfgs, depth, color, FLAG_DROP_INVALID)
+    assert counts == [0, 0] and got.shape[0] == 0
+
+
+def test_fused_device_api_unaligned_payload_and_idempotence(oracle):
+    # the reference's payload pointer is buffer+4 bytes (:690): not 16-byte aligned -> generic store path
+    cfgs, depth, color = S.synth_frame_set(2, 640, 480)
+    want, _ = oracle.process_frames(cfgs, depth, color)
+    n_sh = want.size
+    with PcsContext(cfgs) as ctx:
+        dd = [ctx.device_malloc(d.nbytes) for d in depth]
+        dc = [ctx.device_malloc(c.nbytes) for c in color]
+        for p, a in zip(dd + dc, depth + color):
+            ctx.memcpy_h2d(p, a)
+        out = ctx.device_malloc(n_sh * 2 + 64)
+        for skew in (0, 4, 2, 10):
+            ctx.process_frames_device(dd, dc, out + skew, n_sh)
+            ctx.process_frames_device(dd, dc, out + skew, n_sh)      # idempotent
+            ctx.synchronize()
+            got = np.empty(n_sh, np.int16)
+            ctx.memcpy_d2h(got, out + skew)
+            assert_same(got.reshape(-1, 5), want)
+        with pytest.raises(PcsError) as e:
+            ctx.process_frames_device(dd, dc, out, n_sh - 5)
+        assert e.value.status == -5
+        for p in dd + dc + [out]:
+            ctx.device_free(p)
+
+
+def test_set_cam_to_world(oracle):
+    cfgs, depth, color = S.synth_frame_set(1, 64, 48, single=True)
+    with PcsContext(cfgs) as ctx:
+        ctx.set_cam_to_world(0, TRANSFORMS[5])
+        buf, counts, size = ctx.process_frames(depth, color)
+    for k in range(16):
+        cfgs[0].cam_to_world[k] = float(TRANSFORMS[5][k])
+    want, _ = oracle.process_frames(cfgs, depth, color)
+    assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
+
+
+def test_stitch_device_with_stride(oracle):
+    rng = np.random.default_rng(9)
+    cams = [rng.integers(-30000, 30000, (n, 5), dtype=np.int16) for n in (5000, 0, 2049, 1)]
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        dptr = [ctx.device_malloc(max(c.nbytes, 16)) for c in cams]
+        for p, c in zip(dptr, cams):
+            if c.size:
+                ctx.memcpy_h2d(p, c)
+        out = ctx.device_malloc(sum(c.nbytes for c in cams) + 64)
+        for d in (1, 2, 3, 7):
+            want = oracle.stitch(cams, d)
+            total = ctx.stitch_device(dptr, [c.shape[0] for c in cams], d, out + 4, want.size)
+            ctx.synchronize()
+            assert total == want.shape[0]
+            got = np.empty(want.size, np.int16)
+            ctx.memcpy_d2h(got, out + 4)
+            assert_same(got.reshape(-1, 5), want)
+
+
+def test_sixteen_streams_1080p_digest(oracle):
+    # config 5 geometry: full compare through a digest to keep host memory in check
+    cfgs, depth, color = S.synth_frame_set(16, 1920, 1080)
+    got, counts = run_fused(cfgs, depth, color, FLAG_DROP_INVALID)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+    assert counts == wcounts
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
