@@ -20,6 +20,11 @@ import torch.distributed as dist
 from .types import POINT_SHORTS
 
 
+def _as_bytes(t: torch.Tensor) -> torch.Tensor:
+    """The records are opaque 10-byte units on the wire; uint8 is the one dtype every backend moves."""
+    return t.view(torch.uint8)
+
+
 class RankStitcher:
     def __init__(self, group=None, root: int = 0):
         self.group = group
@@ -31,12 +36,13 @@ class RankStitcher:
     def gather_fixed(self, local_payload: torch.Tensor, stitched: Optional[torch.Tensor], async_op: bool = False):
         """local_payload: int16 [points*5]; stitched (root only): int16 [world*points*5]."""
         n = local_payload.numel()
+        src = _as_bytes(local_payload)
         if self.rank == self.root:
             if stitched is None or stitched.numel() < n * self.world:
                 raise ValueError("root needs a stitched buffer of world * local size")
-            views = [stitched[r * n:(r + 1) * n] for r in range(self.world)]
-            return dist.gather(local_payload, views, dst=self.root, group=self.group, async_op=async_op)
-        return dist.gather(local_payload, None, dst=self.root, group=self.group, async_op=async_op)
+            views = [_as_bytes(stitched[r * n:(r + 1) * n]) for r in range(self.world)]
+            return dist.gather(src, views, dst=self.root, group=self.group, async_op=async_op)
+        return dist.gather(src, None, dst=self.root, group=self.group, async_op=async_op)
 
     # variable-size case (after compaction)
     def gather_counts(self, local_points: int, device) -> List[int]:
@@ -63,12 +69,12 @@ class RankStitcher:
                 if r == self.root:
                     dst.copy_(local_payload[:counts[r] * POINT_SHORTS])
                 else:
-                    ops.append(dist.P2POp(dist.irecv, dst, r, self.group))
+                    ops.append(dist.P2POp(dist.irecv, _as_bytes(dst), r, self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
         elif local_points > 0:
-            ops = [dist.P2POp(dist.isend, local_payload[:local_points * POINT_SHORTS], self.root, self.group)]
+            ops = [dist.P2POp(dist.isend, _as_bytes(local_payload[:local_points * POINT_SHORTS]), self.root, self.group)]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         return counts

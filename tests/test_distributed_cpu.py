@@ -1,0 +1,74 @@
+"""The N>1 path on CPU: world_size 2 over gloo. Each rank produces its cameras' packed payload (with
+the oracle standing in for the HIP kernel — this test is about the exchange step and the stitched
+layout, a7), RankStitcher gathers to rank 0, and rank 0 compares with the oracle run over ALL cameras
+in global camera order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, flags, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointcloud_stitching_amd import synthetic as S
+        from pointcloud_stitching_amd.stitch import RankStitcher
+        from oracle import pcs_oracle as O
+        per_rank, W, H = 3, 64, 48
+        cams = list(range(rank * per_rank, (rank + 1) * per_rank))
+        cfgs = [S.synth_stream_config(W, H, c) for c in cams]
+        depth = [S.synth_depth(W, H, c) for c in cams]
+        color = [S.synth_color(W, H, c) for c in cams]
+        local, counts = O.process_frames(cfgs, depth, color, flags, 1)
+        lp = torch.from_numpy(local.reshape(-1).copy())
+        st = RankStitcher()
+        all_cfgs = [S.synth_stream_config(W, H, c) for c in range(world * per_rank)]
+        all_depth = [S.synth_depth(W, H, c) for c in range(world * per_rank)]
+        all_color = [S.synth_color(W, H, c) for c in range(world * per_rank)]
+        want, _ = O.process_frames(all_cfgs, all_depth, all_color, flags, 1)
+        ok = True
+        if flags == 0:
+            stitched = torch.zeros(lp.numel() * world, dtype=torch.int16) if rank == 0 else None
+            w = st.gather_fixed(lp, stitched, async_op=True)
+            w.wait()
+            if rank == 0:
+                ok = bool((stitched.numpy().reshape(-1, 5) == want).all())
+        else:
+            cap = per_rank * W * H * 5 * world
+            stitched = torch.zeros(cap, dtype=torch.int16) if rank == 0 else None
+            cnts = st.gather_variable(lp, local.shape[0], stitched)
+            ok = sum(cnts) == want.shape[0]
+            if rank == 0:
+                ok = ok and bool((stitched.numpy()[:want.size].reshape(-1, 5) == want).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_two_rank_gather_reproduces_camera_order_concat(oracle, flags):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flags, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

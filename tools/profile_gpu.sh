@@ -1,0 +1,37 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py.
+# Summaries land in gpurun_out/prof_<tag>/ ; copy the ones to keep into profiles/.
+TAG=${1:-r01}
+STEPS=${2:-200}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
+echo "stats rc=$?"
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- $CMD > $OUT/pmc_$N.log 2>&1
+  echo "pmc $N rc=$?"
+done
+cd - > /dev/null
+python - <<PY
+import csv, glob, os, collections, json
+out = "$OUT"
+summ = {}
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    summ["kernel_stats"] = rows[:12]
+for d in glob.glob(out + "/pmc_*"):
+    if not os.path.isdir(d): continue
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                summ.setdefault("pmc", {}).setdefault(k, {})[c] = {"n": len(v), "mean": sum(v) / len(v)}
+json.dump(summ, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(summ, indent=1)[:6000])
+PY
