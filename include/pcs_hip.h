@@ -105,6 +105,8 @@ typedef struct pcs_stream_config {
 #define PCS_FLAG_CUTOFF_COMPAT  0x2u  /* with CUTOFF: reproduce the reference's lane-reversed mask (point k of
                                          each aligned group of 4 is gated by point 3-k)  :501-502,519 */
 #define PCS_FLAG_DROP_INVALID   0x4u  /* drop depth==0 pixels (not in the reference; north-star compaction) */
+#define PCS_FLAG_FORCE_IEEE     0x8u  /* never use the certified reduced-instruction arithmetic (A/B testing);
+                                         results are identical either way */
 
 typedef struct pcs_config {
     int32_t                  device;      /* HIP device ordinal */
@@ -127,6 +129,11 @@ const char*  pcs_last_error(const pcs_ctx* ctx);     /* detail of the last failu
 
 /* Replace one stream's camera->world matrix (the reference edits tf_mat in source, :64-67). */
 int          pcs_set_cam_to_world(pcs_ctx* ctx, int stream, const float m16[16]);
+
+/* Which arithmetic the fused kernels use for `stream`: 0 = IEEE expansion, 1 = certified reduced-instruction
+ * form, 2 = certified + identity depth->colour rotation shortcut (DESIGN.md "Certified arithmetic"). The
+ * results are bit-identical; this is a diagnostic. */
+int          pcs_stream_math(const pcs_ctx* ctx, int stream);
 
 /* Number of points one frame of `stream` deprojects to (= depth width*height). */
 int          pcs_stream_points(const pcs_ctx* ctx, int stream);

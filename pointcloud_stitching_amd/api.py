@@ -90,6 +90,10 @@ class PcsContext:
     def stream_points(self, stream: int) -> int:
         return int(self._lib.pcs_stream_points(self._h, stream))
 
+    def stream_math(self, stream: int) -> int:
+        """0 = IEEE expansion, 1 = certified reduced-instruction arithmetic, 2 = + identity-R shortcut."""
+        return int(self._lib.pcs_stream_math(self._h, stream))
+
     @property
     def max_payload_shorts(self) -> int:
         return int(self._lib.pcs_max_payload_shorts(self._h))

@@ -34,6 +34,7 @@ struct pcs_ctx {
     int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
     bool                            dense_ok = false;          // every stream has n % 8 == 0
     bool                            any_ddist = false, any_cdist = false;
+    std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 certified + identity R
     uint32_t                        max_points = 0;
     size_t                          max_payload_points = 0;
 
@@ -124,6 +125,7 @@ void fill_params(const pcs_stream_config& s, StreamParams& p)
     p.d_ppx = s.depth.ppx; p.d_ppy = s.depth.ppy; p.d_fx = s.depth.fx; p.d_fy = s.depth.fy;
     p.c_fx = s.color.fx; p.c_fy = s.color.fy; p.c_ppx = s.color.ppx; p.c_ppy = s.color.ppy;
     p.c_w_f = (float)s.color.width; p.c_h_f = (float)s.color.height;
+    p.c_rw = (float)(1.0 / (double)p.c_w_f); p.c_rh = (float)(1.0 / (double)p.c_h_f);
     for (int k = 0; k < 5; k++) { p.dk[k] = s.depth.coeffs[k]; p.ck[k] = s.color.coeffs[k]; }
     p.W = s.depth.width; p.H = s.depth.height;
     p.cW = s.color.width; p.cH = s.color.height;
@@ -132,6 +134,110 @@ void fill_params(const pcs_stream_config& s, StreamParams& p)
     p.n_points = (uint32_t)s.depth.width * (uint32_t)s.depth.height;
     p.ddist = (s.depth.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.depth)) ? 1 : 0;
     p.cdist = (s.color.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.color)) ? 1 : 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Certification of the reduced-instruction arithmetic (CertMath in pcs_kernels.hip) for one stream.
+//
+// CertMath::div2 drops v_div_scale / v_div_fmas / v_div_fixup from the IEEE division expansion. That is
+// the same arithmetic as long as no operand would have been rescaled, i.e. for every VALID pixel
+// (depth d in 1..65535):  2^-40 <= |P2| < 2^30,  |P0|,|P1| < 2^30,  and P0,P1 are either exactly zero or
+// >= 2^-70 in magnitude (then every quotient is zero or in [2^-100, 2^70], the exact remainders of the
+// fused corrections are representable, and 1/P2 is normal). Everything is a conservative bound computed
+// from the configuration; if any bound fails, or anything is non-finite, the stream keeps IeeeMath.
+//
+//   Z = depth_scale*d in [zmin, zmax];  |X| <= Z*mxmax,  |Y| <= Z*mymax   (LUT maxima, inflated by 2^-20)
+//   P_i = fl(fl(fl(R_i0 X + R_i3 Y) + R_i6 Z) + t_i)
+//   upper:   |P_i| <= (|R_i0| mxmax + |R_i3| mymax + |R_i6|) zmax + |t_i|                 (+ rounding slack)
+//   P2 low:  P2 >= (R8 - |R2| mxmax - |R5| mymax) Z + t2 - 2^-21 (sigma Z + |t2|),  minimised at Z = zmin
+//   P_i nonzero low: a float sum is an integer multiple of the smallest ulp among its addends, so a
+//            non-zero P_i is >= 2^-24 * (smallest non-zero addend magnitude), with addends
+//            |R_i0| xmin, |R_i3| ymin, |R_i6| zmin, |t_i| (xmin = zmin * smallest non-zero |mx|, ...).
+// ------------------------------------------------------------------------------------------------
+struct Certificate { bool fast = false; bool ident_r = false; };
+
+Certificate certify_stream(const pcs_stream_config& s, const std::vector<float>& mx, const std::vector<float>& my)
+{
+    Certificate c;
+    const auto fin = [](double v) { return std::isfinite(v); };
+    const float* R = s.depth_to_color.rotation;
+    const float* t = s.depth_to_color.translation;
+    for (int k = 0; k < 9; k++) if (!fin(R[k])) return c;
+    for (int k = 0; k < 3; k++) if (!fin(t[k])) return c;
+    if (!fin(s.depth_scale) || !(s.depth_scale > 0.0f)) return c;
+    if (s.depth.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.depth)) return c;   // rays not separable
+    if (!fin(s.color.fx) || !fin(s.color.fy) || !fin(s.color.ppx) || !fin(s.color.ppy)) return c;
+    for (int k = 0; k < 5; k++) if (!fin(s.color.coeffs[k])) return c;
+
+    double mxmax = 0, mymax = 0, mxmin = INFINITY, mymin = INFINITY;   // min over non-zero magnitudes
+    for (float v : mx) { if (!fin(v)) return c; const double a = std::fabs((double)v); mxmax = std::max(mxmax, a); if (a > 0) mxmin = std::min(mxmin, a); }
+    for (float v : my) { if (!fin(v)) return c; const double a = std::fabs((double)v); mymax = std::max(mymax, a); if (a > 0) mymin = std::min(mymin, a); }
+    const double infl = 1.0 + std::ldexp(1.0, -20);
+    mxmax *= infl; mymax *= infl;
+    const double zmin = (double)s.depth_scale * (1.0 - std::ldexp(1.0, -22));
+    const double zmax = (double)s.depth_scale * 65535.0 * infl;
+    if (!(zmin >= std::ldexp(1.0, -40)) || !(zmax < std::ldexp(1.0, 28))) return c;
+    const double xmin = zmin * mxmin * (1.0 - std::ldexp(1.0, -22));
+    const double ymin = zmin * mymin * (1.0 - std::ldexp(1.0, -22));
+
+    const double lim_hi = std::ldexp(1.0, 30), lim_num = std::ldexp(1.0, -70), lim_den = std::ldexp(1.0, -40);
+    for (int i = 0; i < 3; i++) {
+        const double r0 = std::fabs((double)R[i]), r3 = std::fabs((double)R[i + 3]), r6 = std::fabs((double)R[i + 6]);
+        const double ti = std::fabs((double)t[i]);
+        const double sigma = r0 * mxmax + r3 * mymax + r6;
+        if (!(sigma * zmax + ti < lim_hi * 0.5)) return c;
+        // smallest non-zero addend (an addend whose coefficient is zero is an exact zero and drops out)
+        double small = INFINITY;
+        if (r0 > 0 && std::isfinite(xmin)) small = std::min(small, r0 * xmin);
+        if (r3 > 0 && std::isfinite(ymin)) small = std::min(small, r3 * ymin);
+        if (r6 > 0) small = std::min(small, r6 * zmin);
+        if (ti > 0) small = std::min(small, ti);
+        if (std::isfinite(small)) {
+            if (!(small * (1.0 - std::ldexp(1.0, -20)) >= std::ldexp(1.0, -46))) return c;   // no product underflows
+            if (i < 2 && !(std::ldexp(small, -24) >= lim_num)) return c;
+        }
+        if (i == 2) {
+            const double kappa = (double)R[8] - std::fabs((double)R[2]) * mxmax - std::fabs((double)R[5]) * mymax;
+            const double slack = std::ldexp(1.0, -21);
+            const double kp = kappa - slack * sigma;
+            if (!(kp > 0)) return c;
+            const double low = kp * zmin + (double)t[2] - slack * ti;
+            if (!(low >= lim_den)) return c;
+        }
+    }
+    c.fast = true;
+    // identity shortcut: R == I exactly, translation entries are not negative zero
+    static const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool ident = true;
+    for (int k = 0; k < 9; k++) {
+        uint32_t a, b; std::memcpy(&a, &R[k], 4); std::memcpy(&b, &I9[k], 4);
+        if (a != b) ident = false;
+    }
+    for (int k = 0; k < 3; k++) { uint32_t a; std::memcpy(&a, &t[k], 4); if (a == 0x80000000u) ident = false; }
+    c.ident_r = ident;
+    return c;
+}
+
+// floor(i / W) == umulhi(i, magic) >> shift for every i < 2^31 (Granlund-Montgomery round-up method,
+// N = 31 so the multiplier fits 32 bits); returns false (use '/') if it does not fit or fails the check.
+bool row_magic(uint32_t W, uint32_t H, uint32_t& magic, uint32_t& shift)
+{
+    magic = shift = 0;
+    if (W < 2) return false;
+    uint32_t l = 0;
+    while ((1ull << l) < W) l++;
+    const unsigned __int128 m = (((unsigned __int128)1 << (31 + l)) / W) + 1;
+    if (m >> 32) return false;
+    magic = (uint32_t)m; shift = l - 1;
+    auto ok = [&](uint64_t i) { return (uint32_t)(((uint64_t)i * magic) >> 32) >> shift == (uint32_t)(i / W); };
+    for (uint64_t r = 0; r < H; r++) {
+        const uint64_t a = r * W, b = r * W + W - 1;
+        if (a >= (1ull << 31)) break;
+        if (!ok(a) || (b < (1ull << 31) && !ok(b))) { magic = shift = 0; return false; }
+    }
+    if (!ok((1ull << 31) - 1)) { magic = shift = 0; return false; }
+    return true;
 }
 
 inline uint32_t tiles_of(uint32_t n) { return (n + kTilePoints - 1) / kTilePoints; }
@@ -200,10 +306,18 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         FramePtrs fp{};
         uint32_t mp = 0;
         for (int k = 0; k < nl; k++) { fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k]; mp = std::max(mp, c->h_params[s0 + k].n_points); }
+        int m = 2;                                   // AND over the streams of this launch
+        bool dd = false, cd = false;
+        for (int k = 0; k < nl; k++) {
+            m = std::min(m, c->math[s0 + k]);
+            dd |= c->h_params[s0 + k].ddist != 0;
+            cd |= c->h_params[s0 + k].cdist != 0;
+        }
+        const MathSel sel = m == 2 ? MathSel::CertIdentR : (m == 1 ? MathSel::Cert : MathSel::Ieee);
         if (dense)
-            HIPCHK(c, launch_fused_dense(c->d_params, s0, nl, mp, c->any_ddist, c->any_cdist, fp, d_payload, c->stream));
+            HIPCHK(c, launch_fused_dense(c->d_params, s0, nl, mp, dd, cd, sel, fp, d_payload, c->stream));
         else
-            HIPCHK(c, launch_fused_emit(c->d_params, s0, nl, mp, c->flags, c->downsample, fp, c->d_tile_prefix,
+            HIPCHK(c, launch_fused_emit(c->d_params, s0, nl, mp, c->flags, c->downsample, sel, fp, c->d_tile_prefix,
                                         c->d_stream_base, d_payload, c->stream));
     }
     if (!pred && d_counts) {
@@ -273,7 +387,7 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     if (cfg->n_streams < 1 || cfg->n_streams > PCS_MAX_STREAMS)
         return fail(nullptr, PCS_ERR_INVALID_ARG, "n_streams %d outside 1..%d", cfg->n_streams, PCS_MAX_STREAMS);
     if (cfg->downsample < 1) return fail(nullptr, PCS_ERR_INVALID_ARG, "downsample %d < 1", cfg->downsample);
-    if (cfg->flags & ~(PCS_FLAG_CUTOFF | PCS_FLAG_CUTOFF_COMPAT | PCS_FLAG_DROP_INVALID))
+    if (cfg->flags & ~(PCS_FLAG_CUTOFF | PCS_FLAG_CUTOFF_COMPAT | PCS_FLAG_DROP_INVALID | PCS_FLAG_FORCE_IEEE))
         return fail(nullptr, PCS_ERR_INVALID_ARG, "unknown flag bits 0x%x", cfg->flags);
     if ((cfg->flags & PCS_FLAG_CUTOFF_COMPAT) && !(cfg->flags & PCS_FLAG_CUTOFF))
         return fail(nullptr, PCS_ERR_INVALID_ARG, "PCS_FLAG_CUTOFF_COMPAT needs PCS_FLAG_CUTOFF");
@@ -336,6 +450,10 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         std::vector<float> mx(p.W), my(p.H);
         for (int x = 0; x < p.W; x++) mx[x] = ((float)x - p.d_ppx) / p.d_fx;
         for (int y = 0; y < p.H; y++) my[y] = ((float)y - p.d_ppy) / p.d_fy;
+        const Certificate cert = (c->flags & PCS_FLAG_FORCE_IEEE) ? Certificate{} : certify_stream(c->cfg[s], mx, my);
+        p.cert_fast = cert.fast ? 1 : 0;
+        p.ident_r = (cert.fast && cert.ident_r) ? 1 : 0;
+        row_magic((uint32_t)p.W, (uint32_t)p.H, p.w_magic, p.w_shift);
         float *dmx = nullptr, *dmy = nullptr;
         CREATE_CHK(hipMalloc((void**)&dmx, sizeof(float) * ((size_t)p.W + 8)));
         c->d_lut[2 * s] = dmx;
@@ -351,6 +469,36 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     CREATE_CHK(hipMalloc((void**)&c->d_tile_prefix, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_stream_base, sizeof(uint32_t) * (c->n_streams + 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_counts, sizeof(int32_t) * (c->n_streams + 1)));
+    {   // device certificate for CertMath::div_const: all 2^32 numerators, once per distinct raster dimension
+        std::vector<std::pair<int32_t, bool>> seen;
+        unsigned long long* d_bad = nullptr;
+        auto verified = [&](int32_t dim, bool& ok) -> hipError_t {
+            for (auto& pr : seen) if (pr.first == dim) { ok = pr.second; return hipSuccess; }
+            hipError_t e;
+            if (!d_bad && (e = hipMalloc((void**)&d_bad, sizeof(unsigned long long))) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) return e;
+            const float cf = (float)dim, rc = (float)(1.0 / (double)cf);
+            if ((e = launch_verify_div_const(cf, rc, dim, d_bad, c->stream)) != hipSuccess) return e;
+            unsigned long long h = 1;
+            if ((e = hipMemcpyAsync(&h, d_bad, sizeof h, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+            ok = (h == 0);
+            seen.emplace_back(dim, ok);
+            return hipSuccess;
+        };
+        for (int s = 0; s < c->n_streams; s++) {
+            StreamParams& p = c->h_params[s];
+            if (!p.cert_fast) continue;
+            bool okw = false, okh = false;
+            CREATE_CHK(verified(p.cW, okw));
+            CREATE_CHK(verified(p.cH, okh));
+            if (!(okw && okh)) { p.cert_fast = 0; p.ident_r = 0; }
+        }
+        if (d_bad) (void)hipFree(d_bad);
+    }
+    c->math.resize(c->n_streams);
+    for (int s = 0; s < c->n_streams; s++)
+        c->math[s] = c->h_params[s].cert_fast ? (c->h_params[s].ident_r ? 2 : 1) : 0;
     CREATE_CHK(hipMemcpy(c->d_params, c->h_params.data(), sizeof(StreamParams) * c->n_streams, hipMemcpyHostToDevice));
 #undef CREATE_CHK
     *out = c;
@@ -391,6 +539,12 @@ int pcs_stream_points(const pcs_ctx* c, int stream)
 {
     if (!c || stream < 0 || stream >= c->n_streams) return PCS_ERR_INVALID_ARG;
     return (int)c->h_params[stream].n_points;
+}
+
+int pcs_stream_math(const pcs_ctx* c, int stream)
+{
+    if (!c || stream < 0 || stream >= c->n_streams) return PCS_ERR_INVALID_ARG;
+    return c->math[stream];
 }
 
 size_t pcs_max_payload_shorts(const pcs_ctx* c)

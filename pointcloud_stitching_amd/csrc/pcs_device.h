@@ -28,6 +28,7 @@ struct alignas(16) StreamParams {
     float    d_ppx, d_ppy, d_fx, d_fy;
     float    c_fx, c_fy, c_ppx, c_ppy;
     float    c_w_f, c_h_f;   // (float)colour width / height
+    float    c_rw, c_rh;     // RN(1/c_w_f), RN(1/c_h_f) — for the verified constant-divisor quotient
     float    dk[5];          // depth distortion coefficients
     float    ck[5];          // colour distortion coefficients
     int32_t  W, H;           // depth raster
@@ -39,6 +40,9 @@ struct alignas(16) StreamParams {
     uint32_t out_base;       // first output point of this stream in the stitched payload when no
                              // predicate is active: sum over earlier streams of ceil(n/downsample)
     uint32_t tile_base;      // index of this stream's first tile in the per-tile count arrays
+    uint32_t w_magic, w_shift; // floor(i / W) == umulhi(i, w_magic) >> w_shift for i < 2^31 (0 = use '/')
+    int32_t  cert_fast;      // host+device certified for CertMath (see pcs_capi.cpp)
+    int32_t  ident_r;        // depth->colour rotation is exactly I, translation has no -0
     const float* mx;         // [W]  (c - ppx) / fx   — IEEE division done once on the host
     const float* my;         // [H]  (r - ppy) / fy
 };
@@ -56,9 +60,12 @@ struct VertexPtrs {          // a2 twin: one stream per launch
     uint32_t       n_points;
 };
 
+// Which arithmetic policy a launch may use (the AND over the streams of the launch).
+enum class MathSel { Ieee = 0, Cert = 1, CertIdentR = 2 };
+
 // Launchers (defined in pcs_kernels.hip). All enqueue on `st` and return the hipError of the launch.
 hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                              bool any_ddist, bool any_cdist, const FramePtrs& fp, int16_t* d_payload,
+                              bool any_ddist, bool any_cdist, MathSel math, const FramePtrs& fp, int16_t* d_payload,
                               hipStream_t st);
 
 // Generic path: predicate / downsample / unaligned payload / W % 8 != 0.
@@ -72,9 +79,10 @@ hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsamp
                        const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_base,
                        int32_t* d_counts, hipStream_t st);
 hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                             uint32_t flags, int downsample, const FramePtrs& fp,
+                             uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
                              const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
                              int16_t* d_payload, hipStream_t st);
+hipError_t launch_verify_div_const(float c, float rc, int32_t dim, unsigned long long* d_bad, hipStream_t st);
 
 // a2 twin.
 hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const VertexPtrs& vp,

@@ -51,14 +51,124 @@ __device__ __forceinline__ int32_t cvtt_x86(float f)
     return (__builtin_fabsf(f) < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000;
 }
 
-// a2 colour lookup (src/pcs-camera-optimized.cpp:431-452, 584-585). Returns R | G<<8 | B<<16, which is
-// exactly shorts 3 and 4 of the record as one little-endian dword.
-__device__ __forceinline__ uint32_t color_word(const StreamParams& P, const uint8_t* __restrict__ color,
-                                               float u, float v)
+// v_cvt_i32_f32 as the hardware does it: truncate, saturate, NaN -> 0.
+__device__ __forceinline__ int32_t cvt_sat(float f)
 {
-    const float xf = __fmaf_rn(u, P.c_w_f, 0.5f);
-    const float yf = __fmaf_rn(v, P.c_h_f, 0.5f);
-    int32_t xi = cvtt_x86(xf), yi = cvtt_x86(yf);
+    int32_t i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+    return i;
+}
+
+// Float->int conversion policies. The five conversions of a point (world x,y,z; colour column,row) are
+// consumed only as `& 0xFFFF` or as clamp(., 0, dim-1). Under those two uses the saturating hardware
+// convert differs from cvttss2si in exactly one case: f >= 2^31 (hardware INT_MAX, x86 INT_MIN); NaN
+// gives 0 vs INT_MIN, which agree both in the low 16 bits and after the clamp. LazyCvt therefore uses
+// the 1-instruction hardware convert and keeps a running maximum of everything it converted (v_max3
+// ignores NaN); the tile code re-does a lane's points with ExactCvt in the (practically never taken)
+// case that the maximum reached 2^31.
+struct ExactCvt {
+    __device__ __forceinline__ void note(float, float, float, float, float) {}
+    __device__ __forceinline__ int32_t cvt(float f) const { return cvtt_x86(f); }
+    __device__ __forceinline__ bool overflowed() const { return false; }
+};
+struct LazyCvt {
+    float hi = 0.0f;
+    __device__ __forceinline__ void note(float a, float b, float c, float d, float e)
+    {
+        hi = __builtin_fmaxf(__builtin_fmaxf(hi, a), b);
+        hi = __builtin_fmaxf(__builtin_fmaxf(hi, c), d);
+        hi = __builtin_fmaxf(hi, e);
+    }
+    __device__ __forceinline__ int32_t cvt(float f) const { return cvt_sat(f); }
+    __device__ __forceinline__ bool overflowed() const { return hi >= 2147483648.0f; }
+};
+
+// Arithmetic policy of the depth->colour projection. Every policy the product launches is bit-identical
+// to IeeeMath on the inputs it is launched for (see "certification" in pcs_capi.cpp and DESIGN.md);
+// tools/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
+struct IeeeMath {
+    static constexpr bool kLazyCvt = false;
+    // rs2_transform_point_to_point: R column-major, products and sums individually rounded, left to right
+    static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
+                                               float& P0, float& P1, float& P2)
+    {
+        P0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[0], X), __fmul_rn(P.R[3], Y)), __fmul_rn(P.R[6], Z)), P.t[0]);
+        P1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[1], X), __fmul_rn(P.R[4], Y)), __fmul_rn(P.R[7], Z)), P.t[1]);
+        P2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[2], X), __fmul_rn(P.R[5], Y)), __fmul_rn(P.R[8], Z)), P.t[2]);
+    }
+    // two quotients over one denominator (rs2_project_point_to_pixel: x = P0/P2, y = P1/P2)
+    static __device__ __forceinline__ void div2(float a0, float a1, float b, float& q0, float& q1)
+    {
+        q0 = __fdiv_rn(a0, b);
+        q1 = __fdiv_rn(a1, b);
+    }
+    // quotient by a wave-uniform constant (pixel_to_texcoord: px / width); rc = host-computed RN(1/c)
+    static __device__ __forceinline__ float div_const(float a, float c, float /*rc*/) { return __fdiv_rn(a, c); }
+};
+
+// CertMath: the same results with fewer instructions, launched only for streams whose configuration
+// the host has certified (pcs_capi.cpp: certify_stream) and, for div_const, the device has verified.
+//  * div2 is the IEEE-754 division expansion of this compiler (v_rcp, one Newton step on the
+//    reciprocal, multiply, two fused corrections) WITHOUT v_div_scale / v_div_fmas / v_div_fixup, with
+//    the refined reciprocal shared by both numerators. v_div_scale only ever rescales operands whose
+//    exponents lie outside a window; the host proves from the configuration (depth scale, LUT ranges,
+//    R, t) that every valid pixel's P0,P1,P2 lie inside it, and the pixels it cannot speak for (depth 0)
+//    have their quotients discarded. Inside the window the two sequences are the same arithmetic.
+//  * div_const is Markstein's quotient: with y = RN(1/c), q0 = RN(a*y), r = a - c*q0 (exact in one fma),
+//    q = RN(q0 + r*y). It is consumed only through trunc(fma(q, c, 0.5)) clamped to [0, c-1]; that
+//    composite is compared with the IEEE one over ALL 2^32 numerators on the device when the context
+//    is created (pcs_verify_div_const_kernel) and CertMath is used only if no numerator differs.
+//  * IDENT_R: depth->colour rotation is exactly the identity (and t has no negative zeros), so
+//    R*p + t is p + t: the dropped products are exact (1*x) or signed zeros that cannot change a sum.
+template <bool IDENT_R>
+struct CertMath {
+    static constexpr bool kLazyCvt = true;
+    static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
+                                               float& P0, float& P1, float& P2)
+    {
+        if (IDENT_R) {
+            P0 = __fadd_rn(X, P.t[0]);
+            P1 = __fadd_rn(Y, P.t[1]);
+            P2 = __fadd_rn(Z, P.t[2]);
+        } else {
+            IeeeMath::d2c(P, X, Y, Z, P0, P1, P2);
+        }
+    }
+    static __device__ __forceinline__ void div2(float a0, float a1, float b, float& q0, float& q1)
+    {
+        float y = __builtin_amdgcn_rcpf(b);
+        const float e = __fmaf_rn(-b, y, 1.0f);
+        y = __fmaf_rn(e, y, y);
+        float q = __fmul_rn(a0, y);
+        float r = __fmaf_rn(-b, q, a0);
+        q = __fmaf_rn(r, y, q);
+        r = __fmaf_rn(-b, q, a0);
+        q0 = __fmaf_rn(r, y, q);
+        q = __fmul_rn(a1, y);
+        r = __fmaf_rn(-b, q, a1);
+        q = __fmaf_rn(r, y, q);
+        r = __fmaf_rn(-b, q, a1);
+        q1 = __fmaf_rn(r, y, q);
+    }
+    static __device__ __forceinline__ float div_const(float a, float c, float rc)
+    {
+        const float q0 = __fmul_rn(a, rc);
+        const float r = __fmaf_rn(-c, q0, a);
+        return __fmaf_rn(r, rc, q0);
+    }
+};
+
+// a2 colour lookup (src/pcs-camera-optimized.cpp:431-452, 584-585): texcoord -> byte index of the pixel.
+__device__ __forceinline__ void color_coords(const StreamParams& P, float u, float v, float& xf, float& yf)
+{
+    xf = __fmaf_rn(u, P.c_w_f, 0.5f);
+    yf = __fmaf_rn(v, P.c_h_f, 0.5f);
+}
+
+// Returns R | G<<8 | B<<16, which is exactly shorts 3 and 4 of the record as one little-endian dword.
+__device__ __forceinline__ uint32_t color_fetch(const StreamParams& P, const uint8_t* __restrict__ color,
+                                                int32_t xi, int32_t yi)
+{
     xi = min(max(xi, 0), P.cW - 1);
     yi = min(max(yi, 0), P.cH - 1);
     // xi < 2^24, bpp small, yi < 2^24, stride < 2^24: 24-bit multiplies are exact in 32 bits and full rate
@@ -70,15 +180,14 @@ __device__ __forceinline__ uint32_t color_word(const StreamParams& P, const uint
     return (w >> ((idx - off) * 8u)) & 0x00FFFFFFu;
 }
 
-// a2 rigid transform + scale + truncate (src/pcs-camera-optimized.cpp:455-491, 581-583).
+// a2 rigid transform + scale (src/pcs-camera-optimized.cpp:455-491).
 // Order matters: x*col0 + t first, then + y*col1, then + z*col2; then a separately rounded * 1000.0f.
-__device__ __forceinline__ uint32_t world_mm16(const float* __restrict__ Mr, float X, float Y, float Z)
+__device__ __forceinline__ float world_mm(const float* __restrict__ Mr, float X, float Y, float Z)
 {
     float a = __fmaf_rn(X, Mr[0], Mr[3]);
     a = __fmaf_rn(Y, Mr[1], a);
     a = __fmaf_rn(Z, Mr[2], a);
-    a = __fmul_rn(a, 1000.0f);
-    return (uint32_t)cvtt_x86(a) & 0xFFFFu;
+    return __fmul_rn(a, 1000.0f);
 }
 
 struct Record {              // one 10-byte point as three pieces
@@ -87,13 +196,21 @@ struct Record {              // one 10-byte point as three pieces
     uint32_t b;              // B            (low 16 bits valid)
 };
 
+// One point -> one record. short(float) (:581-583) keeps the low 16 bits of the converted value.
+template <class Cvt>
 __device__ __forceinline__ Record make_record(const StreamParams& P, const uint8_t* __restrict__ color,
-                                              const PointIn& p)
+                                              const PointIn& p, Cvt& cv)
 {
-    const uint32_t x = world_mm16(P.M + 0, p.X, p.Y, p.Z);
-    const uint32_t y = world_mm16(P.M + 4, p.X, p.Y, p.Z);
-    const uint32_t z = world_mm16(P.M + 8, p.X, p.Y, p.Z);
-    const uint32_t w = color_word(P, color, p.u, p.v);
+    const float ax = world_mm(P.M + 0, p.X, p.Y, p.Z);
+    const float ay = world_mm(P.M + 4, p.X, p.Y, p.Z);
+    const float az = world_mm(P.M + 8, p.X, p.Y, p.Z);
+    float xf, yf;
+    color_coords(P, p.u, p.v, xf, yf);
+    cv.note(ax, ay, az, xf, yf);
+    const uint32_t x = (uint32_t)cv.cvt(ax) & 0xFFFFu;
+    const uint32_t y = (uint32_t)cv.cvt(ay);
+    const uint32_t z = (uint32_t)cv.cvt(az) & 0xFFFFu;
+    const uint32_t w = color_fetch(P, color, cv.cvt(xf), cv.cvt(yf));
     Record r;
     r.xy = x | (y << 16);
     r.zc = z | (w << 16);
@@ -119,7 +236,7 @@ __device__ __forceinline__ float bc_tangential(float a, float kA, float kB, floa
 }
 
 // a5 for one pixel: depth value d, normalised ray (mx,my) from the LUTs.
-template <bool DDIST, bool CDIST>
+template <bool DDIST, bool CDIST, class Mth>
 __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32_t d, float mx, float my)
 {
     const float z = __fmul_rn(P.depth_scale, (float)d);
@@ -134,12 +251,11 @@ __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32
     p.X = __fmul_rn(z, mx);
     p.Y = __fmul_rn(z, my);
     p.Z = z;
-    // rs2_transform_point_to_point: R column-major, sums left to right
-    const float P0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[0], p.X), __fmul_rn(P.R[3], p.Y)), __fmul_rn(P.R[6], p.Z)), P.t[0]);
-    const float P1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[1], p.X), __fmul_rn(P.R[4], p.Y)), __fmul_rn(P.R[7], p.Z)), P.t[1]);
-    const float P2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.R[2], p.X), __fmul_rn(P.R[5], p.Y)), __fmul_rn(P.R[8], p.Z)), P.t[2]);
+    float P0, P1, P2;
+    Mth::d2c(P, p.X, p.Y, p.Z, P0, P1, P2);
     // rs2_project_point_to_pixel
-    float x = __fdiv_rn(P0, P2), y = __fdiv_rn(P1, P2);
+    float x, y;
+    Mth::div2(P0, P1, P2, x, y);
     if (CDIST && P.cdist) {
         const float r2 = __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
         const float f = bc_radial(P.ck, r2);
@@ -152,8 +268,8 @@ __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32
     const float py = __fadd_rn(__fmul_rn(y, P.c_fy), P.c_ppy);
     // pixel_to_texcoord; invalid depth (z == 0) -> texcoord (0,0)
     const bool valid = (z != 0.0f);
-    p.u = valid ? __fdiv_rn(px, P.c_w_f) : 0.0f;
-    p.v = valid ? __fdiv_rn(py, P.c_h_f) : 0.0f;
+    p.u = valid ? Mth::div_const(px, P.c_w_f, P.c_rw) : 0.0f;
+    p.v = valid ? Mth::div_const(py, P.c_h_f, P.c_rh) : 0.0f;
     return p;
 }
 
@@ -212,8 +328,9 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t c, uint32_t& wa
 // ------------------------------------------------------------------------------------------------
 
 // Z16 raster + LUTs -> points (the fused a5 stage).
-template <bool DDIST, bool CDIST>
+template <bool DDIST, bool CDIST, class Mth = IeeeMath>
 struct DepthSource {
+    using Math = Mth;
     const uint16_t* __restrict__ depth;
 
     __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8],
@@ -226,7 +343,8 @@ struct DepthSource {
         }
         if ((P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0) {
             // all 8 pixels on one raster row; one 16-byte depth load, two 16-byte LUT loads
-            const uint32_t r = i0 / (uint32_t)P.W;
+            // floor(i0 / W) by the host-verified multiply-shift (i0 < 2^31)
+            const uint32_t r = P.w_magic ? (__umulhi(i0, P.w_magic) >> P.w_shift) : i0 / (uint32_t)P.W;
             const uint32_t c0 = i0 - r * (uint32_t)P.W;
             const uint4 dv = *reinterpret_cast<const uint4*>(depth + i0);
             const gptr<float> lut_x = as_global(P.mx);
@@ -238,7 +356,7 @@ struct DepthSource {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
-                p[k] = deproject_pixel<DDIST, CDIST>(P, d, mxs[k], my);
+                p[k] = deproject_pixel<DDIST, CDIST, Mth>(P, d, mxs[k], my);
             }
         } else {
 #pragma unroll
@@ -246,7 +364,7 @@ struct DepthSource {
                 const uint32_t i = min(i0 + k, n - 1);
                 const uint32_t r = i / (uint32_t)P.W;
                 const uint32_t c = i - r * (uint32_t)P.W;
-                p[k] = deproject_pixel<DDIST, CDIST>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+                p[k] = deproject_pixel<DDIST, CDIST, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
             }
         }
     }
@@ -257,6 +375,7 @@ struct DepthSource {
 // The AoS arrays are pulled in with lane-contiguous 16-byte loads and transposed through LDS; a lane
 // then picks up its 8 points (96 B + 64 B) from LDS.
 struct VertexSource {
+    using Math = IeeeMath;
     const float* __restrict__ vertices;
     const float* __restrict__ texcoords;
 
@@ -314,8 +433,11 @@ __device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, 
     const uint32_t end = head + nbytes;
     const uint32_t first_full = (head + 15u) >> 4;           // first chunk entirely inside
     const uint32_t last_full = end >> 4;                     // one past the last chunk entirely inside
+    // nontemporal: the payload is written once and never re-read by this kernel; keeping it out of the
+    // caches' way measured +7 % on the store-dominated stream (tools/kernel_lab.hip, skeleton nt-store)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     for (uint32_t j = first_full + threadIdx.x; j < last_full; j += kBlockThreads)
-        reinterpret_cast<uint4*>(g0)[j] = reinterpret_cast<const uint4*>(lds)[j];
+        __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(lds)[j], reinterpret_cast<u32x4*>(g0) + j);
     // ragged head: shorts in [head, min(first_full*16, end)); ragged tail: [max(last_full*16, head), end)
     const uint32_t head_end = min(first_full << 4, end);
     for (uint32_t b = head + 2u * threadIdx.x; b < head_end; b += 2u * kBlockThreads)
@@ -344,16 +466,26 @@ __device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src
     if (Src::kUsesLdsInput) __syncthreads();     // staging aliases the input region
 
     uint32_t w[20];
+    auto fill = [&](auto& cv) {
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-        const Record a = make_record(P, color, p[k]);
-        const Record b = make_record(P, color, p[k + 1]);
-        uint32_t* o = w + (k >> 1) * 5;
-        o[0] = a.xy;
-        o[1] = a.zc;
-        o[2] = (a.b & 0xFFFFu) | (b.xy << 16);
-        o[3] = (b.xy >> 16) | (b.zc << 16);
-        o[4] = (b.zc >> 16) | (b.b << 16);
+        for (int k = 0; k < 8; k += 2) {
+            const Record a = make_record(P, color, p[k], cv);
+            const Record b = make_record(P, color, p[k + 1], cv);
+            uint32_t* o = w + (k >> 1) * 5;
+            o[0] = a.xy;
+            o[1] = a.zc;
+            o[2] = (a.b & 0xFFFFu) | (b.xy << 16);
+            o[3] = (b.xy >> 16) | (b.zc << 16);
+            o[4] = (b.zc >> 16) | (b.b << 16);
+        }
+    };
+    if (Src::Math::kLazyCvt) {
+        LazyCvt lazy;
+        fill(lazy);
+        if (__builtin_expect(lazy.overflowed(), 0)) { ExactCvt exact; fill(exact); }
+    } else {
+        ExactCvt exact;
+        fill(exact);
     }
     uint4* mine = stage + threadIdx.x * 5;
 #pragma unroll
@@ -414,7 +546,8 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
     for (int k = 0; k < 8; k++) {
         if ((keep >> k) & 1u) {
             if (g % ds == 0) {
-                const Record r = make_record(P, color, p[k]);
+                ExactCvt exact;
+                const Record r = make_record(P, color, p[k], exact);
                 const uint32_t q = out_first + g / ds;
                 uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + (q - q_lo) * PCS_POINT_BYTES);
                 o[0] = (uint16_t)r.xy; o[1] = (uint16_t)(r.xy >> 16);
@@ -432,7 +565,7 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
 // Kernels
 // ------------------------------------------------------------------------------------------------
 
-template <bool DDIST, bool CDIST>
+template <bool DDIST, bool CDIST, class Mth>
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp,
                             uint8_t* __restrict__ payload_bytes)
@@ -443,7 +576,7 @@ void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
-    DepthSource<DDIST, CDIST> src{fp.depth[s]};
+    DepthSource<DDIST, CDIST, Mth> src{fp.depth[s]};
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
@@ -470,7 +603,7 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-template <bool DDIST, bool CDIST, bool PRED>
+template <bool PRED, class Mth>
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                            uint32_t ds, const uint32_t* __restrict__ tile_prefix,
@@ -483,10 +616,10 @@ void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0,
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
-    DepthSource<DDIST, CDIST> src{fp.depth[s]};
+    DepthSource<true, true, Mth> src{fp.depth[s]};
     const uint32_t g0 = PRED ? tile_prefix[P.tile_base + blockIdx.x] : tile0;
     const uint32_t out_first = PRED ? stream_base[stream0 + s] : P.out_base;
-    generic_tile<DepthSource<DDIST, CDIST>, PRED>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
+    generic_tile<DepthSource<true, true, Mth>, PRED>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
                                                   payload_bytes, stage, wsum, nullptr);
 }
 
@@ -609,7 +742,7 @@ void pcs_deproject_kernel(const StreamParams* __restrict__ params, int stream, c
     if (i >= P.n_points) return;
     const uint32_t r = i / (uint32_t)P.W;
     const uint32_t c = i - r * (uint32_t)P.W;
-    const PointIn p = deproject_pixel<DDIST, CDIST>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+    const PointIn p = deproject_pixel<DDIST, CDIST, IeeeMath>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
     vertices[3 * (size_t)i + 0] = p.X;
     vertices[3 * (size_t)i + 1] = p.Y;
     vertices[3 * (size_t)i + 2] = p.Z;
@@ -637,6 +770,28 @@ void pcs_stitch_kernel(const uint16_t* __restrict__ src, uint32_t out_points, ui
     store_staged(stage, head, pts * PCS_POINT_BYTES, gdst);
 }
 
+// Device-side certificate for CertMath::div_const: over ALL 2^32 numerators a, the pixel coordinate that
+// the pack derives from a quotient by the raster dimension c — clamp(cvttss2si(fma(a/c, c, 0.5)), 0, c-1)
+// — is the same with Markstein's quotient as with the IEEE one. Run once per distinct dimension when a
+// context is created (about a millisecond); any difference disables CertMath for that stream.
+__global__ __launch_bounds__(256)
+void pcs_verify_div_const_kernel(float c, float rc, int32_t dim, unsigned long long* __restrict__ bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t local = 0;
+    for (uint64_t bits = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; bits < (1ull << 32); bits += stride) {
+        const float a = __uint_as_float((uint32_t)bits);
+        const float f1 = __fmaf_rn(IeeeMath::div_const(a, c, rc), c, 0.5f);
+        const float f2 = __fmaf_rn(CertMath<false>::div_const(a, c, rc), c, 0.5f);
+        const int32_t i1 = min(max(cvtt_x86(f1), 0), dim - 1);
+        const int32_t i2 = min(max(cvtt_x86(f2), 0), dim - 1);
+        // the lazy convert must also agree whenever it is the one used (f2 < 2^31 or NaN)
+        const int32_t i3 = (f2 >= 2147483648.0f) ? i2 : min(max(cvt_sat(f2), 0), dim - 1);
+        local += (i1 != i2) | (i2 != i3);
+    }
+    if (local) atomicAdd(bad, (unsigned long long)local);
+}
+
 inline dim3 tile_grid(uint32_t max_points, int n_launch)
 {
     return dim3((max_points + kTilePoints - 1) / kTilePoints, (unsigned)n_launch, 1);
@@ -648,21 +803,27 @@ inline dim3 tile_grid(uint32_t max_points, int n_launch)
 // Launchers
 // ------------------------------------------------------------------------------------------------
 
-#define PCS_DISPATCH_DIST(DD, CD, ...)                         \
+#define PCS_DISPATCH_DIST_UNUSED(DD, CD, ...)                         \
     do {                                                       \
         if (DD) { if (CD) { __VA_ARGS__(true, true); } else { __VA_ARGS__(true, false); } } \
         else    { if (CD) { __VA_ARGS__(false, true); } else { __VA_ARGS__(false, false); } } \
     } while (0)
 
 hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                              bool any_ddist, bool any_cdist, const FramePtrs& fp, int16_t* d_payload,
+                              bool any_ddist, bool any_cdist, MathSel math, const FramePtrs& fp, int16_t* d_payload,
                               hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     const dim3 grid = tile_grid(max_points, n_launch);
-#define L(DD, CD) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD>), grid, dim3(kBlockThreads), 0, st, \
-                                     d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload))
-    PCS_DISPATCH_DIST(any_ddist, any_cdist, L);
+#define L(DD, CD, M) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD, M>), grid, dim3(kBlockThreads), 0, st, \
+                                        d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload))
+    if (math != MathSel::Ieee && !any_ddist) {
+        if (math == MathSel::CertIdentR) { if (any_cdist) L(false, true, CertMath<true>); else L(false, false, CertMath<true>); }
+        else                             { if (any_cdist) L(false, true, CertMath<false>); else L(false, false, CertMath<false>); }
+    } else {
+        if (any_ddist) { if (any_cdist) L(true, true, IeeeMath); else L(true, false, IeeeMath); }
+        else           { if (any_cdist) L(false, true, IeeeMath); else L(false, false, IeeeMath); }
+    }
 #undef L
     return hipGetLastError();
 }
@@ -688,7 +849,7 @@ hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsamp
 }
 
 hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                             uint32_t flags, int downsample, const FramePtrs& fp,
+                             uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
                              const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
                              int16_t* d_payload, hipStream_t st)
 {
@@ -696,12 +857,17 @@ hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_la
     const dim3 grid = tile_grid(max_points, n_launch);
     const bool pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
     uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
-    if (pred)
-        hipLaunchKernelGGL((pcs_fused_emit_kernel<true, true, true>), grid, dim3(kBlockThreads), 0, st,
-                           d_params, stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_base, out);
-    else
-        hipLaunchKernelGGL((pcs_fused_emit_kernel<true, true, false>), grid, dim3(kBlockThreads), 0, st,
-                           d_params, stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_base, out);
+#define L(PR, M) hipLaunchKernelGGL((pcs_fused_emit_kernel<PR, M>), grid, dim3(kBlockThreads), 0, st, d_params, stream0, \
+                                    fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_base, out)
+    if (math != MathSel::Ieee) { if (pred) L(true, CertMath<false>); else L(false, CertMath<false>); }
+    else                       { if (pred) L(true, IeeeMath); else L(false, IeeeMath); }
+#undef L
+    return hipGetLastError();
+}
+
+hipError_t launch_verify_div_const(float c, float rc, int32_t dim, unsigned long long* d_bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(pcs_verify_div_const_kernel, dim3(8192), dim3(256), 0, st, c, rc, dim, d_bad);
     return hipGetLastError();
 }
 

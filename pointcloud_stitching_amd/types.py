@@ -19,6 +19,7 @@ MAX_STREAMS = 64
 FLAG_CUTOFF = 0x1
 FLAG_CUTOFF_COMPAT = 0x2
 FLAG_DROP_INVALID = 0x4
+FLAG_FORCE_IEEE = 0x8
 
 DISTORTION_NONE = 0
 DISTORTION_MODIFIED_BROWN_CONRADY = 1
