@@ -125,6 +125,7 @@ void fill_params(const pcs_stream_config& s, StreamParams& p)
     p.d_ppx = s.depth.ppx; p.d_ppy = s.depth.ppy; p.d_fx = s.depth.fx; p.d_fy = s.depth.fy;
     p.c_fx = s.color.fx; p.c_fy = s.color.fy; p.c_ppx = s.color.ppx; p.c_ppy = s.color.ppy;
     p.c_w_f = (float)s.color.width; p.c_h_f = (float)s.color.height;
+    p.c_wm1_f = (float)(s.color.width - 1); p.c_hm1_f = (float)(s.color.height - 1);
     p.c_rw = (float)(1.0 / (double)p.c_w_f); p.c_rh = (float)(1.0 / (double)p.c_h_f);
     for (int k = 0; k < 5; k++) { p.dk[k] = s.depth.coeffs[k]; p.ck[k] = s.color.coeffs[k]; }
     p.W = s.depth.width; p.H = s.depth.height;

@@ -28,6 +28,7 @@ struct alignas(16) StreamParams {
     float    d_ppx, d_ppy, d_fx, d_fy;
     float    c_fx, c_fy, c_ppx, c_ppy;
     float    c_w_f, c_h_f;   // (float)colour width / height
+    float    c_wm1_f, c_hm1_f; // (float)(colour width - 1) / (height - 1)
     float    c_rw, c_rh;     // RN(1/c_w_f), RN(1/c_h_f) — for the verified constant-divisor quotient
     float    dk[5];          // depth distortion coefficients
     float    ck[5];          // colour distortion coefficients

@@ -69,6 +69,11 @@ __device__ __forceinline__ int32_t cvt_sat(float f)
 struct ExactCvt {
     __device__ __forceinline__ void note(float, float, float, float, float) {}
     __device__ __forceinline__ int32_t cvt(float f) const { return cvtt_x86(f); }
+    // colour column / row: clamp(cvttss2si(f), 0, dim-1)   (:438-444)
+    __device__ __forceinline__ int32_t pixel(float f, int32_t dim_m1, float) const
+    {
+        return min(max(cvtt_x86(f), 0), dim_m1);
+    }
     __device__ __forceinline__ bool overflowed() const { return false; }
 };
 struct LazyCvt {
@@ -80,6 +85,12 @@ struct LazyCvt {
         hi = __builtin_fmaxf(hi, e);
     }
     __device__ __forceinline__ int32_t cvt(float f) const { return cvt_sat(f); }
+    // Clamp in the float domain first (one v_med3_f32; NaN -> 0 like the x86 path), then convert: for
+    // f < 2^31 this equals clamp(trunc(f), 0, dim-1); f >= 2^31 is the case overflowed() reports.
+    __device__ __forceinline__ int32_t pixel(float f, int32_t, float dim_m1_f) const
+    {
+        return cvt_sat(__builtin_amdgcn_fmed3f(f, 0.0f, dim_m1_f));
+    }
     __device__ __forceinline__ bool overflowed() const { return hi >= 2147483648.0f; }
 };
 
@@ -169,8 +180,6 @@ __device__ __forceinline__ void color_coords(const StreamParams& P, float u, flo
 __device__ __forceinline__ uint32_t color_fetch(const StreamParams& P, const uint8_t* __restrict__ color,
                                                 int32_t xi, int32_t yi)
 {
-    xi = min(max(xi, 0), P.cW - 1);
-    yi = min(max(yi, 0), P.cH - 1);
     // xi < 2^24, bpp small, yi < 2^24, stride < 2^24: 24-bit multiplies are exact in 32 bits and full rate
     const uint32_t idx = __umul24((uint32_t)xi, (uint32_t)P.bpp) + __umul24((uint32_t)yi, (uint32_t)P.stride);
     // One dword covers R,G,B. Never read past the raster: slide the window back at the very end.
@@ -210,7 +219,7 @@ __device__ __forceinline__ Record make_record(const StreamParams& P, const uint8
     const uint32_t x = (uint32_t)cv.cvt(ax) & 0xFFFFu;
     const uint32_t y = (uint32_t)cv.cvt(ay);
     const uint32_t z = (uint32_t)cv.cvt(az) & 0xFFFFu;
-    const uint32_t w = color_fetch(P, color, cv.cvt(xf), cv.cvt(yf));
+    const uint32_t w = color_fetch(P, color, cv.pixel(xf, P.cW - 1, P.c_wm1_f), cv.pixel(yf, P.cH - 1, P.c_hm1_f));
     Record r;
     r.xy = x | (y << 16);
     r.zc = z | (w << 16);
@@ -266,10 +275,14 @@ __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32
     }
     const float px = __fadd_rn(__fmul_rn(x, P.c_fx), P.c_ppx);
     const float py = __fadd_rn(__fmul_rn(y, P.c_fy), P.c_ppy);
-    // pixel_to_texcoord; invalid depth (z == 0) -> texcoord (0,0)
+    // pixel_to_texcoord; invalid depth (z == 0) -> texcoord (0,0). The quotients are computed
+    // unconditionally and then selected: a conditional here becomes a divergent branch per pixel, which
+    // stops the scheduler from interleaving the 8 pixels of a lane.
+    const float qu = Mth::div_const(px, P.c_w_f, P.c_rw);
+    const float qv = Mth::div_const(py, P.c_h_f, P.c_rh);
     const bool valid = (z != 0.0f);
-    p.u = valid ? Mth::div_const(px, P.c_w_f, P.c_rw) : 0.0f;
-    p.v = valid ? Mth::div_const(py, P.c_h_f, P.c_rh) : 0.0f;
+    p.u = valid ? qu : 0.0f;
+    p.v = valid ? qv : 0.0f;
     return p;
 }
 

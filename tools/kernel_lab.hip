@@ -237,7 +237,7 @@ int main(int argc, char** argv)
         p.depth_scale = 0.001f;
         p.d_ppx = ppx; p.d_ppy = ppy; p.d_fx = p.d_fy = fx;
         p.c_fx = p.c_fy = fx; p.c_ppx = ppx; p.c_ppy = ppy;
-        p.c_w_f = (float)W; p.c_h_f = (float)H; p.c_rw = (float)(1.0 / W); p.c_rh = (float)(1.0 / H);
+        p.c_w_f = (float)W; p.c_h_f = (float)H; p.c_wm1_f = (float)(W - 1); p.c_hm1_f = (float)(H - 1); p.c_rw = (float)(1.0 / W); p.c_rh = (float)(1.0 / H);
         p.W = W; p.H = H; p.cW = W; p.cH = H; p.bpp = 3; p.stride = 3 * W;
         p.color_bytes = 3u * W * H; p.n_points = N; p.out_base = s * N; p.tile_base = s * ((N + 2047) / 2048);
         p.mx = dmx; p.my = dmy;
