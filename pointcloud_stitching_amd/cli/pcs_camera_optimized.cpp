@@ -1,0 +1,242 @@
+// pcs-camera-optimized (MI355X) — work-alike of the reference's edge benchmark/server
+// (src/pcs-camera-optimized.cpp) on top of libpcs_hip.so. Host code only: getopt surface, frame loop,
+// timing, stdout lines and the TCP push are kept; the per-frame work goes through the C ABI.
+//
+//   reference flags (getopt "hf:vst:cmz", :122):  -h  -f <file>  -v  -s  -t <n>  -c  -m  -z
+//   additions:  -g <dev>  -n <streams>  -d <stride>  -i (drop invalid depth)  -C (reference -c lane quirk)
+//               -r <frames>  -o <file> (dump last stitched buffer)  -p <port>
+//
+//   -f takes "synth:<W>x<H>" (deterministic synthetic frames; the reference's bags are LFS stubs and
+//   need librealsense) or a .pcsraw dump (see pointcloud_stitching_amd/synthetic.py: write_pcsraw).
+//   Without -f the reference grabs from a live RealSense camera; that needs librealsense and a camera,
+//   neither of which this build has: it says so and exits non-zero.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include <getopt.h>
+#include <netinet/in.h>
+#include <signal.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include "pcs_synth.h"
+
+typedef std::chrono::high_resolution_clock clockTime;
+typedef std::chrono::duration<double, std::milli> timeMilli;
+
+static const char* filename = nullptr;
+static bool display_updates = false, send_buffer = false, cutoff = false, use_hip = false, compress = false;
+static bool cutoff_compat = false, drop_invalid = false;
+static int num_of_threads = 1, device = 0, n_streams = 1, downsample = 1, max_frames = 60, port = 8000;
+static const char* dump_path = nullptr;
+static int client_sock = 0, sockfd = 0;
+
+static void print_usage()
+{
+    printf("\nUsage: pcs-camera-optimized -f <synth:WxH | frames.pcsraw> [-m] [-t n] [-c] [-s] [-n streams] [-g gpu]\n"
+           "  -f <src>  frame source (synthetic generator or raw dump)\n"
+           "  -s        send data to central camera server if available (TCP push on port 8000)\n"
+           "  -m        use the MI355X HIP path (the reference's SIMD switch)\n"
+           "  -t <n>    OpenMP threads of the reference path; accepted, inert on the HIP path\n"
+           "  -c        cutoff 0<z<=1.5, -2<x<=2 with compaction   -C  same with the reference's lane quirk\n"
+           "  -i        drop invalid-depth pixels   -d <n> keep every n-th point   -n <N> camera streams\n"
+           "  -g <dev>  GPU ordinal   -r <frames>   -o <file> dump last stitched buffer   -p <port>\n\n");
+}
+
+static void parseArgs(int argc, char** argv)
+{
+    int c;
+    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:")) != -1) {
+        switch (c) {
+            case 'h': print_usage(); exit(0);
+            case 'f': filename = optarg; break;
+            case 'v': display_updates = true; break;
+            case 's': send_buffer = true; break;
+            case 't': num_of_threads = atoi(optarg); break;
+            case 'c': cutoff = true; break;
+            case 'C': cutoff = true; cutoff_compat = true; break;
+            case 'm': use_hip = true; break;
+            case 'z': compress = true; break;
+            case 'g': device = atoi(optarg); break;
+            case 'n': n_streams = atoi(optarg); break;
+            case 'd': downsample = atoi(optarg); break;
+            case 'i': drop_invalid = true; break;
+            case 'r': max_frames = atoi(optarg); break;
+            case 'o': dump_path = optarg; break;
+            case 'p': port = atoi(optarg); break;
+            default: print_usage(); exit(2);
+        }
+    }
+}
+
+// Same socket set-up as the reference (:75-105): bind, listen, accept one client.
+static void initSocket(int p)
+{
+    struct sockaddr_in serv_addr;
+    memset(&serv_addr, 0, sizeof(serv_addr));
+    serv_addr.sin_family = AF_INET;
+    serv_addr.sin_addr.s_addr = INADDR_ANY;
+    serv_addr.sin_port = htons(p);
+    if ((sockfd = socket(AF_INET, SOCK_STREAM, IPPROTO_TCP)) < 0) { std::cerr << "\nSocket fd not received." << std::endl; exit(EXIT_FAILURE); }
+    int one = 1;
+    setsockopt(sockfd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    if (bind(sockfd, (struct sockaddr*)&serv_addr, sizeof(serv_addr)) < 0) { std::cerr << "\nBind failed" << std::endl; exit(EXIT_FAILURE); }
+    if (listen(sockfd, 3) < 0) { std::cerr << "\nListen failed" << std::endl; exit(EXIT_FAILURE); }
+    std::cout << "Waiting for client..." << std::endl;
+    if ((client_sock = accept(sockfd, NULL, NULL)) < 0) { std::cerr << "\nConnection failed" << std::endl; exit(EXIT_FAILURE); }
+    std::cout << "Established connection with client_sock: " << client_sock << std::endl;
+}
+
+static void sigintHandler(int) { std::cout << "\n Exiting \n " << std::endl; exit(0); }
+
+struct FrameSource {
+    std::vector<pcs_stream_config> cfg;
+    std::vector<std::vector<uint16_t>> depth;     // per stream, current frame
+    std::vector<std::vector<uint8_t>> color;
+    FILE* fp = nullptr;
+    int frames_in_file = 0, W = 0, H = 0;
+    bool synth = false;
+
+    bool open(const char* spec)
+    {
+        if (strncmp(spec, "synth:", 6) == 0) {
+            if (sscanf(spec + 6, "%dx%d", &W, &H) != 2 || W <= 0 || H <= 0) return false;
+            synth = true;
+            for (int s = 0; s < n_streams; s++) cfg.push_back(pcs_synth::stream_config(W, H, s, n_streams == 1));
+        } else {
+            fp = fopen(spec, "rb");
+            if (!fp) return false;
+            char magic[8]; int32_t ns = 0, nf = 0;
+            if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "PCSRAW1", 8) != 0) return false;
+            if (fread(&ns, 4, 1, fp) != 1 || fread(&nf, 4, 1, fp) != 1 || ns < 1 || ns > PCS_MAX_STREAMS) return false;
+            n_streams = ns; frames_in_file = nf;
+            cfg.resize(ns);
+            if (fread(cfg.data(), sizeof(pcs_stream_config), ns, fp) != (size_t)ns) return false;
+            W = cfg[0].depth.width; H = cfg[0].depth.height;
+        }
+        depth.resize(n_streams); color.resize(n_streams);
+        return true;
+    }
+    bool next(int frame)
+    {
+        if (synth) {
+            for (int s = 0; s < n_streams; s++) {
+                pcs_synth::depth(W, H, s, pcs_synth::kSeed + 7919u * (uint32_t)frame, depth[s]);
+                pcs_synth::color(W, H, s, pcs_synth::kSeed + 7919u * (uint32_t)frame, color[s]);
+            }
+            return true;
+        }
+        if (frame >= frames_in_file) return false;          // the reference stops when the bag loops (:276)
+        for (int s = 0; s < n_streams; s++) {
+            depth[s].resize((size_t)cfg[s].depth.width * cfg[s].depth.height);
+            color[s].resize((size_t)cfg[s].color_stride * cfg[s].color.height);
+            if (fread(depth[s].data(), 2, depth[s].size(), fp) != depth[s].size()) return false;
+            if (fread(color[s].data(), 1, color[s].size(), fp) != color[s].size()) return false;
+        }
+        return true;
+    }
+};
+
+int main(int argc, char** argv)
+{
+    parseArgs(argc, argv);
+    signal(SIGINT, sigintHandler);
+    if (filename == NULL) {
+        std::cerr << "Live capture needs librealsense2 and a RealSense camera, which this build does not link.\n"
+                     "Use -f synth:<W>x<H> or -f <frames.pcsraw>." << std::endl;
+        return 2;
+    }
+    std::cout << "Reading Frames from File: " << filename << std::endl;
+    FrameSource src;
+    if (!src.open(filename)) { std::cerr << "cannot open frame source " << filename << std::endl; return 2; }
+    std::cout << "Camera Info: synthetic D400-like stream x" << n_streams << " FW ver:n/a" << std::endl;
+    if (num_of_threads) std::cout << "OpenMP Threads: " << num_of_threads << std::endl;
+    if (!use_hip)
+        std::cout << "note: without -m the reference runs its scalar loop; this build has no CPU path and uses the HIP path "
+                     "(the scalar variant differs from -m by +-1 LSB and is not reproduced)" << std::endl;
+
+    pcs_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = device; cfg.n_streams = n_streams; cfg.streams = src.cfg.data(); cfg.downsample = downsample;
+    cfg.flags = (cutoff ? PCS_FLAG_CUTOFF : 0u) | (cutoff_compat ? PCS_FLAG_CUTOFF_COMPAT : 0u) | (drop_invalid ? PCS_FLAG_DROP_INVALID : 0u);
+    pcs_ctx* ctx = nullptr;
+    int rc = pcs_create(&ctx, &cfg);
+    if (rc != PCS_OK) { std::cerr << "pcs_create: " << pcs_strerror(rc) << ": " << pcs_last_error(nullptr) << std::endl; return 1; }
+
+    const size_t buf_shorts = PCS_HEADER_SHORTS + pcs_max_payload_shorts(ctx);
+    short* buffer = (short*)malloc(sizeof(short) * buf_shorts);            // the reference mallocs BUF_SIZE shorts (:157)
+    std::vector<const uint16_t*> dptr(n_streams);
+    std::vector<const uint8_t*> cptr(n_streams);
+    std::vector<int> counts(n_streams);
+    pcs_kernel_timing(ctx, 1);
+
+    int i = 0, buff_size = 0;
+    double duration_sum = 0, buff_size_sum = 0;
+    size_t points_in = 0;
+    if (send_buffer) initSocket(port);
+
+    while (i < max_frames && src.next(i)) {
+        i++;
+        for (int s = 0; s < n_streams; s++) { dptr[s] = src.depth[s].data(); cptr[s] = src.color[s].data(); }
+        auto time_start = clockTime::now();                                   // :291
+        rc = pcs_process_frames(ctx, dptr.data(), cptr.data(), buffer, buf_shorts, send_buffer ? 1 : 0, counts.data(), &buff_size);
+        auto time_end = clockTime::now();                                     // :293
+        if (rc != PCS_OK) { std::cerr << "pcs_process_frames: " << pcs_last_error(ctx) << std::endl; return 1; }
+        if (send_buffer) send(client_sock, (char*)buffer, buff_size + sizeof(int), 0);     // :719
+        const double ms = timeMilli(time_end - time_start).count();
+        std::cout << "Frame Time: " << ms << " ms " << "FPS: " << 1000.0 / ms
+                  << "\t Buffer size: " << float(buff_size) / (1 << 20) << " MBytes" << std::endl;       // :295-297
+        duration_sum += ms;
+        buff_size_sum += buff_size;
+        for (int s = 0; s < n_streams; s++) points_in += (size_t)pcs_stream_points(ctx, s);
+    }
+    if (send_buffer) { close(client_sock); close(sockfd); }
+    if (i == 0) { std::cerr << "no frames" << std::endl; return 1; }
+
+    std::vector<float> kms(i);
+    int nk = 0;
+    pcs_kernel_times_ms(ctx, kms.data(), i, &nk);
+    double ksum = 0; for (int k = 0; k < nk && k < i; k++) ksum += kms[k];
+    const double kavg = nk ? ksum / (nk < i ? nk : i) : 0.0;
+    const size_t pts = points_in / i;
+
+    // summary block — same lines as :317-342
+    std::cout << "\n### Video Frames H x W : " << src.cfg[0].color.height << " x " << src.cfg[0].color.width << std::endl;
+    std::cout << "### Depth Frames H x W : " << src.cfg[0].depth.height << " x " << src.cfg[0].depth.width << std::endl;
+    std::cout << "### # Points : " << pts << std::endl;
+    std::cout << "\n### Total Frames = " << i << std::endl;
+    std::cout << "### AVG Frame Time: " << duration_sum / i << " ms" << std::endl;
+    std::cout << "### AVG FPS: " << 1000.0 / (duration_sum / i) << std::endl;
+    if (num_of_threads) std::cout << "### OpenMP Threads : " << num_of_threads << std::endl;
+    else std::cout << "### Running Serialized" << std::endl;
+    if (compress) {
+        std::cout << "\n### Sending Compressed Stream" << std::endl;
+        std::cout << "### AVG Bytes/Frame: " << float(buff_size_sum) / (i * 1000000.0) << " MBytes" << std::endl;
+        std::cout << "### AVG Compression Ratio " << float(buff_size_sum) / ((pts / 100.0) * 5 * sizeof(short) * i) << " %" << std::endl;
+    } else {
+        std::cout << "\n### AVG Bytes/Frame: " << float(buff_size_sum) / (i * 1000000.0) << " MBytes" << std::endl;
+        std::cout << "### AVG Filter Compress Ratio " << float(buff_size_sum) / ((pts / 100.0) * 5 * sizeof(short) * i) << " %" << std::endl;
+    }
+    // additions
+    std::cout << "\n### HIP streams : " << n_streams << " on GPU " << device << " (arithmetic policy " << pcs_stream_math(ctx, 0) << ")" << std::endl;
+    std::cout << "### AVG Kernel Time: " << kavg << " ms  (hipEvent, deproject+transform+pack only)" << std::endl;
+    if (kavg > 0) {
+        std::cout << "### Kernel Mpoints/s: " << pts / kavg / 1e3 << std::endl;
+        std::cout << "### Kernel HBM GB/s (15 B/point algorithmic): " << pts * 15.0 / kavg / 1e6
+                  << "  = " << pts * 15.0 / kavg / 1e6 / 80.0 << " % of 8 TB/s" << std::endl;
+    }
+    std::cout << "### Host-API Mpoints/s (PCIe both ways included): " << pts / (duration_sum / i) / 1e3 << std::endl;
+
+    if (dump_path) {
+        FILE* f = fopen(dump_path, "wb");
+        if (f) { fwrite(buffer, 1, (size_t)buff_size + 4, f); fclose(f); }
+    }
+    free(buffer);
+    pcs_destroy(ctx);
+    return 0;
+}

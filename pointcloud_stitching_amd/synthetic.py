@@ -89,3 +89,20 @@ def synth_frame_set(n_streams: int, width: int, height: int, seed: int = SEED, s
     depth = [synth_depth(width, height, s, seed, mode) for s in range(n_streams)]
     color = [synth_color(cfgs[s].color.width, cfgs[s].color.height, s, seed) for s in range(n_streams)]
     return cfgs, depth, color
+
+
+def write_pcsraw(path: str, configs, frames) -> None:
+    """Raw frame dump read by the C++ CLI (-f file.pcsraw): magic "PCSRAW1\\0", int32 n_streams,
+    int32 n_frames, n_streams x pcs_stream_config, then per frame per stream: Z16 raster, colour raster.
+    `frames` is a list of (depth_list, color_list)."""
+    import ctypes as C
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"PCSRAW1\0")
+        f.write(struct.pack("<ii", len(configs), len(frames)))
+        for c in configs:
+            f.write(bytes(memoryview(C.string_at(C.addressof(c), C.sizeof(c)))))
+        for depth, color in frames:
+            for s in range(len(configs)):
+                f.write(np.ascontiguousarray(depth[s], np.uint16).tobytes())
+                f.write(np.ascontiguousarray(color[s], np.uint8).tobytes())
