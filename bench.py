@@ -156,17 +156,27 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
-    # ring of frame-sets resident in HBM
-    d_depth, d_color, host0 = [], [], None
+    # Ring of frame-sets resident in HBM, carved from ONE slab at 256-byte granularity: power-of-two aligned
+    # per-raster allocations alias the streams onto the same HBM channels (22.7 vs 19.0 us).
+    def up(nbytes):
+        return (nbytes + 16 + 255) & ~255
+    payload_shorts = set_points * POINT_SHORTS
+    depth_b, color_b, out_b = up(npts * 2), up(cfgs[0].color_bytes), up(payload_shorts * 2)
+    slab = torch.empty(R * (S * (depth_b + color_b) + out_b) + 256, dtype=torch.uint8, device=dev)
+    base = slab.data_ptr()
+    off = (-base) % 256
+    d_depth, d_color, d_out, host0 = [], [], [], None
     for slot in range(R):
         dep = [Syn.synth_depth(W, H, rank * S + s, seed=Syn.SEED + 7919 * slot) for s in range(S)]
         col = [Syn.synth_color(W, H, rank * S + s, seed=Syn.SEED + 7919 * slot) for s in range(S)]
         if slot == 0:
             host0 = (dep, col)
-        d_depth.append([torch.from_numpy(d.view(np.int16).reshape(-1)).to(dev) for d in dep])
-        d_color.append([torch.from_numpy(c).to(dev) for c in col])
-    payload_shorts = set_points * POINT_SHORTS
-    d_out = [torch.empty(payload_shorts, dtype=torch.int16, device=dev) for _ in range(R)]
+        dd, dc = [], []
+        for s in range(S):
+            v = slab[off:off + npts * 2]; v.copy_(torch.from_numpy(dep[s].reshape(-1).view(np.uint8))); dd.append(v); off += depth_b
+            v = slab[off:off + col[s].size]; v.copy_(torch.from_numpy(col[s])); dc.append(v); off += color_b
+        d_depth.append(dd); d_color.append(dc)
+        d_out.append(slab[off:off + payload_shorts * 2].view(torch.int16)); off += out_b
     ring_bytes = R * (set_points * ALGO_BYTES_PER_POINT)
 
     gather = world > 1 and not args.no_gather

@@ -46,9 +46,13 @@ struct pcs_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
 
     // lazily sized staging for the host-pointer entry points
+    // Rasters of all streams are carved from ONE slab at 256-byte granularity. Separate hipMalloc()s hand
+    // out 2 MiB-aligned bases; the streams' tiles advance in lockstep, so equal offsets from power-of-two
+    // aligned bases land on the same HBM channels: measured 22.7 us vs 19.0 us per 8x720p launch
+    // (tools/kernel_lab.hip, "allocation mode").
+    uint8_t*                        s_slab = nullptr;
     std::vector<uint16_t*>          s_depth;
     std::vector<uint8_t*>           s_color;
-    std::vector<size_t>             s_depth_cap, s_color_cap;
     int16_t*                        s_payload = nullptr;  size_t s_payload_cap = 0;   // bytes
     float*                          s_vertices = nullptr; size_t s_vertices_cap = 0;
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
@@ -257,6 +261,28 @@ int ensure(pcs_ctx* c, T*& p, size_t& cap, size_t bytes)
     return PCS_OK;
 }
 
+// Lazily allocate the packed raster slab of the host-pointer entry points (sizes are fixed by the config).
+int ensure_rasters(pcs_ctx* c)
+{
+    if (c->s_slab) return PCS_OK;
+    const auto up = [](size_t b) { return (b + 16 + 255) & ~(size_t)255; };
+    size_t total = 0;
+    for (int s = 0; s < c->n_streams; s++)
+        total += up((size_t)c->h_params[s].n_points * sizeof(uint16_t)) + up(c->h_params[s].color_bytes);
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, total + 256);
+    if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    c->s_slab = static_cast<uint8_t*>(q);
+    size_t off = 0;
+    for (int s = 0; s < c->n_streams; s++) {
+        c->s_depth[s] = reinterpret_cast<uint16_t*>(c->s_slab + off);
+        off += up((size_t)c->h_params[s].n_points * sizeof(uint16_t));
+        c->s_color[s] = c->s_slab + off;
+        off += up(c->h_params[s].color_bytes);
+    }
+    return PCS_OK;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
@@ -414,7 +440,6 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     c->h_params.resize(c->n_streams);
     c->d_lut.assign(2 * (size_t)c->n_streams, nullptr);
     c->s_depth.assign(c->n_streams, nullptr); c->s_color.assign(c->n_streams, nullptr);
-    c->s_depth_cap.assign(c->n_streams, 0);   c->s_color_cap.assign(c->n_streams, 0);
 
 #define CREATE_CHK(expr)                                                                             \
     do {                                                                                             \
@@ -512,8 +537,7 @@ void pcs_destroy(pcs_ctx* c)
     DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
-    for (auto* p : c->s_depth) if (p) (void)hipFree(p);
-    for (auto* p : c->s_color) if (p) (void)hipFree(p);
+    if (c->s_slab) (void)hipFree(c->s_slab);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
@@ -615,7 +639,7 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* c, int stream, const float* ve
     int rc;
     if ((rc = ensure(c, c->s_vertices, c->s_vertices_cap, vb))) return rc;
     if ((rc = ensure(c, c->s_texcoords, c->s_texcoords_cap, tb))) return rc;
-    if ((rc = ensure(c, c->s_color[stream], c->s_color_cap[stream], P.color_bytes))) return rc;
+    if ((rc = ensure_rasters(c))) return rc;
     if ((rc = ensure(c, c->s_payload, c->s_payload_cap, ob + 16))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->s_vertices, vertices, vb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->s_texcoords, texcoords, tb, hipMemcpyHostToDevice, c->stream));
@@ -684,12 +708,11 @@ int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* 
     if (!depth || !color || !stitched) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
     DeviceGuard guard(c->device);
     int rc;
+    if ((rc = ensure_rasters(c))) return rc;
     for (int s = 0; s < c->n_streams; s++) {
         if (!depth[s] || !color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
         const StreamParams& P = c->h_params[s];
         const size_t db = (size_t)P.n_points * sizeof(uint16_t);
-        if ((rc = ensure(c, c->s_depth[s], c->s_depth_cap[s], db + 16))) return rc;
-        if ((rc = ensure(c, c->s_color[s], c->s_color_cap[s], P.color_bytes))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->s_depth[s], depth[s], db, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->s_color[s], color[s], P.color_bytes, hipMemcpyHostToDevice, c->stream));
     }
@@ -723,7 +746,7 @@ int pcs_deproject(pcs_ctx* c, int stream, const uint16_t* depth, float* vertices
     const StreamParams& P = c->h_params[stream];
     const size_t n = P.n_points;
     int rc;
-    if ((rc = ensure(c, c->s_depth[stream], c->s_depth_cap[stream], n * sizeof(uint16_t) + 16))) return rc;
+    if ((rc = ensure_rasters(c))) return rc;
     if ((rc = ensure(c, c->s_vertices, c->s_vertices_cap, n * 3 * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->s_texcoords, c->s_texcoords_cap, n * 2 * sizeof(float)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->s_depth[stream], depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));

@@ -53,6 +53,20 @@ void lab_fused_dense(const StreamParams* __restrict__ params, FramePtrs fp, uint
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
+template <class Mth, int WAVES>
+__global__ __launch_bounds__(kBlockThreads, WAVES)
+void lab_fused_dense_lb(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ uint4 stage[kDenseStageBytes / 16];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    DepthSource<false, false, Mth> src{fp.depth[s]};
+    dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
+}
+
 // Memory skeleton: the same loads (uint4 depth, 8 colour dwords at the identity mapping) and the same
 // LDS-transposed 16-byte stores, almost no arithmetic. What the access pattern alone can reach.
 __global__ __launch_bounds__(kBlockThreads)
@@ -247,6 +261,11 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dp, hp.data(), sizeof(StreamParams) * S, hipMemcpyHostToDevice));
 
     // ring of frame-sets
+    const bool packed = argc > 2 && atoi(argv[2]) != 0;
+    const size_t skew = argc > 3 ? (size_t)atol(argv[3]) : 0;     // extra bytes between consecutive rasters
+    uint8_t* slab = nullptr; size_t slab_off = 0;
+    if (packed) CK(hipMalloc(&slab, (size_t)R * S * (5 * (size_t)N + 1024 + 2 * skew) + (size_t)R * S * N * 10 + 4096 + R * (skew + 256)));
+    printf("allocation mode: %s, skew %zu\n", packed ? "one packed slab" : "one hipMalloc per raster", skew);
     std::vector<FramePtrs> ring(R);
     std::vector<uint8_t*> outs(R);
     std::vector<uint16_t> hd(N); std::vector<uint8_t> hc(3 * (size_t)N + 16);
@@ -262,12 +281,16 @@ int main(int argc, char** argv)
             }
             for (size_t i = 0; i < 3 * (size_t)N; i += 4) { const uint32_t h = hhash((uint32_t)(i / 4) * 0x9E3779B1u + r + s * 7u); memcpy(&hc[i], &h, 4); }
             uint16_t* dd; uint8_t* dc;
-            CK(hipMalloc(&dd, sizeof(uint16_t) * N)); CK(hipMalloc(&dc, 3 * (size_t)N + 16));
+            if (packed) {   // carve from one slab, 256-byte granularity (what a pooling allocator does)
+                dd = (uint16_t*)(slab + slab_off); slab_off += ((sizeof(uint16_t) * N + 255) & ~(size_t)255) + skew;
+                dc = slab + slab_off;               slab_off += ((3 * (size_t)N + 16 + 255) & ~(size_t)255) + skew;
+            } else { CK(hipMalloc(&dd, sizeof(uint16_t) * N)); CK(hipMalloc(&dc, 3 * (size_t)N + 16)); }
             CK(hipMemcpy(dd, hd.data(), sizeof(uint16_t) * N, hipMemcpyHostToDevice));
             CK(hipMemcpy(dc, hc.data(), 3 * (size_t)N, hipMemcpyHostToDevice));
             ring[r].depth[s] = dd; ring[r].color[s] = dc;
         }
-        CK(hipMalloc(&outs[r], (size_t)S * N * 10));
+        if (packed) { outs[r] = slab + slab_off; slab_off += (((size_t)S * N * 10 + 255) & ~(size_t)255) + skew; }
+        else CK(hipMalloc(&outs[r], (size_t)S * N * 10));
     }
     uint8_t* ref_out; CK(hipMalloc(&ref_out, (size_t)S * N * 10));
     const dim3 grid((N + 2047) / 2048, S), block(256);
@@ -310,6 +333,10 @@ int main(int argc, char** argv)
         time_it("cert, exact cvt", LAUNCH((lab::lab_fused_dense<lab::CertNoLazy>)));
         time_it("cert (product)", LAUNCH((lab::lab_fused_dense<CertMath<false>>)));
         time_it("cert + identity R (product)", LAUNCH((lab::lab_fused_dense<CertMath<true>>)));
+        time_it("cert+identR, lb(256,8)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 8>)));
+        time_it("cert+identR, lb(256,7)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 7>)));
+        time_it("cert+identR, lb(256,5)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 5>)));
+        time_it("cert+identR, lb(256,4)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 4>)));
         time_it("sloppy (inexact bound)", LAUNCH((lab::lab_fused_dense<lab::SloppyMath>)));
         time_it("memory skeleton", LAUNCH(lab::lab_memory_skeleton));
     }
