@@ -5,6 +5,7 @@
 //   reference flags (getopt "hf:vst:cmz", :122):  -h  -f <file>  -v  -s  -t <n>  -c  -m  -z
 //   additions:  -g <dev>  -n <streams>  -d <stride>  -i (drop invalid depth)  -C (reference -c lane quirk)
 //               -r <frames>  -o <file> (dump last stitched buffer)  -p <port>
+//               -e <file> (camera-to-world matrices instead of the ones pasted into the reference's sources)
 //
 //   -f takes "synth:<W>x<H>" (deterministic synthetic frames; the reference's bags are LFS stubs and
 //   need librealsense) or a .pcsraw dump (see pointcloud_stitching_amd/synthetic.py: write_pcsraw).
@@ -25,15 +26,17 @@
 #include <unistd.h>
 
 #include "pcs_synth.h"
+#include "pcs_wire.h"
 
 typedef std::chrono::high_resolution_clock clockTime;
 typedef std::chrono::duration<double, std::milli> timeMilli;
 
 static const char* filename = nullptr;
 static bool display_updates = false, send_buffer = false, cutoff = false, use_hip = false, compress = false;
-static bool cutoff_compat = false, drop_invalid = false;
+static bool cutoff_compat = false, drop_invalid = false, pull_mode = false;
 static int num_of_threads = 1, device = 0, n_streams = 1, downsample = 1, max_frames = 60, port = 8000;
 static const char* dump_path = nullptr;
+static const char* extrinsics_path = nullptr;
 static int client_sock = 0, sockfd = 0;
 
 static void print_usage()
@@ -45,13 +48,15 @@ static void print_usage()
            "  -t <n>    OpenMP threads of the reference path; accepted, inert on the HIP path\n"
            "  -c        cutoff 0<z<=1.5, -2<x<=2 with compaction   -C  same with the reference's lane quirk\n"
            "  -i        drop invalid-depth pixels   -d <n> keep every n-th point   -n <N> camera streams\n"
-           "  -g <dev>  GPU ordinal   -r <frames>   -o <file> dump last stitched buffer   -p <port>\n\n");
+           "  -g <dev>  GPU ordinal   -r <frames>   -o <file> dump last stitched buffer   -p <port>\n"
+           "  -P        serve frames on 'Z' pull requests (the live server's protocol) instead of pushing them\n"
+           "  -e <file> camera-to-world matrices, 16 row-major floats per line (python -m pointcloud_stitching_amd.calibration)\n\n");
 }
 
 static void parseArgs(int argc, char** argv)
 {
     int c;
-    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:")) != -1) {
+    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:e:P")) != -1) {
         switch (c) {
             case 'h': print_usage(); exit(0);
             case 'f': filename = optarg; break;
@@ -69,6 +74,8 @@ static void parseArgs(int argc, char** argv)
             case 'r': max_frames = atoi(optarg); break;
             case 'o': dump_path = optarg; break;
             case 'p': port = atoi(optarg); break;
+            case 'e': extrinsics_path = optarg; break;
+            case 'P': pull_mode = true; send_buffer = true; break;
             default: print_usage(); exit(2);
         }
     }
@@ -160,6 +167,25 @@ int main(int argc, char** argv)
         std::cout << "note: without -m the reference runs its scalar loop; this build has no CPU path and uses the HIP path "
                      "(the scalar variant differs from -m by +-1 LSB and is not reproduced)" << std::endl;
 
+    if (extrinsics_path) {      // replaces editing tf_mat / transform[i] in source (:64-67)
+        FILE* f = fopen(extrinsics_path, "r");
+        if (!f) { std::cerr << "cannot open extrinsics file " << extrinsics_path << std::endl; return 2; }
+        char line[1024];
+        int cam = 0;
+        while (cam < n_streams && fgets(line, sizeof line, f)) {
+            char* hash = strchr(line, '#');
+            if (hash) *hash = 0;
+            float m[16];
+            int got = 0, pos = 0, adv = 0;
+            while (got < 16 && sscanf(line + pos, " %f%n", &m[got], &adv) == 1) { got++; pos += adv; if (line[pos] == ',') pos++; }
+            if (got == 0) continue;
+            if (got != 16) { std::cerr << extrinsics_path << ": expected 16 values per line" << std::endl; return 2; }
+            memcpy(src.cfg[cam++].cam_to_world, m, sizeof m);
+        }
+        fclose(f);
+        if (cam < n_streams) { std::cerr << extrinsics_path << ": only " << cam << " matrices for " << n_streams << " streams" << std::endl; return 2; }
+    }
+
     pcs_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.device = device; cfg.n_streams = n_streams; cfg.streams = src.cfg.data(); cfg.downsample = downsample;
@@ -187,7 +213,12 @@ int main(int argc, char** argv)
         rc = pcs_process_frames(ctx, dptr.data(), cptr.data(), buffer, buf_shorts, send_buffer ? 1 : 0, counts.data(), &buff_size);
         auto time_end = clockTime::now();                                     // :293
         if (rc != PCS_OK) { std::cerr << "pcs_process_frames: " << pcs_last_error(ctx) << std::endl; return 1; }
-        if (send_buffer) send(client_sock, (char*)buffer, buff_size + sizeof(int), 0);     // :719
+        if (pull_mode) {      // the live server's protocol (:180-184): one 'Z' per frame, anything else is fatal
+            int req = pcs_wire::recv_pull(client_sock);
+            if (req < 0) { std::cout << "Client disconnected" << std::endl; break; }
+            if (req != pcs_wire::kPullXYZRGB) { std::cerr << "Faulty pull request" << std::endl; return 1; }
+        }
+        if (send_buffer && !pcs_wire::send_frame(client_sock, buffer, buff_size)) { std::cout << "Client disconnected" << std::endl; break; }   // :719
         const double ms = timeMilli(time_end - time_start).count();
         std::cout << "Frame Time: " << ms << " ms " << "FPS: " << 1000.0 / ms
                   << "\t Buffer size: " << float(buff_size) / (1 << 20) << " MBytes" << std::endl;       // :295-297

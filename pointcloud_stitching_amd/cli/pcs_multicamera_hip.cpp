@@ -1,0 +1,224 @@
+// pcs-multicamera-hip — the central stitcher (src/pcs-multicamera-client.cpp, non-visual path) on MI355X.
+//
+// Two ways to feed it:
+//   -f synth:<W>x<H> | frames.pcsraw   all cameras' rasters are on this node: ONE fused launch produces the
+//                                       stitched buffer (edge + central collapsed)
+//   -c host:port[,host:port...]         existing edge servers (the reference's, or pcs-camera-optimized -s):
+//                                       one reader thread per camera like readCloud (:363-371); payloads are
+//                                       concatenated on the GPU with the stride -d (sendStitchToUnity :373-395)
+// The stitched cloud is served exactly like the reference: wait for 'Z' on port 9000, write
+// [int32 bytes][points] (:397-403). -t prints the running average like runStitching (:417-430).
+//
+//   reference flags (getopt "hftsvd:n", src/pcs-multicamera-optimized.cpp:90): -h -f -t -s -v -d <n> -n
+//     -f here takes a frame source (the reference's "fast" switch only thinned its PCL viewer); -s (save PLY),
+//     -v (PCL visualiser) and -n belong to the PCL viewer, which this build does not have: refused with a reason.
+//   additions: -c <list>  -N <streams>  -g <gpu>  -p <serve port>  -r <frame-sets>  -o <file>  -q (no server)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <getopt.h>
+#include <signal.h>
+
+#include "pcs_synth.h"
+#include "pcs_wire.h"
+
+typedef std::chrono::high_resolution_clock clockTime;
+typedef std::chrono::duration<double, std::milli> timeMilli;
+
+static bool timer = false, serve = true;
+static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30;
+static const char* source = nullptr;
+static const char* cameras = nullptr;
+static const char* dump_path = nullptr;
+
+static void usage()
+{
+    std::cout << "\nMulticamera pointcloud stitching (MI355X)\nUsage: pcs-multicamera-hip [options]\n\nOptions:\n"
+              << " -h (help)        Display command line options\n"
+              << " -t (timer)       Displays the runtime of certain functions\n"
+              << " -d (downsample)  Downsamples the stitched pointcloud by the specified integer\n"
+              << " -f <src>         cameras on this node: synth:<W>x<H> or frames.pcsraw\n"
+              << " -c <list>        edge servers host:port,... (pull 'Z' protocol)\n"
+              << " -N <n> streams   -g <gpu>   -p <port> (default 9000)   -r <frame-sets>   -o <file>   -q no server\n"
+              << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
+}
+
+int main(int argc, char** argv)
+{
+    signal(SIGPIPE, SIG_IGN);
+    int c;
+    while ((c = getopt(argc, argv, "hf:tsvd:nc:N:g:p:r:o:q")) != -1) {
+        switch (c) {
+            case 't': timer = true; break;
+            case 'd': downsample = atoi(optarg); break;
+            case 'f': source = optarg; break;
+            case 'c': cameras = optarg; break;
+            case 'N': n_streams = atoi(optarg); break;
+            case 'g': device = atoi(optarg); break;
+            case 'p': serve_port = atoi(optarg); break;
+            case 'r': max_sets = atoi(optarg); break;
+            case 'o': dump_path = optarg; break;
+            case 'q': serve = false; break;
+            case 's': case 'v': case 'n':
+                std::cerr << "-" << (char)c << " drives the reference's PCL viewer / PLY writer, which this build does not include" << std::endl;
+                return 2;
+            default: usage(); return c == 'h' ? 0 : 2;
+        }
+    }
+    if (downsample < 1) { std::cerr << "downsample must be >= 1" << std::endl; return 2; }
+    if ((source == nullptr) == (cameras == nullptr)) { std::cerr << "give exactly one of -f <src> or -c <edge list>" << std::endl; usage(); return 2; }
+
+    // ---- frame source / edge connections -------------------------------------------------------
+    std::vector<pcs_stream_config> cfgs;
+    std::vector<int> cam_fd;
+    int W = 0, H = 0;
+    FILE* raw = nullptr; int raw_frames = 0;
+    if (source) {
+        if (strncmp(source, "synth:", 6) == 0) {
+            if (sscanf(source + 6, "%dx%d", &W, &H) != 2) { std::cerr << "bad synth spec" << std::endl; return 2; }
+            for (int s = 0; s < n_streams; s++) cfgs.push_back(pcs_synth::stream_config(W, H, s, false));
+        } else {
+            raw = fopen(source, "rb");
+            char magic[8]; int32_t ns = 0;
+            if (!raw || fread(magic, 1, 8, raw) != 8 || memcmp(magic, "PCSRAW1", 8) != 0 || fread(&ns, 4, 1, raw) != 1 ||
+                fread(&raw_frames, 4, 1, raw) != 1 || ns < 1 || ns > PCS_MAX_STREAMS) { std::cerr << "cannot read " << source << std::endl; return 2; }
+            n_streams = ns; cfgs.resize(ns);
+            if (fread(cfgs.data(), sizeof(pcs_stream_config), ns, raw) != (size_t)ns) return 2;
+        }
+    } else {
+        std::string list = cameras;
+        size_t pos = 0;
+        while (pos < list.size()) {
+            size_t comma = list.find(',', pos);
+            std::string item = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+            pos = comma == std::string::npos ? list.size() : comma + 1;
+            size_t colon = item.rfind(':');
+            if (colon == std::string::npos) { std::cerr << "edge entry needs host:port: " << item << std::endl; return 2; }
+            int fd = pcs_wire::connect_to(item.substr(0, colon).c_str(), atoi(item.c_str() + colon + 1));
+            if (fd < 0) { std::cerr << "Connection failed at " << item << std::endl; return 1; }       // :201-204
+            cam_fd.push_back(fd);
+        }
+        n_streams = (int)cam_fd.size();
+        // the stitch-only context needs a config; geometry is irrelevant for pcs_stitch_device
+        cfgs.push_back(pcs_synth::stream_config(64, 48, 0, false));
+    }
+
+    pcs_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = device; cfg.n_streams = (int)cfgs.size(); cfg.streams = cfgs.data();
+    cfg.downsample = source ? downsample : 1;
+    pcs_ctx* ctx = nullptr;
+    int rc = pcs_create(&ctx, &cfg);
+    if (rc != PCS_OK) { std::cerr << "pcs_create: " << pcs_strerror(rc) << ": " << pcs_last_error(nullptr) << std::endl; return 1; }
+
+    // ---- buffers -------------------------------------------------------------------------------
+    const size_t cam_cap_bytes = (size_t)10 * 4u * 1000 * 1000;           // per-camera receive buffer (reference: 10 MB, :554)
+    size_t stitched_shorts = source ? PCS_HEADER_SHORTS + pcs_max_payload_shorts(ctx)
+                                    : PCS_HEADER_SHORTS + (size_t)n_streams * cam_cap_bytes / 2;
+    std::vector<int16_t> stitched(stitched_shorts);
+    std::vector<std::vector<uint16_t>> depth(source ? n_streams : 0);
+    std::vector<std::vector<uint8_t>> color(source ? n_streams : 0);
+    std::vector<std::vector<uint8_t>> cam_buf(source ? 0 : n_streams, std::vector<uint8_t>(source ? 0 : cam_cap_bytes));
+    std::vector<void*> d_cam(source ? 0 : n_streams, nullptr);
+    void* d_stitched = nullptr;
+    if (!source) {
+        for (int i = 0; i < n_streams; i++) if (pcs_device_malloc(ctx, &d_cam[i], cam_cap_bytes) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+        if (pcs_device_malloc(ctx, &d_stitched, (size_t)n_streams * cam_cap_bytes + 64) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+    }
+
+    int listen_fd = -1, client_fd = -1;
+    if (serve) {
+        listen_fd = pcs_wire::listen_on(serve_port);
+        if (listen_fd < 0) { std::cerr << "Couldn't bind server sockfd" << std::endl; return 1; }            // :226-229
+        std::cout << "Waiting for client..." << std::endl;
+        client_fd = ::accept(listen_fd, NULL, NULL);
+        if (client_fd < 0) { std::cerr << "Connection failed" << std::endl; return 1; }
+        std::cout << "Established connection with client_sock: " << client_fd << std::endl;
+    }
+
+    // the reference primes each camera with one pull before its loop (:557 sendPullRequest)
+    for (int fd : cam_fd) pcs_wire::send_pull(fd);
+
+    double total = 0;
+    int loop_count = 1, size_bytes = 0;
+    for (int set = 0; set < max_sets; set++) {
+        auto stitch_start = clockTime::now();
+        if (source) {
+            if (raw) {
+                if (set >= raw_frames) break;
+                for (int s = 0; s < n_streams; s++) {
+                    depth[s].resize((size_t)cfgs[s].depth.width * cfgs[s].depth.height);
+                    color[s].resize((size_t)cfgs[s].color_stride * cfgs[s].color.height);
+                    if (fread(depth[s].data(), 2, depth[s].size(), raw) != depth[s].size() ||
+                        fread(color[s].data(), 1, color[s].size(), raw) != color[s].size()) { std::cerr << "short read" << std::endl; return 1; }
+                }
+            } else {
+                for (int s = 0; s < n_streams; s++) {
+                    pcs_synth::depth(W, H, s, pcs_synth::kSeed + 7919u * (uint32_t)set, depth[s]);
+                    pcs_synth::color(W, H, s, pcs_synth::kSeed + 7919u * (uint32_t)set, color[s]);
+                }
+                stitch_start = clockTime::now();                   // generation is not part of the stitch
+            }
+            std::vector<const uint16_t*> dp(n_streams); std::vector<const uint8_t*> cp(n_streams);
+            for (int s = 0; s < n_streams; s++) { dp[s] = depth[s].data(); cp[s] = color[s].data(); }
+            rc = pcs_process_frames(ctx, dp.data(), cp.data(), stitched.data(), stitched.size(), 1, nullptr, &size_bytes);
+            if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+        } else {
+            // one reader thread per camera, joined in camera order (:381-386)
+            std::vector<int32_t> got(n_streams, -1);
+            std::vector<std::thread> th;
+            for (int i = 0; i < n_streams; i++)
+                th.emplace_back([&, i]() {
+                    got[i] = pcs_wire::recv_frame(cam_fd[i], cam_buf[i].data(), cam_buf[i].size());
+                    if (got[i] >= 0) pcs_wire::send_pull(cam_fd[i]);                    // :370 next pull right away
+                });
+            for (auto& t : th) t.join();
+            std::vector<int> pts(n_streams);
+            std::vector<const int16_t*> dptr(n_streams);
+            bool ok = true;
+            for (int i = 0; i < n_streams; i++) {
+                if (got[i] < 0) { ok = false; break; }
+                pts[i] = got[i] / PCS_POINT_BYTES;
+                if (got[i] && pcs_memcpy_h2d(ctx, d_cam[i], cam_buf[i].data(), (size_t)got[i]) != PCS_OK) ok = false;
+                dptr[i] = static_cast<const int16_t*>(d_cam[i]);
+            }
+            if (!ok) { std::cout << "camera stream ended" << std::endl; break; }
+            int total_pts = 0;
+            rc = pcs_stitch_device(ctx, dptr.data(), pts.data(), n_streams, downsample, static_cast<int16_t*>(d_stitched),
+                                   (size_t)n_streams * cam_cap_bytes / 2, &total_pts);
+            if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+            size_bytes = total_pts * PCS_POINT_BYTES;
+            if (size_bytes && pcs_memcpy_d2h(ctx, stitched.data() + PCS_HEADER_SHORTS, d_stitched, (size_t)size_bytes) != PCS_OK) return 1;
+            pcs_synchronize(ctx);
+            memcpy(stitched.data(), &size_bytes, sizeof(int));                                             // :394-395
+        }
+        if (serve) {
+            int req = pcs_wire::recv_pull(client_fd);                                                      // :398
+            if (req < 0) { std::cout << "Client disconnected" << std::endl; break; }
+            if (req != pcs_wire::kPullXYZRGB) { std::cerr << "Faulty pull request" << std::endl; return 1; }   // :405-408
+            if (!pcs_wire::send_frame(client_fd, stitched.data(), size_bytes)) { std::cout << "Client disconnected" << std::endl; break; }
+        }
+        if (timer) {
+            total += timeMilli(clockTime::now() - stitch_start).count();
+            std::cout << "Stitching: " << total / loop_count << " ms, " << "Frame: " << loop_count << std::endl;   // :426-428
+            loop_count++;
+        }
+    }
+    if (dump_path) {
+        FILE* f = fopen(dump_path, "wb");
+        if (f) { fwrite(stitched.data(), 1, (size_t)size_bytes + 4, f); fclose(f); }
+    }
+    for (int fd : cam_fd) ::close(fd);
+    if (client_fd >= 0) ::close(client_fd);
+    if (listen_fd >= 0) ::close(listen_fd);
+    for (void* p : d_cam) if (p) pcs_device_free(ctx, p);
+    if (d_stitched) pcs_device_free(ctx, d_stitched);
+    pcs_destroy(ctx);
+    return 0;
+}

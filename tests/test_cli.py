@@ -81,3 +81,31 @@ def test_cli_raw_dump_single_stream_uses_tf_mat(cli, oracle, tmp_path):
     want, _ = oracle.process_frames(cfgs, depth, color)
     got = np.fromfile(out, dtype=np.uint8)[4:4 + want.nbytes].view(np.int16).reshape(-1, 5)
     assert (got == want).all()
+
+
+@pytest.mark.gpu
+def test_cli_loads_extrinsics_file(cli, oracle, tmp_path):
+    from pointcloud_stitching_amd import calibration as cal
+    from pointcloud_stitching_amd.types import TRANSFORMS
+    mats = [TRANSFORMS[5].reshape(4, 4), TRANSFORMS[2].reshape(4, 4)]
+    ext = str(tmp_path / "ext.txt")
+    cal.write_extrinsics(ext, mats)
+    out = str(tmp_path / "o.bin")
+    r = run(cli, "-f", "synth:128x96", "-m", "-n", "2", "-r", "1", "-e", ext, "-o", out)
+    assert r.returncode == 0, r.stderr
+    cfgs = [S.synth_stream_config(128, 96, s) for s in range(2)]
+    for s in range(2):
+        for k in range(16):
+            cfgs[s].cam_to_world[k] = float(np.float32(mats[s].reshape(-1)[k]))
+    depth = [S.synth_depth(128, 96, s) for s in range(2)]
+    color = [S.synth_color(128, 96, s) for s in range(2)]
+    want, _ = oracle.process_frames(cfgs, depth, color)
+    got = np.fromfile(out, dtype=np.uint8)[4:4 + want.nbytes].view(np.int16).reshape(-1, 5)
+    assert (got == want).all()
+
+
+def test_cli_rejects_short_extrinsics_file(cli, tmp_path):
+    ext = tmp_path / "e.txt"
+    ext.write_text("1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1\n")
+    r = run(cli, "-f", "synth:64x48", "-m", "-n", "2", "-e", str(ext))
+    assert r.returncode == 2 and "matrices" in r.stderr

@@ -1,0 +1,159 @@
+"""The reference's TCP framing and star topology on one box:
+   edge(s) --[int32 bytes][points]--> central --'Z' pull--> consumer (this test plays the Unity client)."""
+import os
+import socket
+import struct
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from pointcloud_stitching_amd import synthetic as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI_DIR = os.path.join(ROOT, "pointcloud_stitching_amd", "cli")
+EDGE = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-camera-optimized")
+CENTRAL = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-multicamera-hip")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-C", CLI_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def connect(port, timeout=60.0):
+    t0 = time.time()
+    while True:
+        try:
+            return socket.create_connection(("127.0.0.1", port), timeout=30)
+        except OSError:
+            if time.time() - t0 > timeout:
+                raise
+            time.sleep(0.1)
+
+
+def read_n(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise EOFError
+        buf += chunk
+    return bytes(buf)
+
+
+def read_frame(sock):
+    (size,) = struct.unpack("<i", read_n(sock, 4))
+    return np.frombuffer(read_n(sock, size), dtype=np.int16).reshape(-1, 5)
+
+
+def frame_inputs(n, w, h, frame, single):
+    cfgs = [S.synth_stream_config(w, h, s, single=single and n == 1) for s in range(n)]
+    depth = [S.synth_depth(w, h, s, seed=S.SEED + 7919 * frame) for s in range(n)]
+    color = [S.synth_color(w, h, s, seed=S.SEED + 7919 * frame) for s in range(n)]
+    return cfgs, depth, color
+
+
+def test_central_cli_surface():
+    r = subprocess.run([CENTRAL, "-h"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "-d (downsample)" in r.stdout and "-t (timer)" in r.stdout
+    r = subprocess.run([CENTRAL, "-v"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 2 and "PCL" in r.stderr
+    r = subprocess.run([CENTRAL, "-t"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pull", [False, True])
+def test_edge_server_frames(oracle, pull):
+    port = free_port()
+    args = [EDGE, "-f", "synth:128x96", "-m", "-r", "3", "-p", str(port), "-P" if pull else "-s"]
+    p = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        sock = connect(port)
+        for frame in range(3):
+            if pull:
+                sock.sendall(b"Z")
+            got = read_frame(sock)
+            cfgs, depth, color = frame_inputs(1, 128, 96, frame, single=True)
+            want, _ = oracle.process_frames(cfgs, depth, color)
+            assert got.shape == want.shape and (got == want).all()
+        sock.close()
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 0, err
+        assert "Established connection" in out
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.gpu
+def test_edge_rejects_a_faulty_pull_request():
+    port = free_port()
+    p = subprocess.Popen([EDGE, "-f", "synth:64x48", "-m", "-r", "2", "-p", str(port), "-P"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        sock = connect(port)
+        sock.sendall(b"Q")
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 1 and "Faulty pull request" in err       # src/pcs-camera-optimized.cpp:207-209
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.gpu
+def test_full_star_topology_two_edges_one_central(oracle):
+    p1, p2, p3 = free_port(), free_port(), free_port()
+    edges = [subprocess.Popen([EDGE, "-f", "synth:128x96", "-m", "-r", "4", "-p", str(p), "-P"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for p in (p1, p2)]
+    central = None
+    try:
+        time.sleep(0.5)
+        central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-d", "2", "-p", str(p3), "-r", "2", "-t"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        consumer = connect(p3)
+        for frame in range(2):
+            consumer.sendall(b"Z")
+            got = read_frame(consumer)
+            cfgs, depth, color = frame_inputs(1, 128, 96, frame, single=True)
+            cam, _ = oracle.process_frames(cfgs, depth, color)
+            want = oracle.stitch([cam, cam], 2)           # both edges run the same single-camera config
+            assert got.shape == want.shape and (got == want).all()
+        consumer.close()
+        out, err = central.communicate(timeout=60)
+        assert central.returncode == 0, err
+        assert "Stitching:" in out and "Frame: 2" in out
+        for e in edges:
+            e.communicate(timeout=60)
+            assert e.returncode == 0
+    finally:
+        for p in edges + ([central] if central else []):
+            if p.poll() is None:
+                p.kill()
+
+
+@pytest.mark.gpu
+def test_central_all_gpu_mode(oracle):
+    port = free_port()
+    p = subprocess.Popen([CENTRAL, "-f", "synth:128x96", "-N", "3", "-d", "3", "-p", str(port), "-r", "2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        sock = connect(port)
+        for frame in range(2):
+            sock.sendall(b"Z")
+            got = read_frame(sock)
+            cfgs, depth, color = frame_inputs(3, 128, 96, frame, single=False)
+            want, _ = oracle.process_frames(cfgs, depth, color, 0, 3)
+            assert got.shape == want.shape and (got == want).all()
+        sock.close()
+        _, err = p.communicate(timeout=60)
+        assert p.returncode == 0, err
+    finally:
+        if p.poll() is None:
+            p.kill()
