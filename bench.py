@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--ring", type=int, default=6, help="frame-sets resident in HBM (ring)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
+    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff"], default="dense",
+                    help="diagnostic: time the compaction path instead of the headline dense path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--preheat-ms", type=float, default=400.0,
                     help="untimed launches before the warm-up steps so clocks/power state settle (the first "
@@ -152,7 +155,9 @@ def main():
     set_points = S * npts
     # global camera index = rank*S + s  -> extrinsic transform[(rank*S+s) % 8], distinct seeds per camera
     cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
-    ctx = PcsContext(cfgs, device=local_rank)
+    from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_DROP_INVALID
+    mode_flags = {"dense": 0, "drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}[args.mode]
+    ctx = PcsContext(cfgs, device=local_rank, flags=mode_flags)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -228,8 +233,8 @@ def main():
     launch(0); torch.cuda.synchronize(dev)
     if rank == 0:
         from oracle import pcs_oracle as O
-        want, _ = O.process_frames(cfgs[:1], host0[0][:1], host0[1][:1])
-        got = d_out[0][:npts * POINT_SHORTS].cpu().numpy().reshape(-1, 5)
+        want, _ = O.process_frames(cfgs[:1], host0[0][:1], host0[1][:1], mode_flags, 1)
+        got = d_out[0][:want.size].cpu().numpy().reshape(-1, 5)
         if (got != want).any():
             raise SystemExit("bench aborted: HIP output differs from the oracle")
 
@@ -291,6 +296,20 @@ def main():
                          "algorithmic_bytes_per_launch": set_points * ALGO_BYTES_PER_POINT,
                          "timing": "hipEvent pair on the launch stream around the timed region / steps"},
         }
+        if args.mode != "dense":
+            out["config"]["mode"] = args.mode + " (diagnostic: count + scan + emit passes; not the headline workload)"
+        if world == 1 and not args.no_host_api:
+            # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
+            # pageable numpy memory like a caller of the reference's function would have. Never `value`.
+            reps = 5
+            ctx.process_frames(host0[0], host0[1])
+            th = time.perf_counter()
+            for _ in range(reps):
+                ctx.process_frames(host0[0], host0[1])
+            th = (time.perf_counter() - th) / reps
+            out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
+                               "unit": "Mpoints/s", "note": "pcs_process_frames with pageable host buffers: H2D + kernel + D2H, "
+                               "synchronous; bounded by the host link, not by the kernel"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
