@@ -32,6 +32,14 @@ struct pcs_ctx {
     uint32_t*                       d_tile_prefix = nullptr;
     uint32_t*                       d_stream_base = nullptr;   // n_streams + 1
     int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
+    // single-pass compaction state (pcs_fused_compact_kernel)
+    unsigned long long*             d_ticket = nullptr;        // never reset
+    unsigned long long              tickets_issued = 0;
+    uint64_t*                       d_desc = nullptr;          // one per tile
+    uint32_t*                       d_stream_end = nullptr;    // n_streams
+    uint32_t*                       d_error = nullptr;
+    uint32_t                        compact_seq = 0;
+    bool                            single_pass_ok = true;     // cleared if a look-back ever timed out
     bool                            dense_ok = false;          // every stream has n % 8 == 0
     bool                            any_ddist = false, any_cdist = false;
     std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 certified + identity R
@@ -299,7 +307,7 @@ int acquire_event_pair(pcs_ctx* c, std::pair<hipEvent_t, hipEvent_t>& pr)
 
 // The fused path for device-resident rasters. Counts end up in d_counts (if non-null).
 int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
-                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts)
+                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts, bool force_three_pass = false)
 {
     if (payload_shorts < c->max_payload_points * PCS_POINT_SHORTS && !has_pred(c->flags))
         return fail(c, PCS_ERR_CAPACITY, "payload buffer holds %zu shorts, %zu needed", payload_shorts,
@@ -316,6 +324,49 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         int rc = acquire_event_pair(c, ev);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(ev.first, c->stream));
+    }
+    const bool single_pass = pred && c->downsample == 1 && c->single_pass_ok && !force_three_pass;
+    if (single_pass) {
+        if (!c->d_ticket) {
+            HIPCHK(c, hipMalloc((void**)&c->d_ticket, sizeof(unsigned long long)));
+            HIPCHK(c, hipMalloc((void**)&c->d_desc, sizeof(uint64_t) * std::max<uint32_t>(c->total_tiles, 1)));
+            HIPCHK(c, hipMalloc((void**)&c->d_stream_end, sizeof(uint32_t) * c->n_streams));
+            HIPCHK(c, hipMalloc((void**)&c->d_error, sizeof(uint32_t)));
+            HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * std::max<uint32_t>(c->total_tiles, 1), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_error, 0, sizeof(uint32_t), c->stream));
+        }
+        c->compact_seq++;
+        if ((c->compact_seq & 0x3FFFFFFFu) == 0) {       // generation wrapped: old descriptors could alias
+            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * std::max<uint32_t>(c->total_tiles, 1), c->stream));
+            c->compact_seq++;
+        }
+        for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
+            const int nl = std::min(kLaunchStreams, c->n_streams - s0);
+            FramePtrs fp{};
+            uint32_t tiles = 0;
+            int m = 2;
+            for (int k = 0; k < nl; k++) {
+                fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
+                tiles += tiles_of(c->h_params[s0 + k].n_points);
+                m = std::min(m, c->math[s0 + k]);
+            }
+            CompactLaunch cl{};
+            cl.d_ticket = c->d_ticket; cl.ticket_base = c->tickets_issued;
+            cl.d_desc = c->d_desc + c->h_params[s0].tile_base;
+            cl.d_stream_end = c->d_stream_end;
+            cl.d_chain_in = s0 > 0 ? c->d_stream_end + (s0 - 1) : nullptr;
+            cl.d_error = c->d_error; cl.gen = c->compact_seq; cl.flags = c->flags;
+            HIPCHK(c, launch_fused_compact(c->d_params, s0, nl, tiles, m >= 1 ? MathSel::Cert : MathSel::Ieee, fp, cl,
+                                           d_payload, c->stream));
+            c->tickets_issued += tiles;
+        }
+        HIPCHK(c, launch_counts(c->d_stream_end, c->n_streams, d_counts ? d_counts : c->d_counts, c->stream));
+        if (c->kernel_timing) {
+            HIPCHK(c, hipEventRecord(ev.second, c->stream));
+            c->ev_pool.push_back(ev);
+        }
+        return PCS_OK;
     }
     if (pred) {
         for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
@@ -362,6 +413,22 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
     if (c->kernel_timing) {
         HIPCHK(c, hipEventRecord(ev.second, c->stream));
         c->ev_pool.push_back(ev);
+    }
+    return PCS_OK;
+}
+
+// Reads (and clears) the single-pass compaction's time-out word. Returns 1 if it was set.
+int take_compact_error(pcs_ctx* c, bool& was_set)
+{
+    was_set = false;
+    if (!c->d_error) return PCS_OK;
+    uint32_t e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->d_error, sizeof e, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e) {
+        was_set = true;
+        c->single_pass_ok = false;       // stay on the three-pass path from now on
+        HIPCHK(c, hipMemsetAsync(c->d_error, 0, sizeof e, c->stream));
     }
     return PCS_OK;
 }
@@ -539,6 +606,7 @@ void pcs_destroy(pcs_ctx* c)
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
     if (c->s_slab) (void)hipFree(c->s_slab);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -721,6 +789,13 @@ int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* 
     rc = run_fused_device(c, c->s_depth.data(), c->s_color.data(), c->s_payload, c->max_payload_points * PCS_POINT_SHORTS,
                           c->d_counts);
     if (rc) return rc;
+    bool timed_out = false;
+    if ((rc = take_compact_error(c, timed_out))) return rc;
+    if (timed_out) {      // a look-back spin expired: redo this frame-set with the count + scan + emit passes
+        rc = run_fused_device(c, c->s_depth.data(), c->s_color.data(), c->s_payload,
+                              c->max_payload_points * PCS_POINT_SHORTS, c->d_counts, true);
+        if (rc) return rc;
+    }
     std::vector<int32_t> h(c->n_streams + 1);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->d_counts, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -806,6 +881,12 @@ int pcs_synchronize(pcs_ctx* c)
     if (!c) return PCS_ERR_INVALID_ARG;
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool timed_out = false;
+    int rc = take_compact_error(c, timed_out);
+    if (rc) return rc;
+    if (timed_out)
+        return fail(c, PCS_ERR_HIP, "single-pass compaction: a look-back wait expired; the payload of the frame-set(s) since "
+                    "the last pcs_synchronize is invalid — re-submit them (the context now uses the three-pass path)");
     return PCS_OK;
 }
 

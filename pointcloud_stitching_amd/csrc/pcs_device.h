@@ -83,6 +83,21 @@ hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_la
                              uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
                              const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
                              int16_t* d_payload, hipStream_t st);
+// Single-pass ordered compaction (predicate, stride 1). See pcs_fused_compact_kernel.
+struct CompactLaunch {
+    unsigned long long* d_ticket;       // device counter, never reset
+    unsigned long long  ticket_base;    // tickets issued before this launch
+    uint64_t*           d_desc;         // launch_tiles descriptors
+    uint32_t*           d_stream_end;   // all streams
+    const uint32_t*     d_chain_in;     // total of earlier launches of the same frame-set, or nullptr
+    uint32_t*           d_error;
+    uint32_t            gen;
+    uint32_t            flags;
+};
+hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n_launch, uint32_t launch_tiles,
+                                MathSel math, const FramePtrs& fp, const CompactLaunch& cl, int16_t* d_payload,
+                                hipStream_t st);
+hipError_t launch_counts(const uint32_t* d_stream_end, int n_streams, int32_t* d_counts, hipStream_t st);
 hipError_t launch_verify_div_const(float c, float rc, int32_t dim, unsigned long long* d_bad, hipStream_t st);
 
 // a2 twin.

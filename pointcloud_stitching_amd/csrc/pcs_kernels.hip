@@ -574,6 +574,180 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
     store_staged(stage, head, (q_hi - q_lo) * PCS_POINT_BYTES, gdst);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SINGLE-PASS ordered compaction (predicate active, stride 1): one launch instead of count + scan + emit,
+// and the Z16 raster is read once. Chained scan with decoupled look-back over ALL tiles of the launch
+// in (stream, tile) order, so the global exclusive prefix of a tile IS its output point index and the
+// camera-order concatenation (a7) falls out of the same scan.
+//
+//  * Tile ids are handed out by an atomic ticket in the order workgroups START, never by blockIdx: a tile
+//    only ever waits for lower tickets, whose workgroups are already running and wait for nothing later
+//    -> no dependence on the (unspecified) dispatch order, no deadlock.
+//  * One 64-bit descriptor per tile: [63:34] launch generation, [33:32] status (1 = the tile's own count,
+//    2 = inclusive prefix), [31:0] value. Flag and payload travel in ONE naturally aligned 8-byte
+//    agent-scope relaxed store / load, so no separate release/acquire is needed, and stale descriptors of
+//    earlier launches read as "not ready" without clearing the array.
+//  * The first wavefront looks back 64 tiles at a time (ballot for the nearest inclusive prefix, sum the
+//    aggregates in front of it) while the other wavefronts already compute their records.
+//  * Every spin is bounded; on expiry the error word is set and the host re-runs the frame with the
+//    three-pass path.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kDescAggregate = 1u, kDescPrefix = 2u;
+constexpr uint32_t kSpinLimit = 1u << 18;
+
+__device__ __forceinline__ uint64_t desc_pack(uint32_t gen, uint32_t status, uint32_t value)
+{
+    return ((uint64_t)((gen << 2) | status) << 32) | (uint64_t)value;
+}
+
+// Exclusive prefix of tile `gtile` (first wavefront only, all 64 lanes participate).
+__device__ __forceinline__ uint32_t lookback(const uint64_t* __restrict__ desc, uint32_t gen, int32_t gtile,
+                                             uint32_t chain, uint32_t* __restrict__ error)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = 0;
+    int32_t base = gtile - 1;
+    for (;;) {
+        const int32_t idx = base - lane;                 // lane 0 = nearest predecessor
+        uint32_t value = 0;
+        uint64_t pmask = 0, need = ~0ull;
+        for (uint32_t spins = 0;; spins++) {
+            uint64_t d;
+            if (idx >= 0) d = __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else d = desc_pack(gen, kDescPrefix, chain);         // before the first tile: what earlier launches wrote
+            const uint32_t hi = (uint32_t)(d >> 32);
+            const uint32_t st = ((hi >> 2) == gen) ? (hi & 3u) : 0u;
+            value = (uint32_t)d;
+            const uint64_t rmask = __ballot(st != 0u);
+            pmask = __ballot(st == kDescPrefix);
+            const uint64_t first = pmask & (0ull - pmask);       // nearest inclusive prefix, if any
+            need = pmask ? (first | (first - 1ull)) : ~0ull;     // lanes up to and including it
+            if ((rmask & need) == need) break;
+            if (spins > kSpinLimit) {
+                if (lane == 0) atomicExch(error, 1u);
+                return 0u;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        uint32_t c = ((need >> lane) & 1ull) ? value : 0u;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
+        acc += c;
+        if (pmask) return acc;
+        base -= 64;
+    }
+}
+
+struct CompactArgs {
+    unsigned long long* ticket;       // never reset; ticket_base = its value when this launch was enqueued
+    unsigned long long  ticket_base;
+    uint64_t*           desc;         // one descriptor per tile of this launch
+    uint32_t*           stream_end;   // [stream] inclusive prefix at the stream's last tile
+    const uint32_t*     chain_in;     // output points written by earlier launches of this frame-set (or null)
+    uint32_t*           error;
+    uint32_t            gen;
+    uint32_t            flags;
+};
+
+template <class Mth>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int stream0, int n_launch, FramePtrs fp,
+                              CompactArgs a, uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t bcast[2];
+
+    if (threadIdx.x == 0) bcast[0] = (uint32_t)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
+    __syncthreads();
+    const uint32_t gtile = bcast[0];
+
+    // ticket -> (stream, tile): tiles are numbered stream-major
+    int s = 0;
+    uint32_t t = gtile, tiles_s = 0;
+    for (;; s++) {
+        tiles_s = (params[stream0 + s].n_points + kTilePoints - 1) / kTilePoints;
+        if (t < tiles_s || s == n_launch - 1) break;
+        t -= tiles_s;
+    }
+    const StreamParams& P = params[stream0 + s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = t * kTilePoints;
+    const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
+    const uint8_t* __restrict__ color = fp.color[s];
+
+    DepthSource<true, true, Mth> src{fp.depth[s]};
+    PointIn p[8];
+    src.load8(P, i0, n, p, nullptr);
+    const uint32_t keep = keep_mask8(p, i0, n, a.flags);
+
+    uint32_t wave_total;
+    const uint32_t ex = wave_exclusive_scan(__popc(keep), wave_total);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) wsum[wave] = wave_total;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    const uint32_t tile_kept = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const uint32_t lane_first = before + ex;
+
+    if (wave == 0) {
+        const uint32_t chain = a.chain_in ? *a.chain_in : 0u;
+        if (lane == 0)
+            __hip_atomic_store(a.desc + gtile, desc_pack(a.gen, kDescAggregate, tile_kept), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t excl = lookback(a.desc, a.gen, (int32_t)gtile, chain, a.error);
+        if (lane == 0) {
+            __hip_atomic_store(a.desc + gtile, desc_pack(a.gen, kDescPrefix, excl + tile_kept), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            bcast[1] = excl;
+            if (t == tiles_s - 1) a.stream_end[stream0 + s] = excl + tile_kept;
+        }
+    }
+
+    // records for all 8 points, straight-line (the predicate only gates the staging below)
+    Record rec[8];
+    auto fill = [&](auto& cv) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) rec[k] = make_record(P, color, p[k], cv);
+    };
+    if (Mth::kLazyCvt) {
+        LazyCvt lazy;
+        fill(lazy);
+        if (__builtin_expect(lazy.overflowed(), 0)) { ExactCvt exact; fill(exact); }
+    } else {
+        ExactCvt exact;
+        fill(exact);
+    }
+    __syncthreads();
+
+    const uint32_t q_lo = bcast[1];                       // global output point index of the tile's first kept point
+    uint8_t* gdst = payload_bytes + (size_t)q_lo * PCS_POINT_BYTES;
+    const uint32_t head = (uint32_t)((uintptr_t)gdst & 15u);
+    uint32_t rank = lane_first;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if ((keep >> k) & 1u) {
+            uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + rank * PCS_POINT_BYTES);
+            o[0] = (uint16_t)rec[k].xy; o[1] = (uint16_t)(rec[k].xy >> 16);
+            o[2] = (uint16_t)rec[k].zc; o[3] = (uint16_t)(rec[k].zc >> 16);
+            o[4] = (uint16_t)rec[k].b;
+            rank++;
+        }
+    }
+    __syncthreads();
+    store_staged(stage, head, tile_kept * PCS_POINT_BYTES, gdst);
+}
+
+// counts[s] = points stream s contributed, counts[n] = total; from the per-stream inclusive ends.
+__global__ void pcs_counts_kernel(const uint32_t* __restrict__ stream_end, int n_streams, int32_t* __restrict__ counts)
+{
+    const int s = threadIdx.x;
+    if (s < n_streams) counts[s] = (int32_t)(stream_end[s] - (s ? stream_end[s - 1] : 0u));
+    if (s == 0) counts[n_streams] = (int32_t)stream_end[n_streams - 1];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Kernels
 // ------------------------------------------------------------------------------------------------
@@ -875,6 +1049,31 @@ hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_la
     if (math != MathSel::Ieee) { if (pred) L(true, CertMath<false>); else L(false, CertMath<false>); }
     else                       { if (pred) L(true, IeeeMath); else L(false, IeeeMath); }
 #undef L
+    return hipGetLastError();
+}
+
+
+hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n_launch, uint32_t launch_tiles,
+                                MathSel math, const FramePtrs& fp, const CompactLaunch& cl, int16_t* d_payload,
+                                hipStream_t st)
+{
+    if (n_launch <= 0 || launch_tiles == 0) return hipSuccess;
+    CompactArgs a;
+    a.ticket = cl.d_ticket; a.ticket_base = cl.ticket_base; a.desc = cl.d_desc; a.stream_end = cl.d_stream_end;
+    a.chain_in = cl.d_chain_in; a.error = cl.d_error; a.gen = cl.gen & 0x3FFFFFFFu; a.flags = cl.flags;
+    uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
+    if (math != MathSel::Ieee)
+        hipLaunchKernelGGL((pcs_fused_compact_kernel<CertMath<false>>), dim3(launch_tiles), dim3(kBlockThreads), 0, st,
+                           d_params, stream0, n_launch, fp, a, out);
+    else
+        hipLaunchKernelGGL((pcs_fused_compact_kernel<IeeeMath>), dim3(launch_tiles), dim3(kBlockThreads), 0, st,
+                           d_params, stream0, n_launch, fp, a, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_counts(const uint32_t* d_stream_end, int n_streams, int32_t* d_counts, hipStream_t st)
+{
+    hipLaunchKernelGGL(pcs_counts_kernel, dim3(1), dim3(64), 0, st, d_stream_end, n_streams, d_counts);
     return hipGetLastError();
 }
 

@@ -442,3 +442,55 @@ def test_lazy_convert_redo_path(oracle):
         buf, _, _ = ctx.process_frames(depth, color)
     assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
     assert (want[:, 0] == 0).all()          # INT_MIN & 0xFFFF, the x86 answer (hardware alone would give -1)
+
+
+# ---------------------------------------------------------------------------------------------
+# single-pass ordered compaction (ticketed tiles + decoupled look-back)
+# ---------------------------------------------------------------------------------------------
+def test_single_pass_compaction_chained_launches_and_mixed_sizes(oracle):
+    # 21 streams -> two launches chained through stream_end; mixed raster sizes -> ticket->(stream, tile) search
+    sizes = [(64, 48), (128, 96), (104, 40), (200, 37), (640, 480)]
+    cfgs = [S.synth_stream_config(*sizes[i % len(sizes)], i) for i in range(21)]
+    depth = [S.synth_depth(c.depth.width, c.depth.height, i) for i, c in enumerate(cfgs)]
+    color = [S.synth_color(c.color.width, c.color.height, i) for i, c in enumerate(cfgs)]
+    for flags in (FLAG_DROP_INVALID, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT):
+        got, counts = run_fused(cfgs, depth, color, flags)
+        want, wcounts = oracle.process_frames(cfgs, depth, color, flags)
+        assert counts == wcounts
+        assert_same(got, want)
+
+
+def test_single_pass_compaction_repeated_launches_device_api(oracle):
+    # generations / tickets across many launches on one context; different inputs every time
+    cfgs, _, _ = S.synth_frame_set(3, 640, 480)
+    n_max = sum(c.n_points for c in cfgs) * 5
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        out = ctx.device_malloc(n_max * 2 + 64)
+        d_counts = ctx.device_malloc(4 * 4)
+        dd = [ctx.device_malloc(c.n_points * 2) for c in cfgs]
+        dc = [ctx.device_malloc(c.color_bytes) for c in cfgs]
+        for it in range(40):
+            depth = [S.synth_depth(640, 480, s, seed=1000 + it) for s in range(3)]
+            color = [S.synth_color(640, 480, s, seed=1000 + it) for s in range(3)]
+            if it % 7 == 3:
+                depth[1][:] = 0                      # an entire stream dropped
+            for p, a in zip(dd + dc, depth + color):
+                ctx.memcpy_h2d(p, a)
+            ctx.process_frames_device(dd, dc, out + 4, n_max, d_counts)     # +4: the reference's payload alignment
+            ctx.synchronize()
+            cnt = np.empty(4, np.int32)
+            ctx.memcpy_d2h(cnt, d_counts)
+            want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+            assert list(cnt[:3]) == wcounts and cnt[3] == want.shape[0], it
+            got = np.empty(want.size, np.int16)
+            if want.size:
+                ctx.memcpy_d2h(got, out + 4)
+            assert_same(got.reshape(-1, 5), want)
+
+
+def test_three_pass_path_still_used_for_strided_compaction(oracle):
+    cfgs, depth, color = S.synth_frame_set(2, 640, 480)
+    got, counts = run_fused(cfgs, depth, color, FLAG_DROP_INVALID, 4)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID, 4)
+    assert counts == wcounts
+    assert_same(got, want)
