@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -30,7 +31,8 @@ struct pcs_ctx {
     uint32_t                        total_tiles = 0;
     uint32_t*                       d_tile_counts = nullptr;
     uint32_t*                       d_tile_prefix = nullptr;
-    uint32_t*                       d_stream_base = nullptr;   // n_streams + 1
+    uint32_t*                       d_stream_base = nullptr;   // n_streams + 1 (kept points per stream)
+    uint32_t*                       d_arrive = nullptr;        // scan arrival counter (self-resetting)
     int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
     // single-pass compaction state (pcs_fused_compact_kernel)
     unsigned long long*             d_ticket = nullptr;        // never reset
@@ -145,6 +147,7 @@ void fill_params(const pcs_stream_config& s, StreamParams& p)
     p.bpp = s.color_bpp; p.stride = s.color_stride;
     p.color_bytes = (uint32_t)((uint64_t)s.color_stride * (uint64_t)s.color.height);
     p.n_points = (uint32_t)s.depth.width * (uint32_t)s.depth.height;
+    p.z_zero_iff_d_zero = (std::isfinite(s.depth_scale) && (s.depth_scale * 1.0f) != 0.0f) ? 1 : 0;
     p.ddist = (s.depth.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.depth)) ? 1 : 0;
     p.cdist = (s.color.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.color)) ? 1 : 0;
 }
@@ -377,7 +380,7 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             HIPCHK(c, launch_fused_count(c->d_params, s0, nl, mp, c->flags, fp, c->d_tile_counts, c->stream));
         }
         HIPCHK(c, launch_scan(c->d_params, c->n_streams, c->downsample, c->d_tile_counts, c->d_tile_prefix,
-                              c->d_stream_base, d_counts ? d_counts : c->d_counts, c->stream));
+                              c->d_stream_base, d_counts ? d_counts : c->d_counts, c->d_arrive, c->stream));
     }
     for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
         const int nl = std::min(kLaunchStreams, c->n_streams - s0);
@@ -562,6 +565,8 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     CREATE_CHK(hipMalloc((void**)&c->d_tile_prefix, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_stream_base, sizeof(uint32_t) * (c->n_streams + 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_counts, sizeof(int32_t) * (c->n_streams + 1)));
+    CREATE_CHK(hipMalloc((void**)&c->d_arrive, sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_arrive, 0, sizeof(uint32_t)));
     {   // device certificate for CertMath::div_const: all 2^32 numerators, once per distinct raster dimension
         std::vector<std::pair<int32_t, bool>> seen;
         unsigned long long* d_bad = nullptr;
@@ -589,6 +594,9 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         }
         if (d_bad) (void)hipFree(d_bad);
     }
+    // The single-pass (decoupled look-back) compaction is correct but measured slower than the three-pass
+    // one on MI355X: opt-in for experiments only.
+    { const char* e = getenv("PCS_COMPACT_SINGLE_PASS"); c->single_pass_ok = e && e[0] == '1'; }
     c->math.resize(c->n_streams);
     for (int s = 0; s < c->n_streams; s++)
         c->math[s] = c->h_params[s].cert_fast ? (c->h_params[s].ident_r ? 2 : 1) : 0;
@@ -606,7 +614,7 @@ void pcs_destroy(pcs_ctx* c)
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
     if (c->s_slab) (void)hipFree(c->s_slab);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -684,7 +692,7 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer_device(pcs_ctx* c, int stream, const fl
         c->s_pack_tiles = tiles;
     }
     HIPCHK(c, launch_pack_count(c->d_params, stream, vp, c->flags, c->s_pack_counts, c->stream));
-    HIPCHK(c, launch_pack_scan(tiles_of((uint32_t)n_points), c->s_pack_counts, c->s_pack_prefix, c->d_counts, c->stream));
+    HIPCHK(c, launch_pack_scan(tiles_of((uint32_t)n_points), c->s_pack_counts, c->s_pack_prefix, c->d_counts, c->d_arrive, c->stream));
     HIPCHK(c, launch_pack_emit(c->d_params, stream, vp, c->flags, c->s_pack_prefix, d_pc_buffer, c->stream));
     if (d_out_points)
         HIPCHK(c, hipMemcpyAsync(d_out_points, c->d_counts, sizeof(int), hipMemcpyDeviceToDevice, c->stream));

@@ -44,6 +44,7 @@ struct alignas(16) StreamParams {
     uint32_t w_magic, w_shift; // floor(i / W) == umulhi(i, w_magic) >> w_shift for i < 2^31 (0 = use '/')
     int32_t  cert_fast;      // host+device certified for CertMath (see pcs_capi.cpp)
     int32_t  ident_r;        // depth->colour rotation is exactly I, translation has no -0
+    int32_t  z_zero_iff_d_zero; // depth_scale finite and depth_scale*1 != 0: (z == 0) == (d == 0)
     const float* mx;         // [W]  (c - ppx) / fx   — IEEE division done once on the host
     const float* my;         // [H]  (r - ppy) / fy
 };
@@ -71,17 +72,18 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
 
 // Generic path: predicate / downsample / unaligned payload / W % 8 != 0.
 //   d_tile_counts, d_tile_prefix : one uint32 per tile of every stream (StreamParams::tile_base indexes them)
-//   d_stream_base                : n_total_streams + 1 uint32 (output point offsets; last = total)
+//   d_stream_kept                : n_total_streams uint32 (kept points per stream, before the stride)
+//   d_arrive                     : one zero-initialised uint32 (scan workgroups' arrival counter; self-resetting)
 //   d_counts (optional)          : n_total_streams + 1 int32 handed back to the caller
 // launch_pack_scan: d_out_points receives 2 int32 (kept, total)
 hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                               uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st);
 hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsample,
-                       const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_base,
-                       int32_t* d_counts, hipStream_t st);
+                       const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_kept,
+                       int32_t* d_counts, uint32_t* d_arrive, hipStream_t st);
 hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                              uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
-                             const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
+                             const uint32_t* d_tile_prefix, const uint32_t* d_stream_kept,
                              int16_t* d_payload, hipStream_t st);
 // Single-pass ordered compaction (predicate, stride 1). See pcs_fused_compact_kernel.
 struct CompactLaunch {
@@ -106,7 +108,7 @@ hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const Ver
 hipError_t launch_pack_count(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
                              uint32_t* d_tile_counts, hipStream_t st);
 hipError_t launch_pack_scan(uint32_t n_tiles, const uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
-                            int32_t* d_out_points, hipStream_t st);
+                            int32_t* d_out_points, uint32_t* d_arrive, hipStream_t st);
 hipError_t launch_pack_emit(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
                             const uint32_t* d_tile_prefix, int16_t* d_out, hipStream_t st);
 

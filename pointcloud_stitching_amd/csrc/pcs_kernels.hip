@@ -516,12 +516,13 @@ __device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src
 //   out_first output point index (within the whole payload) of kept-index 0 of this stream
 // A kept point with kept-index g is written iff g % ds == 0, to output point out_first + g / ds.
 // ------------------------------------------------------------------------------------------------
-template <class Src, bool PRED>
+template <class Src, bool PRED, bool DS1>
 __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& src, const uint8_t* __restrict__ color,
                                              uint32_t tile0, uint32_t n, uint32_t flags, uint32_t ds,
                                              uint32_t g0, uint32_t out_first, uint8_t* __restrict__ payload_bytes,
                                              uint8_t* stage, uint32_t* wsum, void* lds_in)
 {
+    if (DS1) ds = 1u;
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
     PointIn p[8];
     src.load8(P, i0, n, p, lds_in);
@@ -548,32 +549,47 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
         if (Src::kUsesLdsInput) __syncthreads();
     }
 
+    // Records for all 8 points, straight-line (a branch per point would serialise the lane's pixels and put
+    // the colour gather behind it); the predicate and the stride only gate the LDS staging below.
+    Record rec[8];
+    auto fill = [&](auto& cv) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) rec[k] = make_record(P, color, p[k], cv);
+    };
+    if (Src::Math::kLazyCvt) {
+        LazyCvt lazy;
+        fill(lazy);
+        if (__builtin_expect(lazy.overflowed(), 0)) { ExactCvt exact; fill(exact); }
+    } else {
+        ExactCvt exact;
+        fill(exact);
+    }
+
     // output range of the tile, in points: q = out_first + ceil(g/ds) for g in [g0, g0 + tile_kept)
-    const uint32_t q_lo = out_first + (g0 + ds - 1) / ds;
-    const uint32_t q_hi = out_first + (g0 + tile_kept + ds - 1) / ds;
+    const uint32_t q_lo = out_first + (DS1 ? g0 : (g0 + ds - 1) / ds);
+    const uint32_t q_hi = out_first + (DS1 ? g0 + tile_kept : (g0 + tile_kept + ds - 1) / ds);
     uint8_t* gdst = payload_bytes + (size_t)q_lo * PCS_POINT_BYTES;
     const uint32_t head = (uint32_t)((uintptr_t)gdst & 15u);
 
+    // kept-index of the lane's first kept point, and (for a stride) its quotient / remainder once per lane
     uint32_t g = g0 + lane_first;
+    uint32_t gq = DS1 ? g : g / ds, gr = DS1 ? 0u : g - gq * ds;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if ((keep >> k) & 1u) {
-            if (g % ds == 0) {
-                ExactCvt exact;
-                const Record r = make_record(P, color, p[k], exact);
-                const uint32_t q = out_first + g / ds;
-                uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + (q - q_lo) * PCS_POINT_BYTES);
-                o[0] = (uint16_t)r.xy; o[1] = (uint16_t)(r.xy >> 16);
-                o[2] = (uint16_t)r.zc; o[3] = (uint16_t)(r.zc >> 16);
-                o[4] = (uint16_t)r.b;
+            if (gr == 0u) {
+                uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + (out_first + gq - q_lo) * PCS_POINT_BYTES);
+                o[0] = (uint16_t)rec[k].xy; o[1] = (uint16_t)(rec[k].xy >> 16);
+                o[2] = (uint16_t)rec[k].zc; o[3] = (uint16_t)(rec[k].zc >> 16);
+                o[4] = (uint16_t)rec[k].b;
             }
-            g++;
+            if (DS1) gq++;
+            else if (++gr == ds) { gr = 0u; gq++; }
         }
     }
     __syncthreads();
     store_staged(stage, head, (q_hi - q_lo) * PCS_POINT_BYTES, gdst);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // SINGLE-PASS ordered compaction (predicate active, stride 1): one launch instead of count + scan + emit,
@@ -778,11 +794,27 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
-    DepthSource<DDIST, CDIST> src{fp.depth[s]};
-    PointIn p[8];
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
-    src.load8(P, i0, n, p, nullptr);
-    uint32_t c = __popc(keep_mask8(p, i0, n, flags));
+    uint32_t c;
+    if (flags == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
+        // z = depth_scale * d is zero exactly when d is (the host checked the scale: finite, and scale*1 != 0):
+        // count the non-zero Z16 values, no deprojection needed
+        c = 0;
+        const uint16_t* __restrict__ dp = fp.depth[s];
+        if (i0 + 8 <= n && ((uintptr_t)dp & 15) == 0 && (i0 & 7u) == 0) {
+            const uint4 dv = *reinterpret_cast<const uint4*>(dp + i0);
+            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) c += ((dw[k] & 0xFFFFu) != 0u) + ((dw[k] >> 16) != 0u);
+        } else {
+            for (uint32_t k = 0; k < 8 && i0 + k < n; k++) c += dp[i0 + k] != 0;
+        }
+    } else {
+        DepthSource<DDIST, CDIST> src{fp.depth[s]};
+        PointIn p[8];
+        src.load8(P, i0, n, p, nullptr);
+        c = __popc(keep_mask8(p, i0, n, flags));
+    }
 #pragma unroll
     for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -790,11 +822,11 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-template <bool PRED, class Mth>
+template <bool PRED, bool DS1, class Mth>
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                            uint32_t ds, const uint32_t* __restrict__ tile_prefix,
-                           const uint32_t* __restrict__ stream_base, uint8_t* __restrict__ payload_bytes)
+                           const uint32_t* __restrict__ stream_kept, uint8_t* __restrict__ payload_bytes)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t wsum[4];
@@ -805,53 +837,67 @@ void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0,
     if (tile0 >= n) return;
     DepthSource<true, true, Mth> src{fp.depth[s]};
     const uint32_t g0 = PRED ? tile_prefix[P.tile_base + blockIdx.x] : tile0;
-    const uint32_t out_first = PRED ? stream_base[stream0 + s] : P.out_base;
-    generic_tile<DepthSource<true, true, Mth>, PRED>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
+    uint32_t out_first = P.out_base;
+    if (PRED) {     // a7: this camera starts after the strided kept points of all earlier cameras
+        out_first = 0;
+        for (int e = 0; e < stream0 + s; e++) out_first += DS1 ? stream_kept[e] : (stream_kept[e] + ds - 1) / ds;
+    }
+    generic_tile<DepthSource<true, true, Mth>, PRED, DS1>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
                                                   payload_bytes, stage, wsum, nullptr);
 }
 
-// One workgroup of 1024 lanes: per-stream exclusive scan of the tile counts, and the running output
-// base of each stream (a7's camera-order concatenation after the per-camera stride).
+// Exclusive scan of the tile counts, one workgroup of 1024 lanes PER STREAM (streams scan concurrently).
+// Writes the tile prefixes, the stream's kept total and its output count ceil(kept / stride); the
+// stream's base in the stitched payload is summed from the totals by the emit kernel, and the grand total
+// by whichever workgroup arrives last (agent-scope counter).
 __global__ __launch_bounds__(1024)
 void pcs_scan_kernel(const StreamParams* __restrict__ params, int stream0, int n_streams, uint32_t override_n,
                      uint32_t ds, const uint32_t* __restrict__ tile_counts, uint32_t* __restrict__ tile_prefix,
-                     uint32_t* __restrict__ stream_base, int32_t* __restrict__ counts)
+                     uint32_t* __restrict__ stream_kept, int32_t* __restrict__ counts, uint32_t* __restrict__ arrive)
 {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
-    uint32_t base = 0;
-    for (int s = 0; s < n_streams; s++) {
-        const uint32_t n = override_n ? override_n : params[stream0 + s].n_points;
-        const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
-        const uint32_t tb = override_n ? 0u : params[stream0 + s].tile_base;
-        if (threadIdx.x == 0) carry_s = 0;
+    const int s = blockIdx.x;
+    const uint32_t n = override_n ? override_n : params[stream0 + s].n_points;
+    const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
+    const uint32_t tb = override_n ? 0u : params[stream0 + s].tile_base;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t c = (t < tiles) ? tile_counts[tb + t] : 0u;
+        uint32_t wave_total;
+        const uint32_t ex = wave_exclusive_scan(c, wave_total);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = wave_total;
         __syncthreads();
-        for (uint32_t t0 = 0; t0 < tiles; t0 += 1024) {
-            const uint32_t t = t0 + threadIdx.x;
-            const uint32_t c = (t < tiles) ? tile_counts[tb + t] : 0u;
-            uint32_t wave_total;
-            const uint32_t ex = wave_exclusive_scan(c, wave_total);
-            if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = wave_total;
-            __syncthreads();
-            uint32_t before = carry_s;
-            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wtot[w];
-            if (t < tiles) tile_prefix[tb + t] = before + ex;
-            __syncthreads();
-            if (threadIdx.x == 1023) carry_s = before + ex + c;
-            __syncthreads();
-        }
-        const uint32_t kept = carry_s;
-        const uint32_t outc = (kept + ds - 1) / ds;
-        if (threadIdx.x == 0) {
-            if (stream_base) stream_base[stream0 + s] = base;
-            if (counts) counts[stream0 + s] = (int32_t)outc;
-        }
-        base += outc;
+        uint32_t before = carry_s;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wtot[w];
+        if (t < tiles) tile_prefix[tb + t] = before + ex;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + ex + c;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (stream_base) stream_base[stream0 + n_streams] = base;
-        if (counts) counts[stream0 + n_streams] = (int32_t)base;
+        const uint32_t kept = carry_s;
+        const uint32_t outc = (kept + ds - 1) / ds;
+        if (stream_kept) stream_kept[stream0 + s] = kept;
+        if (counts) {
+            // grand total: the last workgroup to arrive adds up the per-stream outputs. The per-stream
+            // counts are written with agent-scope stores and read back with agent-scope loads, and the
+            // arrival counter is an agent-scope atomic, so the last arriver sees every other write.
+            __hip_atomic_store(counts + stream0 + s, (int32_t)outc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t ticket = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (uint32_t)n_streams - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                int32_t tot = 0;
+                for (int e = 0; e < n_streams; e++)
+                    tot += __hip_atomic_load(counts + stream0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                counts[stream0 + n_streams] = tot;
+                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+        }
     }
 }
 
@@ -914,7 +960,7 @@ void pcs_pack_emit_kernel(const StreamParams* __restrict__ params, int stream, V
     const uint32_t g0 = PRED ? tile_prefix[blockIdx.x] : tile0;
     // staging must not alias the input here (lanes still read inputs while others stage) unless we
     // barrier after load8 — generic_tile does (PRED path barriers in the scan; non-PRED explicitly).
-    generic_tile<VertexSource, PRED>(P, src, vp.color, tile0, n, flags, 1u, g0, 0u, out_bytes,
+    generic_tile<VertexSource, PRED, true>(P, src, vp.color, tile0, n, flags, 1u, g0, 0u, out_bytes,
                                      reinterpret_cast<uint8_t*>(lds), wsum, lds);
 }
 
@@ -1027,31 +1073,33 @@ hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_l
 }
 
 hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsample,
-                       const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_base,
-                       int32_t* d_counts, hipStream_t st)
+                       const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_kept,
+                       int32_t* d_counts, uint32_t* d_arrive, hipStream_t st)
 {
-    hipLaunchKernelGGL(pcs_scan_kernel, dim3(1), dim3(1024), 0, st, d_params, 0, n_streams, 0u,
-                       (uint32_t)downsample, d_tile_counts, d_tile_prefix, d_stream_base, d_counts);
+    hipLaunchKernelGGL(pcs_scan_kernel, dim3((unsigned)n_streams), dim3(1024), 0, st, d_params, 0, n_streams, 0u,
+                       (uint32_t)downsample, d_tile_counts, d_tile_prefix, d_stream_kept, d_counts, d_arrive);
     return hipGetLastError();
 }
 
 hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                              uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
-                             const uint32_t* d_tile_prefix, const uint32_t* d_stream_base,
+                             const uint32_t* d_tile_prefix, const uint32_t* d_stream_kept,
                              int16_t* d_payload, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     const dim3 grid = tile_grid(max_points, n_launch);
     const bool pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
+    const bool ds1 = downsample == 1;
     uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
-#define L(PR, M) hipLaunchKernelGGL((pcs_fused_emit_kernel<PR, M>), grid, dim3(kBlockThreads), 0, st, d_params, stream0, \
-                                    fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_base, out)
-    if (math != MathSel::Ieee) { if (pred) L(true, CertMath<false>); else L(false, CertMath<false>); }
-    else                       { if (pred) L(true, IeeeMath); else L(false, IeeeMath); }
+#define L(PR, D1, M) hipLaunchKernelGGL((pcs_fused_emit_kernel<PR, D1, M>), grid, dim3(kBlockThreads), 0, st, d_params, \
+                                        stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_kept, out)
+#define LM(M) do { if (pred) { if (ds1) L(true, true, M); else L(true, false, M); } \
+                   else      { if (ds1) L(false, true, M); else L(false, false, M); } } while (0)
+    if (math != MathSel::Ieee) LM(CertMath<false>); else LM(IeeeMath);
+#undef LM
 #undef L
     return hipGetLastError();
 }
-
 
 hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n_launch, uint32_t launch_tiles,
                                 MathSel math, const FramePtrs& fp, const CompactLaunch& cl, int16_t* d_payload,
@@ -1102,12 +1150,12 @@ hipError_t launch_pack_count(const StreamParams* d_params, int stream, const Ver
 }
 
 hipError_t launch_pack_scan(uint32_t n_tiles, const uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
-                            int32_t* d_out_points, hipStream_t st)
+                            int32_t* d_out_points, uint32_t* d_arrive, hipStream_t st)
 {
     // override_n makes the scan kernel ignore the params table (one segment of n_tiles tiles at index 0);
     // counts[0] = kept, counts[1] = total — d_out_points must hold 2 ints.
     hipLaunchKernelGGL(pcs_scan_kernel, dim3(1), dim3(1024), 0, st, (const StreamParams*)nullptr, 0, 1,
-                       n_tiles * kTilePoints, 1u, d_tile_counts, d_tile_prefix, (uint32_t*)nullptr, d_out_points);
+                       n_tiles * kTilePoints, 1u, d_tile_counts, d_tile_prefix, (uint32_t*)nullptr, d_out_points, d_arrive);
     return hipGetLastError();
 }
 

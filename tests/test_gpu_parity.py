@@ -248,7 +248,7 @@ def test_fused_more_streams_than_one_launch(oracle):
 @pytest.mark.parametrize("flags", [FLAG_DROP_INVALID, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT,
                                    FLAG_CUTOFF | FLAG_DROP_INVALID])
 @pytest.mark.parametrize("downsample", [1, 3])
-def test_fused_compaction_and_stride(oracle, flags, downsample):
+def test_fused_compaction_and_stride(oracle, flags, downsample, compaction_path):
     cfgs, depth, color = S.synth_frame_set(3, 640, 480)
     for d in depth:
         d[100:140, :] //= 4          # bring part of the scene inside the 1.5 m cutoff
@@ -447,7 +447,17 @@ def test_lazy_convert_redo_path(oracle):
 # ---------------------------------------------------------------------------------------------
 # single-pass ordered compaction (ticketed tiles + decoupled look-back)
 # ---------------------------------------------------------------------------------------------
-def test_single_pass_compaction_chained_launches_and_mixed_sizes(oracle):
+@pytest.fixture(params=["three_pass", "single_pass"])
+def compaction_path(request, monkeypatch):
+    """The three-pass path is the default; the single-pass (decoupled look-back) one is opt-in by environment."""
+    if request.param == "single_pass":
+        monkeypatch.setenv("PCS_COMPACT_SINGLE_PASS", "1")
+    else:
+        monkeypatch.delenv("PCS_COMPACT_SINGLE_PASS", raising=False)
+    return request.param
+
+
+def test_single_pass_compaction_chained_launches_and_mixed_sizes(oracle, compaction_path):
     # 21 streams -> two launches chained through stream_end; mixed raster sizes -> ticket->(stream, tile) search
     sizes = [(64, 48), (128, 96), (104, 40), (200, 37), (640, 480)]
     cfgs = [S.synth_stream_config(*sizes[i % len(sizes)], i) for i in range(21)]
@@ -460,7 +470,7 @@ def test_single_pass_compaction_chained_launches_and_mixed_sizes(oracle):
         assert_same(got, want)
 
 
-def test_single_pass_compaction_repeated_launches_device_api(oracle):
+def test_single_pass_compaction_repeated_launches_device_api(oracle, compaction_path):
     # generations / tickets across many launches on one context; different inputs every time
     cfgs, _, _ = S.synth_frame_set(3, 640, 480)
     n_max = sum(c.n_points for c in cfgs) * 5
@@ -492,5 +502,17 @@ def test_three_pass_path_still_used_for_strided_compaction(oracle):
     cfgs, depth, color = S.synth_frame_set(2, 640, 480)
     got, counts = run_fused(cfgs, depth, color, FLAG_DROP_INVALID, 4)
     want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID, 4)
+    assert counts == wcounts
+    assert_same(got, want)
+
+
+def test_drop_invalid_with_degenerate_depth_scale(oracle):
+    """depth_scale so small that scale*d underflows to 0 for small d: `z != 0` is no longer `d != 0`, so the
+    depth-only count shortcut must not be used (count and emit must agree)."""
+    cfgs, depth, color = S.synth_frame_set(1, 64, 48)
+    cfgs[0].depth_scale = 1e-45
+    depth[0][:] = (np.arange(64 * 48).reshape(48, 64) % 7).astype(np.uint16)
+    got, counts = run_fused(cfgs, depth, color, FLAG_DROP_INVALID)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
     assert counts == wcounts
     assert_same(got, want)
