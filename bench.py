@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
+    ap.add_argument("--payload-skew", type=int, default=0,
+                    help="diagnostic: offset the payload pointer by this many bytes (4 = the reference's buffer+2 shorts) "
+                         "to force the generic (unaligned) store path")
     ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff"], default="dense",
                     help="diagnostic: time the compaction path instead of the headline dense path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -166,7 +169,7 @@ def main():
     def up(nbytes):
         return (nbytes + 16 + 255) & ~255
     payload_shorts = set_points * POINT_SHORTS
-    depth_b, color_b, out_b = up(npts * 2), up(cfgs[0].color_bytes), up(payload_shorts * 2)
+    depth_b, color_b, out_b = up(npts * 2), up(cfgs[0].color_bytes), up(payload_shorts * 2 + 256)
     slab = torch.empty(R * (S * (depth_b + color_b) + out_b) + 256, dtype=torch.uint8, device=dev)
     base = slab.data_ptr()
     off = (-base) % 256
@@ -181,7 +184,8 @@ def main():
             v = slab[off:off + npts * 2]; v.copy_(torch.from_numpy(dep[s].reshape(-1).view(np.uint8))); dd.append(v); off += depth_b
             v = slab[off:off + col[s].size]; v.copy_(torch.from_numpy(col[s])); dc.append(v); off += color_b
         d_depth.append(dd); d_color.append(dc)
-        d_out.append(slab[off:off + payload_shorts * 2].view(torch.int16)); off += out_b
+        sk = args.payload_skew & ~1
+        d_out.append(slab[off + sk:off + sk + payload_shorts * 2].view(torch.int16)); off += out_b
     ring_bytes = R * (set_points * ALGO_BYTES_PER_POINT)
 
     gather = world > 1 and not args.no_gather

@@ -199,11 +199,21 @@ __device__ __forceinline__ float world_mm(const float* __restrict__ Mr, float X,
     return __fmul_rn(a, 1000.0f);
 }
 
+struct __attribute__((packed)) Record10 { uint32_t xy, zc; uint16_t b; };   // the wire layout of one point
+
 struct Record {              // one 10-byte point as three pieces
     uint32_t xy;             // x | y << 16
     uint32_t zc;             // z | (R | G<<8) << 16
     uint32_t b;              // B            (low 16 bits valid)
 };
+
+// Park one record at a 2-byte aligned LDS address: gfx950 takes unaligned DS accesses, so this is one
+// ds_write_b64 + one ds_write_b16 instead of five 2-byte writes.
+__device__ __forceinline__ void stage_record(uint8_t* lds, const Record& r)
+{
+    const Record10 w{r.xy, r.zc, (uint16_t)r.b};
+    __builtin_memcpy(lds, &w, sizeof w);
+}
 
 // One point -> one record. short(float) (:581-583) keeps the low 16 bits of the converted value.
 template <class Cvt>
@@ -527,30 +537,21 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
     PointIn p[8];
     src.load8(P, i0, n, p, lds_in);
 
-    uint32_t keep, lane_first, tile_kept;
+    uint32_t keep, ex = 0;
     if (PRED) {
         keep = keep_mask8(p, i0, n, flags);
         uint32_t wave_total;
-        const uint32_t c = __popc(keep);
-        const uint32_t ex = wave_exclusive_scan(c, wave_total);
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 63) wsum[wave] = wave_total;
-        __syncthreads();
-        uint32_t before = 0;
-        for (int w = 0; w < wave; w++) before += wsum[w];
-        tile_kept = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        lane_first = before + ex;
+        ex = wave_exclusive_scan(__popc(keep), wave_total);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = wave_total;
     } else {
-        const uint32_t pts = min(kTilePoints, n - tile0);
         const uint32_t mine = (i0 < n) ? min(8u, n - i0) : 0u;
         keep = (1u << mine) - 1u;
-        lane_first = min(threadIdx.x * kPointsPerLane, pts);
-        tile_kept = pts;
-        if (Src::kUsesLdsInput) __syncthreads();
     }
 
     // Records for all 8 points, straight-line (a branch per point would serialise the lane's pixels and put
-    // the colour gather behind it); the predicate and the stride only gate the LDS staging below.
+    // the colour gather behind it); the predicate and the stride only gate the LDS staging below. They are
+    // computed BEFORE the barrier of the cross-wave scan so that the colour gathers are in flight while the
+    // workgroup waits for its slowest wavefront.
     Record rec[8];
     auto fill = [&](auto& cv) {
 #pragma unroll
@@ -563,6 +564,21 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
     } else {
         ExactCvt exact;
         fill(exact);
+    }
+
+    uint32_t lane_first, tile_kept;
+    if (PRED) {
+        __syncthreads();
+        const int wave = threadIdx.x >> 6;
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        tile_kept = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        lane_first = before + ex;
+    } else {
+        const uint32_t pts = min(kTilePoints, n - tile0);
+        lane_first = min(threadIdx.x * kPointsPerLane, pts);
+        tile_kept = pts;
+        if (Src::kUsesLdsInput) __syncthreads();
     }
 
     // output range of the tile, in points: q = out_first + ceil(g/ds) for g in [g0, g0 + tile_kept)
@@ -578,10 +594,7 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
     for (int k = 0; k < 8; k++) {
         if ((keep >> k) & 1u) {
             if (gr == 0u) {
-                uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + (out_first + gq - q_lo) * PCS_POINT_BYTES);
-                o[0] = (uint16_t)rec[k].xy; o[1] = (uint16_t)(rec[k].xy >> 16);
-                o[2] = (uint16_t)rec[k].zc; o[3] = (uint16_t)(rec[k].zc >> 16);
-                o[4] = (uint16_t)rec[k].b;
+                stage_record(stage + head + (out_first + gq - q_lo) * PCS_POINT_BYTES, rec[k]);
             }
             if (DS1) gq++;
             else if (++gr == ds) { gr = 0u; gq++; }
@@ -745,10 +758,7 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if ((keep >> k) & 1u) {
-            uint16_t* o = reinterpret_cast<uint16_t*>(stage + head + rank * PCS_POINT_BYTES);
-            o[0] = (uint16_t)rec[k].xy; o[1] = (uint16_t)(rec[k].xy >> 16);
-            o[2] = (uint16_t)rec[k].zc; o[3] = (uint16_t)(rec[k].zc >> 16);
-            o[4] = (uint16_t)rec[k].b;
+            stage_record(stage + head + rank * PCS_POINT_BYTES, rec[k]);
             rank++;
         }
     }
@@ -783,17 +793,36 @@ void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
+// Count pass + scan, one launch. Every workgroup counts its tile's kept points; the LAST workgroup of a
+// stream to arrive (agent-scope arrival counter, G16-style hand-off: plain stores -> lane-0 agent release
+// fence + vmcnt(0) drain -> relaxed atomic arrive; the last arriver does one agent acquire, a barrier, and
+// reads the tile counts with agent-scope loads) turns that stream's counts into exclusive prefixes, writes
+// the stream's kept total and output count, and the last stream to finish adds up the grand total.
+// Counters reset themselves for the next launch.
+struct CountScanArgs {
+    uint32_t* tile_counts;
+    uint32_t* tile_prefix;
+    uint32_t* stream_kept;      // [stream] kept points (before the stride)
+    int32_t*  counts;           // [n_streams + 1] output points per stream, then the total
+    uint32_t* stream_arrive;    // [stream] zero-initialised, self-resetting
+    uint32_t* arrive;           // zero-initialised, self-resetting
+    uint32_t  flags, ds;
+    int32_t   n_streams_total;
+};
+
 template <bool DDIST, bool CDIST>
 __global__ __launch_bounds__(kBlockThreads)
-void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
-                            uint32_t* __restrict__ tile_counts)
+void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, CountScanArgs a)
 {
     __shared__ uint32_t wsum[4];
+    __shared__ uint32_t last_flag;
+    __shared__ uint32_t carry_s;
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
+    const uint32_t flags = a.flags;
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
     uint32_t c;
     if (flags == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
@@ -819,7 +848,59 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+
+    const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
+    const uint32_t tb = P.tile_base;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.tile_counts + tb + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t arrived = __hip_atomic_fetch_add(a.stream_arrive + stream0 + s, 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = (arrived == tiles - 1u);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(a.stream_arrive + stream0 + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        last_flag = last ? 1u : 0u;
+        carry_s = 0;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+
+    // this workgroup arrived last for its stream: exclusive scan of the stream's tile counts
+    for (uint32_t t0 = 0; t0 < tiles; t0 += kBlockThreads) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = (t < tiles) ? __hip_atomic_load(a.tile_counts + tb + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t wave_total;
+        const uint32_t ex = wave_exclusive_scan(v, wave_total);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = wave_total;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
+        if (t < tiles) a.tile_prefix[tb + t] = before + ex;
+        __syncthreads();
+        if (threadIdx.x == kBlockThreads - 1) carry_s = before + ex + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t kept = carry_s;
+        const uint32_t outc = (kept + a.ds - 1) / a.ds;
+        a.stream_kept[stream0 + s] = kept;
+        __hip_atomic_store(a.counts + stream0 + s, (int32_t)outc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t done = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (uint32_t)a.n_streams_total - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            int32_t tot = 0;
+            for (int e = 0; e < a.n_streams_total; e++)
+                tot += __hip_atomic_load(a.counts + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.counts[a.n_streams_total] = tot;
+            __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <bool PRED, bool DS1, class Mth>
@@ -1061,14 +1142,17 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
     return hipGetLastError();
 }
 
-hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                              uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st)
+hipError_t launch_fused_count_scan(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                                   const FramePtrs& fp, const CountScan& cs, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     const dim3 grid = tile_grid(max_points, n_launch);
+    CountScanArgs a;
+    a.tile_counts = cs.d_tile_counts; a.tile_prefix = cs.d_tile_prefix; a.stream_kept = cs.d_stream_kept;
+    a.counts = cs.d_counts; a.stream_arrive = cs.d_stream_arrive; a.arrive = cs.d_arrive;
+    a.flags = cs.flags; a.ds = cs.downsample; a.n_streams_total = cs.n_streams_total;
     // the predicate depends on depth-side distortion only through x; always run the general form
-    hipLaunchKernelGGL((pcs_fused_count_kernel<true, false>), grid, dim3(kBlockThreads), 0, st,
-                       d_params, stream0, fp, flags, d_tile_counts);
+    hipLaunchKernelGGL((pcs_fused_count_kernel<true, false>), grid, dim3(kBlockThreads), 0, st, d_params, stream0, fp, a);
     return hipGetLastError();
 }
 
@@ -1095,7 +1179,7 @@ hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_la
                                         stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_kept, out)
 #define LM(M) do { if (pred) { if (ds1) L(true, true, M); else L(true, false, M); } \
                    else      { if (ds1) L(false, true, M); else L(false, false, M); } } while (0)
-    if (math != MathSel::Ieee) LM(CertMath<false>); else LM(IeeeMath);
+    if (math == MathSel::CertIdentR) LM(CertMath<true>); else if (math == MathSel::Cert) LM(CertMath<false>); else LM(IeeeMath);
 #undef LM
 #undef L
     return hipGetLastError();
