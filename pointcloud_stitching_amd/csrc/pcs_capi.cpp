@@ -33,7 +33,6 @@ struct pcs_ctx {
     uint32_t*                       d_tile_prefix = nullptr;
     uint32_t*                       d_stream_base = nullptr;   // n_streams + 1 (kept points per stream)
     uint32_t*                       d_arrive = nullptr;        // scan arrival counter (self-resetting)
-    uint32_t*                       d_stream_arrive = nullptr; // per-stream tile arrival counters (self-resetting)
     int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
     // single-pass compaction state (pcs_fused_compact_kernel)
     unsigned long long*             d_ticket = nullptr;        // never reset
@@ -373,17 +372,15 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         return PCS_OK;
     }
     if (pred) {
-        CountScan cs{};
-        cs.d_tile_counts = c->d_tile_counts; cs.d_tile_prefix = c->d_tile_prefix; cs.d_stream_kept = c->d_stream_base;
-        cs.d_counts = d_counts ? d_counts : c->d_counts; cs.d_stream_arrive = c->d_stream_arrive; cs.d_arrive = c->d_arrive;
-        cs.flags = c->flags; cs.downsample = (uint32_t)c->downsample; cs.n_streams_total = c->n_streams;
         for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
             const int nl = std::min(kLaunchStreams, c->n_streams - s0);
             FramePtrs fp{};
             uint32_t mp = 0;
             for (int k = 0; k < nl; k++) { fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k]; mp = std::max(mp, c->h_params[s0 + k].n_points); }
-            HIPCHK(c, launch_fused_count_scan(c->d_params, s0, nl, mp, fp, cs, c->stream));
+            HIPCHK(c, launch_fused_count(c->d_params, s0, nl, mp, c->flags, fp, c->d_tile_counts, c->stream));
         }
+        HIPCHK(c, launch_scan(c->d_params, c->n_streams, c->downsample, c->d_tile_counts, c->d_tile_prefix,
+                              c->d_stream_base, d_counts ? d_counts : c->d_counts, c->d_arrive, c->stream));
     }
     for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
         const int nl = std::min(kLaunchStreams, c->n_streams - s0);
@@ -570,8 +567,6 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     CREATE_CHK(hipMalloc((void**)&c->d_counts, sizeof(int32_t) * (c->n_streams + 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_arrive, sizeof(uint32_t)));
     CREATE_CHK(hipMemset(c->d_arrive, 0, sizeof(uint32_t)));
-    CREATE_CHK(hipMalloc((void**)&c->d_stream_arrive, sizeof(uint32_t) * c->n_streams));
-    CREATE_CHK(hipMemset(c->d_stream_arrive, 0, sizeof(uint32_t) * c->n_streams));
     {   // device certificate for CertMath::div_const: all 2^32 numerators, once per distinct raster dimension
         std::vector<std::pair<int32_t, bool>> seen;
         unsigned long long* d_bad = nullptr;
@@ -619,7 +614,7 @@ void pcs_destroy(pcs_ctx* c)
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
     if (c->s_slab) (void)hipFree(c->s_slab);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_stream_arrive,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

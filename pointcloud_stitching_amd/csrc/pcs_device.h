@@ -76,18 +76,8 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
 //   d_arrive                     : one zero-initialised uint32 (scan workgroups' arrival counter; self-resetting)
 //   d_counts (optional)          : n_total_streams + 1 int32 handed back to the caller
 // launch_pack_scan: d_out_points receives 2 int32 (kept, total)
-struct CountScan {              // count pass with the per-stream scan folded in (last-arriver)
-    uint32_t* d_tile_counts;
-    uint32_t* d_tile_prefix;
-    uint32_t* d_stream_kept;    // n_streams
-    int32_t*  d_counts;         // n_streams + 1
-    uint32_t* d_stream_arrive;  // n_streams, zero-initialised (self-resetting)
-    uint32_t* d_arrive;         // 1, zero-initialised (self-resetting)
-    uint32_t  flags, downsample;
-    int32_t   n_streams_total;
-};
-hipError_t launch_fused_count_scan(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                                   const FramePtrs& fp, const CountScan& cs, hipStream_t st);
+hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                              uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st);
 hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsample,
                        const uint32_t* d_tile_counts, uint32_t* d_tile_prefix, uint32_t* d_stream_kept,
                        int32_t* d_counts, uint32_t* d_arrive, hipStream_t st);

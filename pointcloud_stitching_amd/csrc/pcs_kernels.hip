@@ -793,36 +793,20 @@ void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
-// Count pass + scan, one launch. Every workgroup counts its tile's kept points; the LAST workgroup of a
-// stream to arrive (agent-scope arrival counter, G16-style hand-off: plain stores -> lane-0 agent release
-// fence + vmcnt(0) drain -> relaxed atomic arrive; the last arriver does one agent acquire, a barrier, and
-// reads the tile counts with agent-scope loads) turns that stream's counts into exclusive prefixes, writes
-// the stream's kept total and output count, and the last stream to finish adds up the grand total.
-// Counters reset themselves for the next launch.
-struct CountScanArgs {
-    uint32_t* tile_counts;
-    uint32_t* tile_prefix;
-    uint32_t* stream_kept;      // [stream] kept points (before the stride)
-    int32_t*  counts;           // [n_streams + 1] output points per stream, then the total
-    uint32_t* stream_arrive;    // [stream] zero-initialised, self-resetting
-    uint32_t* arrive;           // zero-initialised, self-resetting
-    uint32_t  flags, ds;
-    int32_t   n_streams_total;
-};
-
+// Count pass: kept points per tile. (Folding the per-stream scan into this launch through a last-arriver
+// counter was measured and is slower — 450 returning atomics per counter line cost more than the separate
+// 5 us scan launch)
 template <bool DDIST, bool CDIST>
 __global__ __launch_bounds__(kBlockThreads)
-void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, CountScanArgs a)
+void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
+                            uint32_t* __restrict__ tile_counts)
 {
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t last_flag;
-    __shared__ uint32_t carry_s;
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
-    const uint32_t flags = a.flags;
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
     uint32_t c;
     if (flags == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
@@ -848,59 +832,7 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
-
-    const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
-    const uint32_t tb = P.tile_base;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(a.tile_counts + tb + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t arrived = __hip_atomic_fetch_add(a.stream_arrive + stream0 + s, 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = (arrived == tiles - 1u);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(a.stream_arrive + stream0 + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        last_flag = last ? 1u : 0u;
-        carry_s = 0;
-    }
-    __syncthreads();
-    if (!last_flag) return;
-
-    // this workgroup arrived last for its stream: exclusive scan of the stream's tile counts
-    for (uint32_t t0 = 0; t0 < tiles; t0 += kBlockThreads) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t v = (t < tiles) ? __hip_atomic_load(a.tile_counts + tb + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        uint32_t wave_total;
-        const uint32_t ex = wave_exclusive_scan(v, wave_total);
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = wave_total;
-        __syncthreads();
-        uint32_t before = carry_s;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
-        if (t < tiles) a.tile_prefix[tb + t] = before + ex;
-        __syncthreads();
-        if (threadIdx.x == kBlockThreads - 1) carry_s = before + ex + v;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t kept = carry_s;
-        const uint32_t outc = (kept + a.ds - 1) / a.ds;
-        a.stream_kept[stream0 + s] = kept;
-        __hip_atomic_store(a.counts + stream0 + s, (int32_t)outc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t done = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (uint32_t)a.n_streams_total - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            int32_t tot = 0;
-            for (int e = 0; e < a.n_streams_total; e++)
-                tot += __hip_atomic_load(a.counts + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.counts[a.n_streams_total] = tot;
-            __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 template <bool PRED, bool DS1, class Mth>
@@ -967,12 +899,10 @@ void pcs_scan_kernel(const StreamParams* __restrict__ params, int stream0, int n
             // counts are written with agent-scope stores and read back with agent-scope loads, and the
             // arrival counter is an agent-scope atomic, so the last arriver sees every other write.
             __hip_atomic_store(counts + stream0 + s, (int32_t)outc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t ticket = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ticket == (uint32_t)n_streams - 1u) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                int32_t tot = 0;
+                    int32_t tot = 0;
                 for (int e = 0; e < n_streams; e++)
                     tot += __hip_atomic_load(counts + stream0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 counts[stream0 + n_streams] = tot;
@@ -1142,17 +1072,14 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
     return hipGetLastError();
 }
 
-hipError_t launch_fused_count_scan(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                                   const FramePtrs& fp, const CountScan& cs, hipStream_t st)
+hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                              uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     const dim3 grid = tile_grid(max_points, n_launch);
-    CountScanArgs a;
-    a.tile_counts = cs.d_tile_counts; a.tile_prefix = cs.d_tile_prefix; a.stream_kept = cs.d_stream_kept;
-    a.counts = cs.d_counts; a.stream_arrive = cs.d_stream_arrive; a.arrive = cs.d_arrive;
-    a.flags = cs.flags; a.ds = cs.downsample; a.n_streams_total = cs.n_streams_total;
     // the predicate depends on depth-side distortion only through x; always run the general form
-    hipLaunchKernelGGL((pcs_fused_count_kernel<true, false>), grid, dim3(kBlockThreads), 0, st, d_params, stream0, fp, a);
+    hipLaunchKernelGGL((pcs_fused_count_kernel<true, false>), grid, dim3(kBlockThreads), 0, st,
+                       d_params, stream0, fp, flags, d_tile_counts);
     return hipGetLastError();
 }
 
