@@ -356,14 +356,13 @@ struct DepthSource {
     using Math = Mth;
     const uint16_t* __restrict__ depth;
 
-    __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8],
-                                          void* /*lds*/) const
+    // The distortion decision is taken ONCE per lane, outside the pixel loop: a (wave-uniform) test per
+    // pixel splits the lane's code into 16 basic blocks, which stops the scheduler from interleaving the
+    // pixels and the compiler from packing pairs of them into v_pk_* instructions (measured: the emit
+    // kernel ran 27 us with per-pixel tests vs 19 us for the dense kernel without them).
+    template <bool DD, bool CD>
+    __device__ __forceinline__ void load8_impl(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8]) const
     {
-        if (i0 >= n) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) p[k] = PointIn{0, 0, 0, 0, 0};
-            return;
-        }
         if ((P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0) {
             // all 8 pixels on one raster row; one 16-byte depth load, two 16-byte LUT loads
             // floor(i0 / W) by the host-verified multiply-shift (i0 < 2^31)
@@ -379,7 +378,7 @@ struct DepthSource {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
-                p[k] = deproject_pixel<DDIST, CDIST, Mth>(P, d, mxs[k], my);
+                p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], my);
             }
         } else {
 #pragma unroll
@@ -387,9 +386,21 @@ struct DepthSource {
                 const uint32_t i = min(i0 + k, n - 1);
                 const uint32_t r = i / (uint32_t)P.W;
                 const uint32_t c = i - r * (uint32_t)P.W;
-                p[k] = deproject_pixel<DDIST, CDIST, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+                p[k] = deproject_pixel<DD, CD, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
             }
         }
+    }
+
+    __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8],
+                                          void* /*lds*/) const
+    {
+        if (i0 >= n) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) p[k] = PointIn{0, 0, 0, 0, 0};
+            return;
+        }
+        if ((DDIST || CDIST) && (P.ddist | P.cdist)) load8_impl<DDIST, CDIST>(P, i0, n, p);
+        else load8_impl<false, false>(P, i0, n, p);
     }
     static constexpr bool kUsesLdsInput = false;
 };
