@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--payload-skew", type=int, default=0,
                     help="diagnostic: offset the payload pointer by this many bytes (4 = the reference's buffer+2 shorts) "
                          "to force the generic (unaligned) store path")
-    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff"], default="dense",
+    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff", "pack"], default="dense",
                     help="diagnostic: time the compaction path instead of the headline dense path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--preheat-ms", type=float, default=400.0,
@@ -159,7 +159,7 @@ def main():
     # global camera index = rank*S + s  -> extrinsic transform[(rank*S+s) % 8], distinct seeds per camera
     cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
     from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_DROP_INVALID
-    mode_flags = {"dense": 0, "drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}[args.mode]
+    mode_flags = {"dense": 0, "drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF, "pack": 0}[args.mode]
     ctx = PcsContext(cfgs, device=local_rank, flags=mode_flags)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
@@ -199,6 +199,17 @@ def main():
     lib = ctx._lib
     h = ctx._h
     VP = C.c_void_p
+    pack_args = None
+    if args.mode == "pack":
+        # a2 twin: copyPointCloudXYZRGBToBufferSIMD's inputs (vertices 12 B + texcoords 8 B per point) resident in HBM
+        vt_slab = torch.empty(S * (up(npts * 12) + up(npts * 8)) + 256, dtype=torch.uint8, device=dev)
+        vo = (-vt_slab.data_ptr()) % 256
+        pack_args = []
+        for s in range(S):
+            v, t = ctx.deproject(s, host0[0][s])
+            dv = vt_slab[vo:vo + npts * 12]; dv.copy_(torch.from_numpy(v.reshape(-1).view(np.uint8))); vo += up(npts * 12)
+            dt = vt_slab[vo:vo + npts * 8]; dt.copy_(torch.from_numpy(t.reshape(-1).view(np.uint8))); vo += up(npts * 8)
+            pack_args.append((VP(dv.data_ptr()), VP(dt.data_ptr())))
     call_args = []
     for slot in range(R):
         dp = (VP * S)(*[t.data_ptr() for t in d_depth[slot]])
@@ -207,6 +218,13 @@ def main():
 
     def launch(slot):
         dp, cp, out = call_args[slot]
+        if pack_args is not None:
+            for s in range(S):
+                rc = lib.pcs_copy_pointcloud_xyzrgb_to_buffer_device(
+                    h, s, pack_args[s][0], pack_args[s][1], npts, cp[s], VP(out.value + s * npts * 10), None)
+                if rc:
+                    raise RuntimeError(lib.pcs_last_error(h).decode())
+            return
         rc = lib.pcs_process_frames_device(h, dp, cp, out, payload_shorts, None)
         if rc:
             raise RuntimeError(lib.pcs_last_error(h).decode())
@@ -259,10 +277,21 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms = ctx.timer_elapsed_ms()
 
+    shard_only = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if gather:
+            # the same K steps without the exchange: what the kernels alone sustain when streams are only sharded
+            barrier()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                launch(k % R)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            shard_only = float(t.item())
 
     traffic, traffic_src = args.traffic, "--traffic"
     if traffic is None:
@@ -300,7 +329,22 @@ def main():
                          "algorithmic_bytes_per_launch": set_points * ALGO_BYTES_PER_POINT,
                          "timing": "hipEvent pair on the launch stream around the timed region / steps"},
         }
-        if args.mode != "dense":
+        if shard_only is not None:
+            gb = (world - 1) * payload_shorts * 2 * args.steps / elapsed / 1e9
+            out["gather"] = {"root_ingest_GBps": round(gb, 1), "bytes_per_peer_per_step": payload_shorts * 2,
+                             "note": "value includes one RCCL gather of every rank's payload to rank 0 per step "
+                                     "(double-buffered against the next kernel); it is bound by the peers' xGMI links "
+                                     "into the root, not by the kernel",
+                             "shard_only_value": round(total_points / shard_only / 1e6, 1),
+                             "shard_only_ms_per_step": round(shard_only * 1e3 / args.steps, 5)}
+        if args.mode == "pack":
+            out["config"]["mode"] = "pack (diagnostic: a2 twin from resident vertices/texcoords, one launch per stream, 33 B/point)"
+            out["roofline"]["achieved"] = round(set_points * 33 / (kern_ms * 1e-3) / 1e9, 1)
+            out["roofline"]["frac"] = round(out["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
+            out["roofline"]["kernel"] = "pcs_pack_dense_kernel"
+            out["roofline"]["algorithmic_bytes_per_launch"] = npts * 33
+            out["roofline"]["traffic"] = None
+        elif args.mode != "dense":
             out["config"]["mode"] = args.mode + " (diagnostic: count + scan + emit passes; not the headline workload)"
         if world == 1 and not args.no_host_api:
             # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
