@@ -265,6 +265,29 @@ def main():
         for k in range(50):
             launch(k % R)
         torch.cuda.synchronize(dev)
+    gather_error = None
+    if gather:
+        # The exchange cannot be exercised on the single-GPU development boxes; if RCCL refuses it here the run
+        # degrades to shard-only (and says so) instead of producing no line at all.
+        try:
+            step(0); step(1); drain(); torch.cuda.synchronize(dev)
+            ok = torch.tensor([1], dtype=torch.int32, device=dev)
+        except Exception as e:          # noqa: BLE001
+            gather_error = f"{type(e).__name__}: {e}"[:300]
+            ok = torch.tensor([0], dtype=torch.int32, device=dev)
+            pending[0] = pending[1] = None
+        try:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                gather = False
+        except Exception as e:          # noqa: BLE001
+            gather = False
+            gather_error = (gather_error or "") + f" | all_reduce: {e}"[:200]
+        if rank == 0 and gather:
+            # a7: rank r's payload must sit at [r*n, (r+1)*n) of the stitched buffer; rank 0's own slice is checkable here
+            own = stitched[1][:payload_shorts]
+            if not torch.equal(own, d_out[1 % R]):
+                raise SystemExit("bench aborted: gathered slice of rank 0 differs from its payload")
     for k in range(args.warmup):
         step(k)
     drain(); barrier()
@@ -329,6 +352,9 @@ def main():
                          "algorithmic_bytes_per_launch": set_points * ALGO_BYTES_PER_POINT,
                          "timing": "hipEvent pair on the launch stream around the timed region / steps"},
         }
+        if gather_error:
+            out["gather_error"] = gather_error
+            out["config"]["gather_to_rank0"] = False
         if shard_only is not None:
             gb = (world - 1) * payload_shorts * 2 * args.steps / elapsed / 1e9
             out["gather"] = {"root_ingest_GBps": round(gb, 1), "bytes_per_peer_per_step": payload_shorts * 2,
