@@ -193,6 +193,16 @@ int pcs_deproject(pcs_ctx* ctx, int stream, const uint16_t* depth, float* vertic
 int pcs_stitch_device(pcs_ctx* ctx, const int16_t* const* d_cam_payload, const int* cam_points, int n_cams,
                       int downsample, int16_t* d_stitched_payload, size_t stitched_shorts, int* total_points);
 
+/* ---- voxel-grid downsample of a packed payload (BASELINE config 5) ------------------------------ *
+ * NOT in the reference (it includes pcl/filters/voxel_grid.h but never instantiates it). Defined in the
+ * payload's integer millimetre domain: voxel = floor(coord / leaf_mm) per axis; one output point per occupied
+ * voxel = integer mean of x,y,z (truncating) and of R,G,B; output sorted by (z,y,x) voxel, x fastest.
+ * The output needs room for n_points points in the worst case. *d_out_points / *out_points = voxels written. */
+int pcs_voxel_grid_device(pcs_ctx* ctx, const int16_t* d_payload, int n_points, int leaf_mm,
+                          int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
+int pcs_voxel_grid(pcs_ctx* ctx, const int16_t* payload, int n_points, int leaf_mm,
+                   int16_t* out, size_t out_shorts, int* out_points);
+
 /* ---- stream / timing plumbing ----------------------------------------------------------- */
 int   pcs_set_stream(pcs_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL = own stream) */
 void* pcs_get_stream(pcs_ctx* ctx);

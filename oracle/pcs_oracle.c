@@ -141,3 +141,55 @@ int pcs_oracle_process_frames(const pcs_stream_config* streams, int n_streams,
     }
     return (int)total;
 }
+
+/* ------------------------------------------------------------------------------------------ *
+ * Voxel-grid downsample. NOT a restatement of the reference (which includes pcl/filters/voxel_grid.h,
+ * src/pcs-multicamera-optimized.cpp:17, but never uses it): this is the CPU statement of the op as
+ * DEFINED by this build (include/pcs_hip.h, pcs_voxel_grid) — parity with PCL 1.8's float VoxelGrid is
+ * unpinned. Sort point indices by (z,y,x) voxel, then integer means per run.
+ * ------------------------------------------------------------------------------------------ */
+static int floor_div_i(int v, int leaf) { return v >= 0 ? v / leaf : -((-v + leaf - 1) / leaf); }
+
+typedef struct { uint64_t key; uint32_t idx; } pcs_o_vk;
+
+static int pcs_o_vk_cmp(const void* a, const void* b)
+{
+    const pcs_o_vk* x = (const pcs_o_vk*)a; const pcs_o_vk* y = (const pcs_o_vk*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+int pcs_oracle_voxel_grid(const int16_t* payload, int n_points, int leaf_mm, int16_t* out)
+{
+    if (n_points <= 0) return 0;
+    pcs_o_vk* v = (pcs_o_vk*)malloc(sizeof(pcs_o_vk) * (size_t)n_points);
+    if (!v) return -1;
+    for (int i = 0; i < n_points; i++) {
+        const int16_t* p = payload + PCS_POINT_SHORTS * (size_t)i;
+        uint64_t kx = (uint64_t)(floor_div_i(p[0], leaf_mm) + 32768);
+        uint64_t ky = (uint64_t)(floor_div_i(p[1], leaf_mm) + 32768);
+        uint64_t kz = (uint64_t)(floor_div_i(p[2], leaf_mm) + 32768);
+        v[i].key = (kz << 34) | (ky << 17) | kx;
+        v[i].idx = (uint32_t)i;
+    }
+    qsort(v, (size_t)n_points, sizeof(pcs_o_vk), pcs_o_vk_cmp);
+    int nv = 0;
+    for (int i = 0; i < n_points;) {
+        int64_t sx = 0, sy = 0, sz = 0; uint32_t r = 0, g = 0, b = 0, n = 0;
+        int j = i;
+        for (; j < n_points && v[j].key == v[i].key; j++) {
+            const int16_t* p = payload + PCS_POINT_SHORTS * (size_t)v[j].idx;
+            const uint32_t c = (uint16_t)p[3];
+            sx += p[0]; sy += p[1]; sz += p[2];
+            r += c & 0xFFu; g += c >> 8; b += (uint16_t)p[4] & 0xFFu; n++;
+        }
+        int16_t* o = out + PCS_POINT_SHORTS * (size_t)nv;
+        o[0] = (int16_t)(sx / (int64_t)n); o[1] = (int16_t)(sy / (int64_t)n); o[2] = (int16_t)(sz / (int64_t)n);
+        o[3] = (int16_t)(uint16_t)((r / n) | ((g / n) << 8));
+        o[4] = (int16_t)(b / n);
+        nv++;
+        i = j;
+    }
+    free(v);
+    return nv;
+}

@@ -63,6 +63,10 @@ int pcs_oracle_process_frames(const pcs_stream_config* streams, int n_streams,
                               const uint16_t* const* depth, const uint8_t* const* color,
                               uint32_t flags, int downsample, int16_t* payload, int* counts);
 
+/* Voxel-grid downsample as DEFINED by this build (not in the reference; see include/pcs_hip.h). Returns the
+ * number of voxels written to out (room for n_points points needed), <0 on OOM. */
+int pcs_oracle_voxel_grid(const int16_t* payload, int n_points, int leaf_mm, int16_t* out);
+
 /* ---- timed CPU baseline (pcs_oracle_simd.c): AVX2/FMA + OpenMP forms of the same arithmetic,
  * bit-identical to the functions above for flags == 0, downsample == 1. ------------------------ */
 int  pcs_oracle_simd_available(void);   /* 1 if the host CPU has AVX2+FMA */

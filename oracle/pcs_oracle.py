@@ -49,6 +49,8 @@ def lib():
         L.pcs_oracle_process_frames.restype = C.c_int
         L.pcs_oracle_process_frames.argtypes = [SC, C.c_int, P(C.c_void_p), P(C.c_void_p), C.c_uint32, C.c_int,
                                                  C.c_void_p, P(C.c_int)]
+        L.pcs_oracle_voxel_grid.restype = C.c_int
+        L.pcs_oracle_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pcs_oracle_simd_available.restype = C.c_int
         L.pcs_oracle_max_threads.restype = C.c_int
         L.pcs_oracle_pack_simd_omp.restype = C.c_int
@@ -157,3 +159,12 @@ def process_frames(configs: Sequence[StreamConfig], depth: Sequence[np.ndarray],
     if tot < 0:
         raise MemoryError("oracle out of memory")
     return out[:tot].copy(), [int(x) for x in counts]
+
+
+def voxel_grid(payload: np.ndarray, leaf_mm: int) -> np.ndarray:
+    p = np.ascontiguousarray(payload, np.int16).reshape(-1, POINT_SHORTS)
+    out = np.zeros((max(p.shape[0], 1), POINT_SHORTS), np.int16)
+    nv = lib().pcs_oracle_voxel_grid(_p(p), p.shape[0], int(leaf_mm), _p(out))
+    if nv < 0:
+        raise MemoryError
+    return out[:nv].copy()

@@ -187,6 +187,20 @@ class PcsContext:
                                                 stitched_shorts, C.byref(total)))
         return total.value
 
+    # -- voxel grid (defined by this build; see include/pcs_hip.h) --------------------------------
+    def voxel_grid(self, payload: np.ndarray, leaf_mm: int) -> np.ndarray:
+        """Voxel-grid downsample of packed records (int16 [n,5]) -> int16 [n_voxels,5]."""
+        p = np.ascontiguousarray(payload, np.int16).reshape(-1, POINT_SHORTS)
+        out = np.zeros((max(p.shape[0], 1), POINT_SHORTS), np.int16)
+        cnt = C.c_int(0)
+        self._check(self._lib.pcs_voxel_grid(self._h, _ptr(p), p.shape[0], int(leaf_mm), _ptr(out), out.size, C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def voxel_grid_device(self, d_payload: int, n_points: int, leaf_mm: int, d_out: int, out_shorts: int,
+                          d_out_points: int = 0) -> None:
+        self._check(self._lib.pcs_voxel_grid_device(self._h, d_payload, n_points, int(leaf_mm), d_out, out_shorts,
+                                                    d_out_points or None))
+
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))

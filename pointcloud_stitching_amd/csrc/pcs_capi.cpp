@@ -66,6 +66,9 @@ struct pcs_ctx {
     int16_t*                        s_payload = nullptr;  size_t s_payload_cap = 0;   // bytes
     float*                          s_vertices = nullptr; size_t s_vertices_cap = 0;
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
+    void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
+    int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
+    int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
     uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
 
     std::string                     err;
@@ -614,7 +617,7 @@ void pcs_destroy(pcs_ctx* c)
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
     if (c->s_slab) (void)hipFree(c->s_slab);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -869,6 +872,52 @@ int pcs_stitch_device(pcs_ctx* c, const int16_t* const* d_cam_payload, const int
         out += kept;
     }
     if (total_points) *total_points = (int)out;
+    return PCS_OK;
+}
+
+// ---- voxel-grid downsample (not in the reference; defined in pcs_voxel.hip / DESIGN.md) ----------
+int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, int leaf_mm, int16_t* d_out,
+                          size_t out_shorts, int32_t* d_out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
+    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
+    if (n_points > 0 && (!d_payload || !d_out)) return fail(c, PCS_ERR_INVALID_ARG, "NULL device pointer");
+    if (out_shorts < (size_t)n_points * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every point its own voxel) needs %zu",
+                    out_shorts, (size_t)n_points * PCS_POINT_SHORTS);
+    DeviceGuard guard(c->device);
+    const size_t need = voxel_workspace_bytes((uint32_t)n_points, nullptr, nullptr);
+    if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
+    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    if (rc) return rc;
+    HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out,
+                                d_out_points, c->stream));
+    return PCS_OK;
+}
+
+int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,
+                   int* out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
+    if (n_points == 0) { if (out_points) *out_points = 0; return PCS_OK; }
+    if (!payload || !out) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    DeviceGuard guard(c->device);
+    const size_t bytes = (size_t)n_points * PCS_POINT_BYTES;
+    int rc;
+    if ((rc = ensure(c, c->s_voxel_in, c->s_voxel_in_cap, bytes))) return rc;
+    if ((rc = ensure(c, c->s_voxel_out, c->s_voxel_out_cap, bytes))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_voxel_in, payload, bytes, hipMemcpyHostToDevice, c->stream));
+    rc = pcs_voxel_grid_device(c, c->s_voxel_in, n_points, leaf_mm, c->s_voxel_out, (size_t)n_points * PCS_POINT_SHORTS, c->d_counts);
+    if (rc) return rc;
+    int32_t nv = 0;
+    HIPCHK(c, hipMemcpyAsync(&nv, c->d_counts, sizeof nv, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_shorts < (size_t)nv * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts, %zu needed", out_shorts, (size_t)nv * PCS_POINT_SHORTS);
+    if (nv) HIPCHK(c, hipMemcpy(out, c->s_voxel_out, (size_t)nv * PCS_POINT_BYTES, hipMemcpyDeviceToHost));
+    if (out_points) *out_points = nv;
     return PCS_OK;
 }
 
