@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
+    ap.add_argument("--debug-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: exercise the N>1 control flow on ONE GPU (all ranks on device 0, gathers staged through "
+                         "host memory). For testing the script only — the numbers mean nothing.")
     ap.add_argument("--payload-skew", type=int, default=0,
                     help="diagnostic: offset the payload pointer by this many bytes (4 = the reference's buffer+2 shorts) "
                          "to force the generic (unaligned) store path")
@@ -147,11 +150,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
+    debug_gloo = args.debug_backend == "gloo"
+    if debug_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if debug_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     S, W, H, R = args.streams, args.width, args.height, max(args.ring, 2)
     npts = W * H
@@ -230,6 +239,23 @@ def main():
             raise RuntimeError(lib.pcs_last_error(h).decode())
 
     pending = [None, None]
+    red_dev = torch.device("cpu") if debug_gloo else dev      # where the tiny control reductions live
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def gather_async(src, dst):
+        if not debug_gloo:
+            return st.gather_fixed(src, dst, async_op=True)
+        torch.cuda.synchronize(dev)                       # script test only: stage through host memory
+        host = src.cpu()
+        outs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, outs, dst=0)
+        if rank == 0:
+            for r, o in enumerate(outs):
+                dst[r * host.numel():(r + 1) * host.numel()].copy_(o)
+        return _Done()
 
     def step(k):
         slot = k % R
@@ -237,7 +263,7 @@ def main():
             if pending[k & 1] is not None:       # the buffer pair (slot's out, stitched[k&1]) is free again
                 pending[k & 1].wait()
             launch(slot)
-            pending[k & 1] = st.gather_fixed(d_out[slot], stitched[k & 1] if rank == 0 else None, async_op=True)
+            pending[k & 1] = gather_async(d_out[slot], stitched[k & 1] if rank == 0 else None)
         else:
             launch(slot)
 
@@ -271,10 +297,10 @@ def main():
         # degrades to shard-only (and says so) instead of producing no line at all.
         try:
             step(0); step(1); drain(); torch.cuda.synchronize(dev)
-            ok = torch.tensor([1], dtype=torch.int32, device=dev)
+            ok = torch.tensor([1], dtype=torch.int32, device=red_dev)
         except Exception as e:          # noqa: BLE001
             gather_error = f"{type(e).__name__}: {e}"[:300]
-            ok = torch.tensor([0], dtype=torch.int32, device=dev)
+            ok = torch.tensor([0], dtype=torch.int32, device=red_dev)
             pending[0] = pending[1] = None
         try:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -302,7 +328,7 @@ def main():
 
     shard_only = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if gather:
@@ -312,7 +338,7 @@ def main():
             for k in range(args.steps):
                 launch(k % R)
             barrier()
-            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             shard_only = float(t.item())
 
@@ -352,6 +378,8 @@ def main():
                          "algorithmic_bytes_per_launch": set_points * ALGO_BYTES_PER_POINT,
                          "timing": "hipEvent pair on the launch stream around the timed region / steps"},
         }
+        if debug_gloo:
+            out["debug"] = "gloo control-flow test: all ranks on one GPU, host-staged gathers; numbers are meaningless"
         if gather_error:
             out["gather_error"] = gather_error
             out["config"]["gather_to_rank0"] = False

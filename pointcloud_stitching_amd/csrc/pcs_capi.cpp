@@ -34,6 +34,7 @@ struct pcs_ctx {
     uint32_t*                       d_stream_base = nullptr;   // n_streams + 1 (kept points per stream)
     uint32_t*                       d_arrive = nullptr;        // scan arrival counter (self-resetting)
     int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
+    int32_t*                        d_static_counts = nullptr; // n_streams + 1: ceil(n/downsample) per stream, total
     // single-pass compaction state (pcs_fused_compact_kernel)
     unsigned long long*             d_ticket = nullptr;        // never reset
     unsigned long long              tickets_issued = 0;
@@ -404,18 +405,9 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             HIPCHK(c, launch_fused_emit(c->d_params, s0, nl, mp, c->flags, c->downsample, sel, fp, c->d_tile_prefix,
                                         c->d_stream_base, d_payload, c->stream));
     }
-    if (!pred && d_counts) {
-        // counts are host-known; give the caller the same table the scan would have written
-        std::vector<int32_t> h(c->n_streams + 1);
-        int64_t tot = 0;
-        for (int s = 0; s < c->n_streams; s++) {
-            h[s] = (int32_t)((c->h_params[s].n_points + c->downsample - 1) / c->downsample);
-            tot += h[s];
-        }
-        h[c->n_streams] = (int32_t)tot;
-        HIPCHK(c, hipMemcpyAsync(d_counts, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // h goes out of scope
-    }
+    if (!pred && d_counts)     // counts are known from the configuration: a device-to-device copy, no host sync
+        HIPCHK(c, hipMemcpyAsync(d_counts, c->d_static_counts, sizeof(int32_t) * (c->n_streams + 1),
+                                 hipMemcpyDeviceToDevice, c->stream));
     if (c->kernel_timing) {
         HIPCHK(c, hipEventRecord(ev.second, c->stream));
         c->ev_pool.push_back(ev);
@@ -568,6 +560,17 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     CREATE_CHK(hipMalloc((void**)&c->d_tile_prefix, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_stream_base, sizeof(uint32_t) * (c->n_streams + 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_counts, sizeof(int32_t) * (c->n_streams + 1)));
+    {
+        std::vector<int32_t> hc(c->n_streams + 1);
+        int64_t tot = 0;
+        for (int s = 0; s < c->n_streams; s++) {
+            hc[s] = (int32_t)((c->h_params[s].n_points + c->downsample - 1) / c->downsample);
+            tot += hc[s];
+        }
+        hc[c->n_streams] = (int32_t)tot;
+        CREATE_CHK(hipMalloc((void**)&c->d_static_counts, sizeof(int32_t) * hc.size()));
+        CREATE_CHK(hipMemcpy(c->d_static_counts, hc.data(), sizeof(int32_t) * hc.size(), hipMemcpyHostToDevice));
+    }
     CREATE_CHK(hipMalloc((void**)&c->d_arrive, sizeof(uint32_t)));
     CREATE_CHK(hipMemset(c->d_arrive, 0, sizeof(uint32_t)));
     {   // device certificate for CertMath::div_const: all 2^32 numerators, once per distinct raster dimension
@@ -617,7 +620,7 @@ void pcs_destroy(pcs_ctx* c)
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
     if (c->s_slab) (void)hipFree(c->s_slab);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -680,9 +683,7 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer_device(pcs_ctx* c, int stream, const fl
             HIPCHK(c, launch_pack_dense(c->d_params, stream, vp, d_pc_buffer, c->stream));
         else
             HIPCHK(c, launch_pack_emit(c->d_params, stream, vp, 0u, nullptr, d_pc_buffer, c->stream));
-        if (d_out_points)
-            HIPCHK(c, hipMemcpyAsync(d_out_points, &vp.n_points, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        if (d_out_points) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (d_out_points) HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)d_out_points, n_points, 1, c->stream));
         return PCS_OK;
     }
     const uint32_t tiles = std::max<uint32_t>(tiles_of((uint32_t)n_points), 1);

@@ -1058,12 +1058,6 @@ inline dim3 tile_grid(uint32_t max_points, int n_launch)
 // Launchers
 // ------------------------------------------------------------------------------------------------
 
-#define PCS_DISPATCH_DIST_UNUSED(DD, CD, ...)                         \
-    do {                                                       \
-        if (DD) { if (CD) { __VA_ARGS__(true, true); } else { __VA_ARGS__(true, false); } } \
-        else    { if (CD) { __VA_ARGS__(false, true); } else { __VA_ARGS__(false, false); } } \
-    } while (0)
-
 hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                               bool any_ddist, bool any_cdist, MathSel math, const FramePtrs& fp, int16_t* d_payload,
                               hipStream_t st)
