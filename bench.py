@@ -249,12 +249,13 @@ def main():
         if not debug_gloo:
             return st.gather_fixed(src, dst, async_op=True)
         torch.cuda.synchronize(dev)                       # script test only: stage through host memory
-        host = src.cpu()
+        host = src.view(torch.uint8).cpu()
         outs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
         dist.gather(host, outs, dst=0)
         if rank == 0:
+            db = dst.view(torch.uint8)
             for r, o in enumerate(outs):
-                dst[r * host.numel():(r + 1) * host.numel()].copy_(o)
+                db[r * host.numel():(r + 1) * host.numel()].copy_(o)
         return _Done()
 
     def step(k):
