@@ -516,3 +516,16 @@ def test_drop_invalid_with_degenerate_depth_scale(oracle):
     want, wcounts = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
     assert counts == wcounts
     assert_same(got, want)
+
+
+def test_large_raster_multi_chunk_scan_and_dense(oracle):
+    """2048x1100 = 1100 tiles per stream: more than one 1024-wide chunk in the per-stream scan; also the dense
+    path on a raster larger than the reference's BUF_SIZE could ever hold."""
+    cfgs = [S.synth_stream_config(2048, 1100, 0), S.synth_stream_config(2048, 1100, 1)]
+    depth = [S.synth_depth(2048, 1100, i) for i in range(2)]
+    color = [S.synth_color(2048, 1100, i) for i in range(2)]
+    for flags in (0, FLAG_DROP_INVALID, FLAG_CUTOFF):
+        got, counts = run_fused(cfgs, depth, color, flags)
+        want, wcounts = oracle.process_frames(cfgs, depth, color, flags)
+        assert counts == wcounts
+        assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()

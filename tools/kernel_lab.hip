@@ -164,6 +164,81 @@ void lab_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n
     for (uint32_t j = i; j < n_write16; j += gridDim.x * 256u) { dst[j] = v; }
 }
 
+
+// Skeleton with a DEPENDENT gather: the colour address is derived from the depth value (a few pixels of
+// shift), so the two loads form the same latency chain as in the product kernel. Isolates the cost of the
+// dependency from the cost of the arithmetic.
+__global__ __launch_bounds__(kBlockThreads)
+void lab_skeleton_dependent(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ uint4 stage[kDenseStageBytes / 16];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    const uint32_t i0 = tile0 + threadIdx.x * 8;
+    const uint4 dv = *reinterpret_cast<const uint4*>(fp.depth[s] + i0);
+    const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+    uint32_t w[20];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+        const uint32_t shift = (d >> 7) & 31u;                       // 0..31 pixels, like the parallax shift
+        uint32_t c;
+        __builtin_memcpy(&c, fp.color[s] + min((i0 + k + shift) * 3u, P.color_bytes - 4u), 4);
+        w[(k * 5) / 2] = d ^ c;
+        w[(k * 5) / 2 + 1] = c + k;
+        if ((k & 1) == 0) w[(k * 5) / 2 + 2] = d;
+    }
+    uint4* mine = stage + threadIdx.x * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) mine[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    __syncthreads();
+    store_staged(reinterpret_cast<const uint8_t*>(stage), 0u, kTilePoints * PCS_POINT_BYTES,
+                 payload_bytes + ((size_t)P.out_base + tile0) * PCS_POINT_BYTES);
+}
+
+// Product arithmetic, two tiles per workgroup: the second tile's depth/LUT loads are issued before the
+// first tile is computed (software prefetch), and its arithmetic overlaps the first tile's stores.
+template <class Mth>
+__global__ __launch_bounds__(kBlockThreads)
+void lab_fused_dense_2tiles(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ uint4 stage[2][kDenseStageBytes / 16];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint8_t* __restrict__ color = fp.color[s];
+    uint8_t* out = payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES;
+    DepthSource<false, false, Mth> src{fp.depth[s]};
+    PointIn pa[8], pb[8];
+    const uint32_t tA = (blockIdx.x * 2u) * kTilePoints, tB = tA + kTilePoints;
+    if (tA >= n) return;
+    src.load8(P, tA + threadIdx.x * 8, n, pa, nullptr);
+    const bool hasB = tB < n;
+    if (hasB) src.load8(P, tB + threadIdx.x * 8, n, pb, nullptr);
+    auto emit = [&](PointIn (&p)[8], uint4* st) {
+        uint32_t w[20];
+        LazyCvt lazy;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const Record a = make_record(P, color, p[k], lazy);
+            const Record b = make_record(P, color, p[k + 1], lazy);
+            uint32_t* o = w + (k >> 1) * 5;
+            o[0] = a.xy; o[1] = a.zc; o[2] = (a.b & 0xFFFFu) | (b.xy << 16); o[3] = (b.xy >> 16) | (b.zc << 16); o[4] = (b.zc >> 16) | (b.b << 16);
+        }
+        uint4* mine = st + threadIdx.x * 5;
+#pragma unroll
+        for (int k = 0; k < 5; k++) mine[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    };
+    emit(pa, stage[0]);
+    if (hasB) emit(pb, stage[1]);
+    __syncthreads();
+    store_staged(reinterpret_cast<const uint8_t*>(stage[0]), 0u, min(kTilePoints, n - tA) * PCS_POINT_BYTES, out + (size_t)tA * PCS_POINT_BYTES);
+    if (hasB) store_staged(reinterpret_cast<const uint8_t*>(stage[1]), 0u, min(kTilePoints, n - tB) * PCS_POINT_BYTES, out + (size_t)tB * PCS_POINT_BYTES);
+}
+
 // ---- exhaustive / fuzz verification kernels ---------------------------------------------------
 __global__ void verify_div_const(float c, float rc, unsigned long long* bad, uint32_t* first_bad)
 {
@@ -339,6 +414,11 @@ int main(int argc, char** argv)
         time_it("cert+identR, lb(256,4)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 4>)));
         time_it("sloppy (inexact bound)", LAUNCH((lab::lab_fused_dense<lab::SloppyMath>)));
         time_it("memory skeleton", LAUNCH(lab::lab_memory_skeleton));
+        time_it("skeleton, dependent gather", LAUNCH(lab::lab_skeleton_dependent));
+        {
+            const dim3 g2(((N + 2047) / 2048 + 1) / 2, S);
+            time_it("cert+identR, 2 tiles/WG", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_2tiles<CertMath<true>>), g2, block, 0, st, dp, ring[r], o); });
+        }
     }
     time_it("skeleton nt-store", LAUNCH((lab::lab_skeleton_v<1>)));
     {   // plain copy with the same read/write volume, grid sized so each lane reads 16 B and writes 2x16 B
@@ -367,6 +447,10 @@ int main(int argc, char** argv)
         CK(hipDeviceSynchronize());
         const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / iters;
         printf("ieee, 1 stream, host clock   %8.2f us/launch\n", us);
+    }
+    {
+        const dim3 g2(((N + 2047) / 2048 + 1) / 2, S);
+        count_diff("cert+identR, 2 tiles/WG", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_2tiles<CertMath<true>>), g2, block, 0, st, dp, ring[r], o); });
     }
     count_diff("cert (product)", LAUNCH((lab::lab_fused_dense<CertMath<false>>)));
     count_diff("cert + identity R (product)", LAUNCH((lab::lab_fused_dense<CertMath<true>>)));
