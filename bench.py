@@ -404,15 +404,24 @@ def main():
         if world == 1 and not args.no_host_api:
             # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
             # pageable numpy memory like a caller of the reference's function would have. Never `value`.
-            reps = 5
-            ctx.process_frames(host0[0], host0[1])
-            th = time.perf_counter()
-            for _ in range(reps):
-                ctx.process_frames(host0[0], host0[1])
-            th = (time.perf_counter() - th) / reps
+            def time_host(dep, col, outbuf, reps=5):
+                ctx.process_frames(dep, col, out=outbuf)
+                t0h = time.perf_counter()
+                for _ in range(reps):
+                    ctx.process_frames(dep, col, out=outbuf)
+                return (time.perf_counter() - t0h) / reps
+            th = time_host(host0[0], host0[1], None)
+            pd = [ctx.host_array(d.shape, np.uint16) for d in host0[0]]
+            pc = [ctx.host_array(c.shape, np.uint8) for c in host0[1]]
+            for a, b in zip(pd + pc, host0[0] + host0[1]):
+                a[...] = b
+            po = ctx.host_array((2 + payload_shorts,), np.int16)
+            tp = time_host(pd, pc, po)
             out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
-                               "unit": "Mpoints/s", "note": "pcs_process_frames with pageable host buffers: H2D + kernel + D2H, "
-                               "synchronous; bounded by the host link, not by the kernel"}
+                               "pinned_ms_per_step": round(tp * 1e3, 3), "pinned_value": round(set_points / tp / 1e6, 1),
+                               "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous: H2D (36.9 MB) + kernel + D2H (73.7 MB) per "
+                               "frame-set, with pageable host buffers and with buffers from pcs_host_malloc; bounded by the host link, "
+                               "not by the kernel"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -216,6 +216,12 @@ int   pcs_timer_elapsed_ms(pcs_ctx* ctx, float* ms);    /* synchronises on the e
 int   pcs_kernel_timing(pcs_ctx* ctx, int enable);
 int   pcs_kernel_times_ms(pcs_ctx* ctx, float* ms, int capacity, int* n);
 
+/* Page-locked host memory for the buffers that cross PCIe every frame (the reference mallocs its `buffer`
+ * once, src/pcs-camera-optimized.cpp:157 — allocating it here instead lets the D2H of the payload run at
+ * link speed instead of through the runtime's pageable bounce buffers). Plain host pointers otherwise. */
+int   pcs_host_malloc(pcs_ctx* ctx, void** h_ptr, size_t bytes);
+int   pcs_host_free(pcs_ctx* ctx, void* h_ptr);
+
 /* Thin device-memory helpers so a C/C++ host needs no HIP headers. */
 int   pcs_device_malloc(pcs_ctx* ctx, void** d_ptr, size_t bytes);
 int   pcs_device_free(pcs_ctx* ctx, void* d_ptr);

@@ -66,6 +66,9 @@ class PcsContext:
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
+            for p in getattr(self, "_pinned", []):
+                self._lib.pcs_host_free(self._h, p)
+            self._pinned = []
             self._lib.pcs_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -137,7 +140,7 @@ class PcsContext:
 
     # -- fused ---------------------------------------------------------------------------------
     def process_frames(self, depth: Sequence[np.ndarray], color: Sequence[np.ndarray],
-                       write_header: bool = True) -> Tuple[np.ndarray, List[int], int]:
+                       write_header: bool = True, out: Optional[np.ndarray] = None) -> Tuple[np.ndarray, List[int], int]:
         """Deproject + transform + pack every stream; returns (stitched int16 buffer incl. 2 header
         shorts, per-stream point counts, payload bytes)."""
         if len(depth) != self.n_streams or len(color) != self.n_streams:
@@ -151,7 +154,9 @@ class PcsContext:
                 raise ValueError(f"stream {s}: colour raster smaller than stride*height")
         dp = (C.c_void_p * self.n_streams)(*[_ptr(x) for x in d])
         cp = (C.c_void_p * self.n_streams)(*[_ptr(x) for x in c])
-        buf = np.zeros(HEADER_SHORTS + self.max_payload_shorts, np.int16)
+        buf = out if out is not None else np.zeros(HEADER_SHORTS + self.max_payload_shorts, np.int16)
+        if buf.dtype != np.int16 or not buf.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a contiguous int16 array")
         counts = (C.c_int * self.n_streams)()
         size = C.c_int(0)
         self._check(self._lib.pcs_process_frames(self._h, dp, cp, _ptr(buf), buf.size, int(write_header),
@@ -230,6 +235,18 @@ class PcsContext:
         n = C.c_int(0)
         self._check(self._lib.pcs_kernel_times_ms(self._h, arr, capacity, C.byref(n)))
         return np.array(arr[:min(n.value, capacity)], dtype=np.float32)
+
+    def host_array(self, shape, dtype) -> np.ndarray:
+        """A numpy array in page-locked host memory (freed with the context). Use it for the rasters and the
+        stitched buffer handed to process_frames so the PCIe copies run at link speed."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.pcs_host_malloc(self._h, C.byref(p), max(n, 16)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        buf = (C.c_uint8 * max(n, 16)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
     def device_malloc(self, nbytes: int) -> int:
         p = C.c_void_p()

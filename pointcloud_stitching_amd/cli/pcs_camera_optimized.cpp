@@ -195,7 +195,10 @@ int main(int argc, char** argv)
     if (rc != PCS_OK) { std::cerr << "pcs_create: " << pcs_strerror(rc) << ": " << pcs_last_error(nullptr) << std::endl; return 1; }
 
     const size_t buf_shorts = PCS_HEADER_SHORTS + pcs_max_payload_shorts(ctx);
-    short* buffer = (short*)malloc(sizeof(short) * buf_shorts);            // the reference mallocs BUF_SIZE shorts (:157)
+    short* buffer = nullptr;                                               // the reference mallocs BUF_SIZE shorts (:157);
+    if (pcs_host_malloc(ctx, (void**)&buffer, sizeof(short) * buf_shorts) != PCS_OK) {   // page-locked: D2H at link speed
+        std::cerr << pcs_last_error(ctx) << std::endl; return 1;
+    }
     std::vector<const uint16_t*> dptr(n_streams);
     std::vector<const uint8_t*> cptr(n_streams);
     std::vector<int> counts(n_streams);
@@ -267,7 +270,7 @@ int main(int argc, char** argv)
         FILE* f = fopen(dump_path, "wb");
         if (f) { fwrite(buffer, 1, (size_t)buff_size + 4, f); fclose(f); }
     }
-    free(buffer);
+    pcs_host_free(ctx, buffer);
     pcs_destroy(ctx);
     return 0;
 }

@@ -996,6 +996,24 @@ int pcs_kernel_times_ms(pcs_ctx* c, float* ms, int capacity, int* n)
     return PCS_OK;
 }
 
+int pcs_host_malloc(pcs_ctx* c, void** h_ptr, size_t bytes)
+{
+    if (!c || !h_ptr) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    hipError_t e = hipHostMalloc(h_ptr, std::max<size_t>(bytes, 16), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return PCS_OK;
+}
+
+int pcs_host_free(pcs_ctx* c, void* h_ptr)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipHostFree(h_ptr));
+    return PCS_OK;
+}
+
 int pcs_device_malloc(pcs_ctx* c, void** d_ptr, size_t bytes)
 {
     if (!c || !d_ptr) return PCS_ERR_INVALID_ARG;
