@@ -365,9 +365,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 affine -> int16 records (u16 depth, u8 colour)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} synthetic {W}x{H} Z16+RGB8 streams per GPU, batched fused kernel, "
                                    f"one extrinsic per stream (BASELINE.json configs[2])",
+                       "arithmetic": "f32 deprojection + affine (bit-exact vs the -m path), u16 depth in, u8 colour in, int16 records out",
                        "streams_per_gpu": S, "width": W, "height": H, "points_per_step_per_gpu": set_points,
                        "ring_frame_sets": R, "ring_mbytes": round(ring_bytes / 1e6, 1),
                        "gather_to_rank0": bool(gather), "parallelism": f"streams sharded {S}/GPU x {world}"},

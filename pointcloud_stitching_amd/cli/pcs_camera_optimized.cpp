@@ -20,7 +20,6 @@
 #include <vector>
 
 #include <getopt.h>
-#include <netinet/in.h>
 #include <signal.h>
 #include <sys/socket.h>
 #include <unistd.h>
@@ -81,22 +80,16 @@ static void parseArgs(int argc, char** argv)
     }
 }
 
-// Same socket set-up as the reference (:75-105): bind, listen, accept one client.
-static void initSocket(int p)
+// One consumer per edge server, as in the reference (:75-105): listen on the port, take the first client.
+static bool openServer(int p)
 {
-    struct sockaddr_in serv_addr;
-    memset(&serv_addr, 0, sizeof(serv_addr));
-    serv_addr.sin_family = AF_INET;
-    serv_addr.sin_addr.s_addr = INADDR_ANY;
-    serv_addr.sin_port = htons(p);
-    if ((sockfd = socket(AF_INET, SOCK_STREAM, IPPROTO_TCP)) < 0) { std::cerr << "\nSocket fd not received." << std::endl; exit(EXIT_FAILURE); }
-    int one = 1;
-    setsockopt(sockfd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-    if (bind(sockfd, (struct sockaddr*)&serv_addr, sizeof(serv_addr)) < 0) { std::cerr << "\nBind failed" << std::endl; exit(EXIT_FAILURE); }
-    if (listen(sockfd, 3) < 0) { std::cerr << "\nListen failed" << std::endl; exit(EXIT_FAILURE); }
+    sockfd = pcs_wire::listen_on(p);
+    if (sockfd < 0) { std::cerr << "\ncannot listen on port " << p << std::endl; return false; }
     std::cout << "Waiting for client..." << std::endl;
-    if ((client_sock = accept(sockfd, NULL, NULL)) < 0) { std::cerr << "\nConnection failed" << std::endl; exit(EXIT_FAILURE); }
+    client_sock = ::accept(sockfd, nullptr, nullptr);
+    if (client_sock < 0) { std::cerr << "\nConnection failed" << std::endl; return false; }
     std::cout << "Established connection with client_sock: " << client_sock << std::endl;
+    return true;
 }
 
 static void sigintHandler(int) { std::cout << "\n Exiting \n " << std::endl; exit(0); }
@@ -207,7 +200,7 @@ int main(int argc, char** argv)
     int i = 0, buff_size = 0;
     double duration_sum = 0, buff_size_sum = 0;
     size_t points_in = 0;
-    if (send_buffer) initSocket(port);
+    if (send_buffer && !openServer(port)) return 1;
 
     while (i < max_frames && src.next(i)) {
         i++;
