@@ -50,21 +50,32 @@ struct LoadPoint {
     }
 };
 
-__device__ __forceinline__ unsigned int voxel_index(int v, int leaf)
+// Bits one axis needs: voxel indices run over 0 .. floor(32767/leaf) + ceil(32768/leaf) <= 65536/leaf + 1.
+// Packing the three axes into 3*bits (instead of a fixed 51) saves whole radix passes for realistic leaves.
+inline unsigned int axis_bits(int leaf)
+{
+    const unsigned int max_index = 32767u / (unsigned)leaf + (32768u + (unsigned)leaf - 1u) / (unsigned)leaf;
+    unsigned int b = 1;
+    while ((1u << b) <= max_index) b++;
+    return b;
+}
+
+__device__ __forceinline__ unsigned int voxel_index_packed(int v, int leaf, unsigned int bias)
 {
     const int q = v >= 0 ? v / leaf : -((-v + leaf - 1) / leaf);     // floor division
-    return (unsigned int)(q + 32768);                                // |q| <= 32768 -> 0..65536
+    return (unsigned int)(q + (int)bias);                            // bias = ceil(32768/leaf) -> non-negative
 }
 
 __global__ __launch_bounds__(256)
-void pcs_voxel_keys_kernel(const int16_t* __restrict__ payload, unsigned int n, int leaf,
-                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx)
+void pcs_voxel_keys_kernel(const int16_t* __restrict__ payload, unsigned int n, int leaf, unsigned int bits,
+                           unsigned int bias, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx)
 {
     const unsigned int i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
-    const unsigned long long kx = voxel_index(p[0], leaf), ky = voxel_index(p[1], leaf), kz = voxel_index(p[2], leaf);
-    keys[i] = (kz << 34) | (ky << 17) | kx;                          // 17 bits per axis, z major, x fastest
+    const unsigned long long kx = voxel_index_packed(p[0], leaf, bias), ky = voxel_index_packed(p[1], leaf, bias),
+                             kz = voxel_index_packed(p[2], leaf, bias);
+    keys[i] = (kz << (2 * bits)) | (ky << bits) | kx;                // z major, x fastest; order == (z,y,x) voxel order
     idx[i] = i;
 }
 
@@ -124,12 +135,14 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
     unsigned int* nvox = (unsigned int*)take(256);
     void* tmp = take(sort_tmp > reduce_tmp ? sort_tmp : reduce_tmp);
 
+    const unsigned int bits = axis_bits(leaf_mm);
+    const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
     hipLaunchKernelGGL(pcs_voxel_keys_kernel, dim3((n_points + 255) / 256), dim3(256), 0, st, d_payload, n_points, leaf_mm,
-                       keys_a, idx_a);
+                       bits, bias, keys_a, idx_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t s1 = sort_tmp;
-    e = rocprim::radix_sort_pairs(tmp, s1, keys_a, keys_b, idx_a, idx_b, n, 0u, 51u, st);
+    e = rocprim::radix_sort_pairs(tmp, s1, keys_a, keys_b, idx_a, idx_b, n, 0u, 3u * bits, st);
     if (e != hipSuccess) return e;
     auto values = rocprim::make_transform_iterator(idx_b, LoadPoint{d_payload});
     size_t s2 = reduce_tmp;
