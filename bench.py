@@ -351,7 +351,8 @@ def main():
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/traffic.json (" + tj.get("tag", "?") + ")"
         except (OSError, ValueError, KeyError):
             traffic = None
-    policy = {0: "ieee", 1: "certified", 2: "certified+identityR"}[min(ctx.stream_math(s) for s in range(S))]
+    policy = {0: "ieee", 1: "certified", 2: "certified+identityR", 3: "certified+noOverflow",
+              4: "certified+identityR+noOverflow"}[min(ctx.stream_math(s) for s in range(S))]
 
     if rank == 0:
         total_points = set_points * world * args.steps

@@ -131,7 +131,8 @@ const char*  pcs_last_error(const pcs_ctx* ctx);     /* detail of the last failu
 int          pcs_set_cam_to_world(pcs_ctx* ctx, int stream, const float m16[16]);
 
 /* Which arithmetic the fused kernels use for `stream`: 0 = IEEE expansion, 1 = certified reduced-instruction
- * form, 2 = certified + identity depth->colour rotation shortcut (DESIGN.md "Certified arithmetic"). The
+ * form, 2 = certified + identity depth->colour rotation shortcut; 3 / 4 = 1 / 2 plus the no-overflow certificate
+ * (conversions cannot reach 2^31, so no running maximum is kept) (DESIGN.md "Certified arithmetic"). The
  * results are bit-identical; this is a diagnostic. */
 int          pcs_stream_math(const pcs_ctx* ctx, int stream);
 

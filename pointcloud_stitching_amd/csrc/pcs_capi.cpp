@@ -19,6 +19,13 @@
 
 using namespace pcs;
 
+struct Certificate {
+    bool   fast = false, ident_r = false;
+    double xb = 0, yb = 0, zb = 0;      // |X|,|Y|,|Z| upper bounds over valid depths
+    double a_max[3] = {0, 0, 0};        // |P_i| upper bounds
+    double p2_low = 0;                  // P2 lower bound (> 0) over valid depths
+};
+
 struct pcs_ctx {
     int                             device = 0;
     int                             n_streams = 0;
@@ -45,7 +52,8 @@ struct pcs_ctx {
     bool                            single_pass_ok = true;     // cleared if a look-back ever timed out
     bool                            dense_ok = false;          // every stream has n % 8 == 0
     bool                            any_ddist = false, any_cdist = false;
-    std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 certified + identity R
+    std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 + identity R, 3/4 = 1/2 + no-overflow
+    std::vector<Certificate>        cert;
     uint32_t                        max_points = 0;
     size_t                          max_payload_points = 0;
 
@@ -175,7 +183,6 @@ void fill_params(const pcs_stream_config& s, StreamParams& p)
 //            non-zero P_i is >= 2^-24 * (smallest non-zero addend magnitude), with addends
 //            |R_i0| xmin, |R_i3| ymin, |R_i6| zmin, |t_i| (xmin = zmin * smallest non-zero |mx|, ...).
 // ------------------------------------------------------------------------------------------------
-struct Certificate { bool fast = false; bool ident_r = false; };
 
 Certificate certify_stream(const pcs_stream_config& s, const std::vector<float>& mx, const std::vector<float>& my)
 {
@@ -207,6 +214,7 @@ Certificate certify_stream(const pcs_stream_config& s, const std::vector<float>&
         const double ti = std::fabs((double)t[i]);
         const double sigma = r0 * mxmax + r3 * mymax + r6;
         if (!(sigma * zmax + ti < lim_hi * 0.5)) return c;
+        c.a_max[i] = (sigma * zmax + ti) * infl;
         // smallest non-zero addend (an addend whose coefficient is zero is an exact zero and drops out)
         double small = INFINITY;
         if (r0 > 0 && std::isfinite(xmin)) small = std::min(small, r0 * xmin);
@@ -224,9 +232,11 @@ Certificate certify_stream(const pcs_stream_config& s, const std::vector<float>&
             if (!(kp > 0)) return c;
             const double low = kp * zmin + (double)t[2] - slack * ti;
             if (!(low >= lim_den)) return c;
+            c.p2_low = low;
         }
     }
     c.fast = true;
+    c.xb = zmax * mxmax; c.yb = zmax * mymax; c.zb = zmax;
     // identity shortcut: R == I exactly, translation entries are not negative zero
     static const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     bool ident = true;
@@ -237,6 +247,29 @@ Certificate certify_stream(const pcs_stream_config& s, const std::vector<float>&
     for (int k = 0; k < 3; k++) { uint32_t a; std::memcpy(&a, &t[k], 4); if (a == 0x80000000u) ident = false; }
     c.ident_r = ident;
     return c;
+}
+
+// Second certificate, on top of `fast`: no float the pack converts to an integer can reach 2^31, so the
+// kernels may use the saturating hardware convert without keeping a running maximum.
+//   world millimetres  |a_r| <= (|M_r0| Xb + |M_r1| Yb + |M_r2| Zb + |M_r3|) * 1000
+//   colour column/row  |xf|  <= (A0 / P2low) * |fx_c| + |ppx_c| + 0.5      (no colour distortion)
+// each required < 2^30. Depends on cam_to_world, so it is re-evaluated by pcs_set_cam_to_world.
+bool certify_no_overflow(const pcs_stream_config& s, const Certificate& c, const float* M)
+{
+    if (!c.fast || !(c.p2_low > 0)) return false;
+    if (s.color.model != PCS_DISTORTION_NONE && coeffs_nonzero(s.color)) return false;
+    const double lim = std::ldexp(1.0, 30), infl = 1.0 + std::ldexp(1.0, -18);
+    for (int r = 0; r < 3; r++) {
+        double a = 0;
+        for (int k = 0; k < 4; k++) if (!std::isfinite(M[4 * r + k])) return false;
+        a = std::fabs((double)M[4 * r]) * c.xb + std::fabs((double)M[4 * r + 1]) * c.yb + std::fabs((double)M[4 * r + 2]) * c.zb +
+            std::fabs((double)M[4 * r + 3]);
+        if (!(a * 1000.0 * infl < lim)) return false;
+    }
+    const double x = c.a_max[0] / c.p2_low * infl, y = c.a_max[1] / c.p2_low * infl;
+    const double xf = x * std::fabs((double)s.color.fx) * infl + std::fabs((double)s.color.ppx) + 1.0;
+    const double yf = y * std::fabs((double)s.color.fy) * infl + std::fabs((double)s.color.ppy) + 1.0;
+    return xf * infl < lim && yf * infl < lim;
 }
 
 // floor(i / W) == umulhi(i, magic) >> shift for every i < 2^31 (Granlund-Montgomery round-up method,
@@ -352,11 +385,11 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             const int nl = std::min(kLaunchStreams, c->n_streams - s0);
             FramePtrs fp{};
             uint32_t tiles = 0;
-            int m = 2;
+            int m = 1;
             for (int k = 0; k < nl; k++) {
                 fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
                 tiles += tiles_of(c->h_params[s0 + k].n_points);
-                m = std::min(m, c->math[s0 + k]);
+                m = std::min(m, c->h_params[s0 + k].cert_fast);
             }
             CompactLaunch cl{};
             cl.d_ticket = c->d_ticket; cl.ticket_base = c->tickets_issued;
@@ -391,14 +424,17 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         FramePtrs fp{};
         uint32_t mp = 0;
         for (int k = 0; k < nl; k++) { fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k]; mp = std::max(mp, c->h_params[s0 + k].n_points); }
-        int m = 2;                                   // AND over the streams of this launch
+        bool fast = true, ident = true, noovf = true;    // AND over the streams of this launch
         bool dd = false, cd = false;
         for (int k = 0; k < nl; k++) {
-            m = std::min(m, c->math[s0 + k]);
-            dd |= c->h_params[s0 + k].ddist != 0;
-            cd |= c->h_params[s0 + k].cdist != 0;
+            const StreamParams& q = c->h_params[s0 + k];
+            fast &= q.cert_fast != 0; ident &= q.ident_r != 0; noovf &= q.no_overflow != 0;
+            dd |= q.ddist != 0;
+            cd |= q.cdist != 0;
         }
-        const MathSel sel = m == 2 ? MathSel::CertIdentR : (m == 1 ? MathSel::Cert : MathSel::Ieee);
+        const MathSel sel = !fast ? MathSel::Ieee
+                          : noovf ? (ident ? MathSel::CertIdentRNoOvf : MathSel::CertNoOvf)
+                                  : (ident ? MathSel::CertIdentR : MathSel::Cert);
         if (dense)
             HIPCHK(c, launch_fused_dense(c->d_params, s0, nl, mp, dd, cd, sel, fp, d_payload, c->stream));
         else
@@ -544,6 +580,8 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         const Certificate cert = (c->flags & PCS_FLAG_FORCE_IEEE) ? Certificate{} : certify_stream(c->cfg[s], mx, my);
         p.cert_fast = cert.fast ? 1 : 0;
         p.ident_r = (cert.fast && cert.ident_r) ? 1 : 0;
+        p.no_overflow = certify_no_overflow(c->cfg[s], cert, c->cfg[s].cam_to_world) ? 1 : 0;
+        c->cert.push_back(cert);
         row_magic((uint32_t)p.W, (uint32_t)p.H, p.w_magic, p.w_shift);
         float *dmx = nullptr, *dmy = nullptr;
         CREATE_CHK(hipMalloc((void**)&dmx, sizeof(float) * ((size_t)p.W + 8)));
@@ -596,7 +634,7 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
             bool okw = false, okh = false;
             CREATE_CHK(verified(p.cW, okw));
             CREATE_CHK(verified(p.cH, okh));
-            if (!(okw && okh)) { p.cert_fast = 0; p.ident_r = 0; }
+            if (!(okw && okh)) { p.cert_fast = 0; p.ident_r = 0; p.no_overflow = 0; }
         }
         if (d_bad) (void)hipFree(d_bad);
     }
@@ -604,8 +642,10 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     // one on MI355X: opt-in for experiments only.
     { const char* e = getenv("PCS_COMPACT_SINGLE_PASS"); c->single_pass_ok = e && e[0] == '1'; }
     c->math.resize(c->n_streams);
-    for (int s = 0; s < c->n_streams; s++)
-        c->math[s] = c->h_params[s].cert_fast ? (c->h_params[s].ident_r ? 2 : 1) : 0;
+    for (int s = 0; s < c->n_streams; s++) {
+        const StreamParams& q = c->h_params[s];
+        c->math[s] = q.cert_fast ? ((q.ident_r ? 2 : 1) + (q.no_overflow ? 2 : 0)) : 0;
+    }
     CREATE_CHK(hipMemcpy(c->d_params, c->h_params.data(), sizeof(StreamParams) * c->n_streams, hipMemcpyHostToDevice));
 #undef CREATE_CHK
     *out = c;
@@ -638,7 +678,10 @@ int pcs_set_cam_to_world(pcs_ctx* c, int stream, const float m16[16])
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(c->cfg[stream].cam_to_world, m16, sizeof(float) * 16);
-    for (int k = 0; k < 12; k++) c->h_params[stream].M[k] = m16[k];
+    StreamParams& q = c->h_params[stream];
+    for (int k = 0; k < 12; k++) q.M[k] = m16[k];
+    q.no_overflow = (q.cert_fast && certify_no_overflow(c->cfg[stream], c->cert[stream], m16)) ? 1 : 0;
+    c->math[stream] = q.cert_fast ? ((q.ident_r ? 2 : 1) + (q.no_overflow ? 2 : 0)) : 0;
     return upload_params(c);
 }
 

@@ -44,6 +44,7 @@ struct alignas(16) StreamParams {
     uint32_t w_magic, w_shift; // floor(i / W) == umulhi(i, w_magic) >> w_shift for i < 2^31 (0 = use '/')
     int32_t  cert_fast;      // host+device certified for CertMath (see pcs_capi.cpp)
     int32_t  ident_r;        // depth->colour rotation is exactly I, translation has no -0
+    int32_t  no_overflow;    // certified: no converted value (world mm, colour column/row) can reach 2^31
     int32_t  z_zero_iff_d_zero; // depth_scale finite and depth_scale*1 != 0: (z == 0) == (d == 0)
     const float* mx;         // [W]  (c - ppx) / fx   — IEEE division done once on the host
     const float* my;         // [H]  (r - ppy) / fy
@@ -63,7 +64,7 @@ struct VertexPtrs {          // a2 twin: one stream per launch
 };
 
 // Which arithmetic policy a launch may use (the AND over the streams of the launch).
-enum class MathSel { Ieee = 0, Cert = 1, CertIdentR = 2 };
+enum class MathSel { Ieee = 0, Cert = 1, CertIdentR = 2, CertNoOvf = 3, CertIdentRNoOvf = 4 };
 
 // Launchers (defined in pcs_kernels.hip). All enqueue on `st` and return the hipError of the launch.
 hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,

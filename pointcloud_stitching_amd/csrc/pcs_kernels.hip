@@ -74,31 +74,58 @@ struct ExactCvt {
     {
         return min(max(cvtt_x86(f), 0), dim_m1);
     }
-    __device__ __forceinline__ bool overflowed() const { return false; }
+    // One dword covers R,G,B. Never read past the raster: slide the window back at the very end of it and
+    // shift the wanted bytes down.
+    __device__ __forceinline__ uint32_t window(uint32_t idx, uint32_t lim, uint32_t& shift)
+    {
+        const uint32_t off = min(idx, lim);
+        shift = (idx - off) * 8u;
+        return off;
+    }
+    __device__ __forceinline__ bool redo() const { return false; }
 };
-struct LazyCvt {
-    float hi = 0.0f;
+
+// TRACK = false is for streams whose certificate also proves that no converted value can reach 2^31
+// (pcs_capi.cpp: certify_no_overflow): then the running maximum is not needed at all.
+template <bool TRACK>
+struct FastCvt {
+    float    hi = 0.0f;
+    uint32_t max_idx = 0;
+    uint32_t lim = 0xFFFFFFFFu;
     __device__ __forceinline__ void note(float a, float b, float c, float d, float e)
     {
-        hi = __builtin_fmaxf(__builtin_fmaxf(hi, a), b);
-        hi = __builtin_fmaxf(__builtin_fmaxf(hi, c), d);
-        hi = __builtin_fmaxf(hi, e);
+        if (TRACK) {
+            hi = __builtin_fmaxf(__builtin_fmaxf(hi, a), b);
+            hi = __builtin_fmaxf(__builtin_fmaxf(hi, c), d);
+            hi = __builtin_fmaxf(hi, e);
+        }
     }
     __device__ __forceinline__ int32_t cvt(float f) const { return cvt_sat(f); }
     // Clamp in the float domain first (one v_med3_f32; NaN -> 0 like the x86 path), then convert: for
-    // f < 2^31 this equals clamp(trunc(f), 0, dim-1); f >= 2^31 is the case overflowed() reports.
+    // f < 2^31 this equals clamp(trunc(f), 0, dim-1); f >= 2^31 is the case redo() reports.
     __device__ __forceinline__ int32_t pixel(float f, int32_t, float dim_m1_f) const
     {
         return cvt_sat(__builtin_amdgcn_fmed3f(f, 0.0f, dim_m1_f));
     }
-    __device__ __forceinline__ bool overflowed() const { return hi >= 2147483648.0f; }
+    // The window only ever slides for the raster's very last pixel: clamp the address (so nothing past the
+    // raster is read), remember the largest index seen, and let redo() send the lane through the exact path
+    // if any index actually needed the slide.
+    __device__ __forceinline__ uint32_t window(uint32_t idx, uint32_t l, uint32_t& shift)
+    {
+        max_idx = max(max_idx, idx);
+        lim = l;
+        shift = 0u;
+        return min(idx, l);
+    }
+    __device__ __forceinline__ bool redo() const { return (TRACK && hi >= 2147483648.0f) || max_idx > lim; }
 };
+using LazyCvt = FastCvt<true>;
 
 // Arithmetic policy of the depth->colour projection. Every policy the product launches is bit-identical
 // to IeeeMath on the inputs it is launched for (see "certification" in pcs_capi.cpp and DESIGN.md);
 // tools/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
 struct IeeeMath {
-    static constexpr bool kLazyCvt = false;
+    static constexpr int kCvtMode = 0;      // 0 exact conversions, 1 fast with overflow tracking, 2 fast, overflow certified impossible
     // rs2_transform_point_to_point: R column-major, products and sums individually rounded, left to right
     static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
                                                float& P0, float& P1, float& P2)
@@ -131,9 +158,9 @@ struct IeeeMath {
 //    is created (pcs_verify_div_const_kernel) and CertMath is used only if no numerator differs.
 //  * IDENT_R: depth->colour rotation is exactly the identity (and t has no negative zeros), so
 //    R*p + t is p + t: the dropped products are exact (1*x) or signed zeros that cannot change a sum.
-template <bool IDENT_R>
+template <bool IDENT_R, bool NO_OVERFLOW = false>
 struct CertMath {
-    static constexpr bool kLazyCvt = true;
+    static constexpr int kCvtMode = NO_OVERFLOW ? 2 : 1;
     static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
                                                float& P0, float& P1, float& P2)
     {
@@ -169,6 +196,9 @@ struct CertMath {
     }
 };
 
+using CertNoOvf = CertMath<false, true>;
+using CertIdentNoOvf = CertMath<true, true>;
+
 // a2 colour lookup (src/pcs-camera-optimized.cpp:431-452, 584-585): texcoord -> byte index of the pixel.
 __device__ __forceinline__ void color_coords(const StreamParams& P, float u, float v, float& xf, float& yf)
 {
@@ -176,17 +206,19 @@ __device__ __forceinline__ void color_coords(const StreamParams& P, float u, flo
     yf = __fmaf_rn(v, P.c_h_f, 0.5f);
 }
 
-// Returns R | G<<8 | B<<16, which is exactly shorts 3 and 4 of the record as one little-endian dword.
+// Returns R | G<<8 | B<<16 in the low 24 bits (the top byte is whatever followed in memory): shorts 3 and 4
+// of the record are its low half and byte 2.
+template <class Cvt>
 __device__ __forceinline__ uint32_t color_fetch(const StreamParams& P, const uint8_t* __restrict__ color,
-                                                int32_t xi, int32_t yi)
+                                                int32_t xi, int32_t yi, Cvt& cv)
 {
     // xi < 2^24, bpp small, yi < 2^24, stride < 2^24: 24-bit multiplies are exact in 32 bits and full rate
     const uint32_t idx = __umul24((uint32_t)xi, (uint32_t)P.bpp) + __umul24((uint32_t)yi, (uint32_t)P.stride);
-    // One dword covers R,G,B. Never read past the raster: slide the window back at the very end.
-    const uint32_t off = min(idx, P.color_bytes - 4u);
+    uint32_t shift;
+    const uint32_t off = cv.window(idx, P.color_bytes - 4u, shift);
     uint32_t w;
     __builtin_memcpy(&w, color + off, 4);
-    return (w >> ((idx - off) * 8u)) & 0x00FFFFFFu;
+    return w >> shift;                   // R | G<<8 | B<<16 | (don't care)<<24
 }
 
 // a2 rigid transform + scale (src/pcs-camera-optimized.cpp:455-491).
@@ -200,6 +232,13 @@ __device__ __forceinline__ float world_mm(const float* __restrict__ Mr, float X,
 }
 
 struct __attribute__((packed)) Record10 { uint32_t xy, zc; uint16_t b; };   // the wire layout of one point
+
+// v_perm_b32: every result byte picks one of the 8 bytes of {hi, lo} (lo = bytes 0-3, hi = bytes 4-7).
+// Two selectors cover all the 16-bit shuffles of the record packing in ONE instruction each, with no
+// masks or shifts around them:
+//   kLoLo: lo.lo16 | hi.lo16 << 16          kHiLo: lo.hi16 | hi.lo16 << 16
+constexpr uint32_t kLoLo = 0x05040100u, kHiLo = 0x05040302u;
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 struct Record {              // one 10-byte point as three pieces
     uint32_t xy;             // x | y << 16
@@ -216,8 +255,8 @@ struct Record {              // one 10-byte point as three pieces
 __device__ __forceinline__ void stage_record(uint8_t* lds, uint32_t off, const Record& r)
 {
     const bool odd = (off & 2u) != 0u;
-    const uint32_t yz = (r.xy >> 16) | (r.zc << 16);
-    const uint32_t cc = (r.zc >> 16) | (r.b << 16);
+    const uint32_t yz = perm(r.zc, r.xy, kHiLo);
+    const uint32_t cc = perm(r.b, r.zc, kHiLo);
     const uint32_t h_val = odd ? r.xy : r.b;                 // low 16 bits are what is written
     const uint32_t a_val = odd ? yz : r.xy;
     const uint32_t b_val = odd ? cc : r.zc;
@@ -239,14 +278,12 @@ __device__ __forceinline__ Record make_record(const StreamParams& P, const uint8
     float xf, yf;
     color_coords(P, p.u, p.v, xf, yf);
     cv.note(ax, ay, az, xf, yf);
-    const uint32_t x = (uint32_t)cv.cvt(ax) & 0xFFFFu;
-    const uint32_t y = (uint32_t)cv.cvt(ay);
-    const uint32_t z = (uint32_t)cv.cvt(az) & 0xFFFFu;
-    const uint32_t w = color_fetch(P, color, cv.pixel(xf, P.cW - 1, P.c_wm1_f), cv.pixel(yf, P.cH - 1, P.c_hm1_f));
+    const uint32_t x = (uint32_t)cv.cvt(ax), y = (uint32_t)cv.cvt(ay), z = (uint32_t)cv.cvt(az);
+    const uint32_t w = color_fetch(P, color, cv.pixel(xf, P.cW - 1, P.c_wm1_f), cv.pixel(yf, P.cH - 1, P.c_hm1_f), cv);
     Record r;
-    r.xy = x | (y << 16);
-    r.zc = z | (w << 16);
-    r.b  = w >> 16;
+    r.xy = perm(y, x, kLoLo);                    // short(x) | short(y) << 16  — the low 16 bits of each (:581-583)
+    r.zc = perm(w, z, kLoLo);                    // short(z) | (R | G<<8) << 16
+    r.b  = __builtin_amdgcn_ubfe(w, 16, 8);      // B, high byte 0 (:585)
     return r;
 }
 
@@ -521,15 +558,19 @@ __device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src
             uint32_t* o = w + (k >> 1) * 5;
             o[0] = a.xy;
             o[1] = a.zc;
-            o[2] = (a.b & 0xFFFFu) | (b.xy << 16);
-            o[3] = (b.xy >> 16) | (b.zc << 16);
-            o[4] = (b.zc >> 16) | (b.b << 16);
+            o[2] = perm(b.xy, a.b, kLoLo);
+            o[3] = perm(b.zc, b.xy, kHiLo);
+            o[4] = perm(b.b, b.zc, kHiLo);
         }
     };
-    if (Src::Math::kLazyCvt) {
-        LazyCvt lazy;
-        fill(lazy);
-        if (__builtin_expect(lazy.overflowed(), 0)) { ExactCvt exact; fill(exact); }
+    if (Src::Math::kCvtMode == 2) {
+        FastCvt<false> fast;
+        fill(fast);
+        if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+    } else if (Src::Math::kCvtMode == 1) {
+        FastCvt<true> fast;
+        fill(fast);
+        if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
     } else {
         ExactCvt exact;
         fill(exact);
@@ -581,10 +622,14 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
 #pragma unroll
         for (int k = 0; k < 8; k++) rec[k] = make_record(P, color, p[k], cv);
     };
-    if (Src::Math::kLazyCvt) {
-        LazyCvt lazy;
-        fill(lazy);
-        if (__builtin_expect(lazy.overflowed(), 0)) { ExactCvt exact; fill(exact); }
+    if (Src::Math::kCvtMode == 2) {
+        FastCvt<false> fast;
+        fill(fast);
+        if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+    } else if (Src::Math::kCvtMode == 1) {
+        FastCvt<true> fast;
+        fill(fast);
+        if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
     } else {
         ExactCvt exact;
         fill(exact);
@@ -765,10 +810,14 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
 #pragma unroll
         for (int k = 0; k < 8; k++) rec[k] = make_record(P, color, p[k], cv);
     };
-    if (Mth::kLazyCvt) {
-        LazyCvt lazy;
-        fill(lazy);
-        if (__builtin_expect(lazy.overflowed(), 0)) { ExactCvt exact; fill(exact); }
+    if (Mth::kCvtMode == 2) {
+        FastCvt<false> fast;
+        fill(fast);
+        if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+    } else if (Mth::kCvtMode == 1) {
+        FastCvt<true> fast;
+        fill(fast);
+        if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
     } else {
         ExactCvt exact;
         fill(exact);
@@ -1080,8 +1129,11 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
 #define L(DD, CD, M) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD, M>), grid, dim3(kBlockThreads), 0, st, \
                                         d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload))
     if (math != MathSel::Ieee && !any_ddist) {
-        if (math == MathSel::CertIdentR) { if (any_cdist) L(false, true, CertMath<true>); else L(false, false, CertMath<true>); }
-        else                             { if (any_cdist) L(false, true, CertMath<false>); else L(false, false, CertMath<false>); }
+        const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
+        const bool noovf = (math == MathSel::CertNoOvf || math == MathSel::CertIdentRNoOvf) && !any_cdist;
+        if (noovf)      { if (ident) L(false, false, CertIdentNoOvf); else L(false, false, CertNoOvf); }
+        else if (ident) { if (any_cdist) L(false, true, CertMath<true>); else L(false, false, CertMath<true>); }
+        else            { if (any_cdist) L(false, true, CertMath<false>); else L(false, false, CertMath<false>); }
     } else {
         if (any_ddist) { if (any_cdist) L(true, true, IeeeMath); else L(true, false, IeeeMath); }
         else           { if (any_cdist) L(false, true, IeeeMath); else L(false, false, IeeeMath); }
@@ -1124,7 +1176,8 @@ hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_la
                                         stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_kept, out)
 #define LM(M) do { if (pred) { if (ds1) L(true, true, M); else L(true, false, M); } \
                    else      { if (ds1) L(false, true, M); else L(false, false, M); } } while (0)
-    if (math == MathSel::CertIdentR) LM(CertMath<true>); else if (math == MathSel::Cert) LM(CertMath<false>); else LM(IeeeMath);
+    const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
+    if (math == MathSel::Ieee) LM(IeeeMath); else if (ident) LM(CertMath<true>); else LM(CertMath<false>);
 #undef LM
 #undef L
     return hipGetLastError();

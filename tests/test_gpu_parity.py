@@ -351,7 +351,7 @@ def test_policy_selection_and_equivalence_on_the_benchmark_config(oracle):
     cfgs, depth, color = S.synth_frame_set(8, 1280, 720)
     want, _ = oracle.process_frames(cfgs, depth, color)
     with PcsContext(cfgs) as ctx:
-        assert [ctx.stream_math(s) for s in range(8)] == [2] * 8      # certified + identity R
+        assert [ctx.stream_math(s) for s in range(8)] == [4] * 8      # certified + identity R + no-overflow
         buf, _, _ = ctx.process_frames(depth, color)
     assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
     with PcsContext(cfgs, flags=FLAG_FORCE_IEEE) as ctx:
@@ -375,7 +375,7 @@ def test_policy_falls_back_when_not_certifiable(oracle):
     color = [S.synth_color(cc.color.width, cc.color.height, i) for i, cc in enumerate(cfgs)]
     for i in range(3):
         with PcsContext([cfgs[i]]) as ctx:
-            assert ctx.stream_math(0) == (0, 1, 0)[i]
+            assert ctx.stream_math(0) == (0, 3, 0)[i]
             buf, counts, _ = ctx.process_frames([depth[i]], [color[i]])
         want, _ = oracle.process_frames([cfgs[i]], [depth[i]], [color[i]])
         assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
@@ -438,10 +438,18 @@ def test_lazy_convert_redo_path(oracle):
         cfgs[0].cam_to_world[k] = float(m[k])
     want, _ = oracle.process_frames(cfgs, depth, color)
     with PcsContext(cfgs) as ctx:
-        assert ctx.stream_math(0) == 2
+        assert ctx.stream_math(0) == 2      # certified, but NOT the no-overflow variant: the extrinsic rules it out
         buf, _, _ = ctx.process_frames(depth, color)
     assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
     assert (want[:, 0] == 0).all()          # INT_MIN & 0xFFFF, the x86 answer (hardware alone would give -1)
+    # and through pcs_set_cam_to_world: a context that starts in the no-overflow variant must leave it
+    cfgs2, _, _ = S.synth_frame_set(1, 64, 48, single=True)
+    with PcsContext(cfgs2) as ctx:
+        assert ctx.stream_math(0) == 4
+        ctx.set_cam_to_world(0, m)
+        assert ctx.stream_math(0) == 2
+        buf, _, _ = ctx.process_frames(depth, color)
+    assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -529,3 +537,20 @@ def test_large_raster_multi_chunk_scan_and_dense(oracle):
         want, wcounts = oracle.process_frames(cfgs, depth, color, flags)
         assert counts == wcounts
         assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+def test_last_colour_pixel_window_redo(oracle):
+    """Tight RGB8 raster: only the very last colour pixel needs the dword window slid back; the fast path must
+    notice (max index > limit) and redo the lane exactly. Force every point onto that pixel."""
+    cfgs, depth, color = S.synth_frame_set(1, 64, 48, single=True)
+    cfgs[0].color.ppx = 1.0e6        # projects everything far right/bottom -> clamps to (W-1, H-1)
+    cfgs[0].color.ppy = 1.0e6
+    want, _ = oracle.process_frames(cfgs, depth, color)
+    with PcsContext(cfgs) as ctx:
+        assert ctx.stream_math(0) in (2, 4)
+        buf, _, _ = ctx.process_frames(depth, color)
+    got = buf[2:2 + want.size].reshape(-1, 5)
+    assert_same(got, want)
+    valid = depth[0].reshape(-1) != 0
+    last = color[0][-3:]
+    assert (got[valid, 3].view(np.uint16) == (int(last[0]) | int(last[1]) << 8)).all() and (got[valid, 4] == last[2]).all()

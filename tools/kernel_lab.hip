@@ -30,8 +30,8 @@ struct SloppyMath : CertMath<true> {
     static __device__ __forceinline__ float div_const(float a, float, float rc) { return a * rc; }
 };
 // ---- ablations of the certified policy ----
-struct IeeeLazy : IeeeMath { static constexpr bool kLazyCvt = true; };                 // only the lazy convert
-struct CertNoLazy : CertMath<false> { static constexpr bool kLazyCvt = false; };       // only the quotients
+struct IeeeLazy : IeeeMath { static constexpr int kCvtMode = 1; };                 // only the lazy convert
+struct CertNoLazy : CertMath<false> { static constexpr int kCvtMode = 0; };       // only the quotients
 struct CertDiv2Only : IeeeMath {                                                        // only the shared-reciprocal div2
     static __device__ __forceinline__ void div2(float a0, float a1, float b, float& q0, float& q1) { CertMath<false>::div2(a0, a1, b, q0, q1); }
 };
@@ -226,7 +226,7 @@ void lab_fused_dense_2tiles(const StreamParams* __restrict__ params, FramePtrs f
             const Record a = make_record(P, color, p[k], lazy);
             const Record b = make_record(P, color, p[k + 1], lazy);
             uint32_t* o = w + (k >> 1) * 5;
-            o[0] = a.xy; o[1] = a.zc; o[2] = (a.b & 0xFFFFu) | (b.xy << 16); o[3] = (b.xy >> 16) | (b.zc << 16); o[4] = (b.zc >> 16) | (b.b << 16);
+            o[0] = a.xy; o[1] = a.zc; o[2] = perm(b.xy, a.b, kLoLo); o[3] = perm(b.zc, b.xy, kHiLo); o[4] = perm(b.b, b.zc, kHiLo);
         }
         uint4* mine = st + threadIdx.x * 5;
 #pragma unroll
@@ -408,6 +408,8 @@ int main(int argc, char** argv)
         time_it("cert, exact cvt", LAUNCH((lab::lab_fused_dense<lab::CertNoLazy>)));
         time_it("cert (product)", LAUNCH((lab::lab_fused_dense<CertMath<false>>)));
         time_it("cert + identity R (product)", LAUNCH((lab::lab_fused_dense<CertMath<true>>)));
+        time_it("cert, no-overflow cert.", LAUNCH((lab::lab_fused_dense<CertNoOvf>)));
+        time_it("cert + identR, no-overflow", LAUNCH((lab::lab_fused_dense<CertIdentNoOvf>)));
         time_it("cert+identR, lb(256,8)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 8>)));
         time_it("cert+identR, lb(256,7)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 7>)));
         time_it("cert+identR, lb(256,5)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 5>)));
