@@ -125,7 +125,10 @@ using LazyCvt = FastCvt<true>;
 // to IeeeMath on the inputs it is launched for (see "certification" in pcs_capi.cpp and DESIGN.md);
 // tools/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
 struct IeeeMath {
-    static constexpr int kCvtMode = 0;      // 0 exact conversions, 1 fast with overflow tracking, 2 fast, overflow certified impossible
+    // 0 exact conversions, 1 fast with overflow tracking, 2 fast, overflow certified impossible.
+    // The tracked fast form is exact for every input (its redo path IS the exact form), so even the
+    // fallback policy uses it; only the quotients stay on the IEEE expansion here.
+    static constexpr int kCvtMode = 1;
     // rs2_transform_point_to_point: R column-major, products and sums individually rounded, left to right
     static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
                                                float& P0, float& P1, float& P2)
