@@ -554,3 +554,44 @@ def test_last_colour_pixel_window_redo(oracle):
     valid = depth[0].reshape(-1) != 0
     last = color[0][-3:]
     assert (got[valid, 3].view(np.uint16) == (int(last[0]) | int(last[1]) << 8)).all() and (got[valid, 4] == last[2]).all()
+
+
+def test_adversarial_configurations_near_certificate_thresholds(oracle):
+    """Configurations pushed towards the edges of what certify_stream / certify_no_overflow accept or refuse:
+    tiny and huge depth scales, colour plane almost through the camera, strong rotations, extreme focal
+    lengths, extreme depth values. Whatever the certificates decide, the output must equal the oracle."""
+    rng = np.random.default_rng(77)
+    depth_vals = np.array([1, 2, 3, 65535, 65534, 32768, 1000, 0, 7, 500], np.uint16)
+    seen = set()
+    for trial in range(120):
+        w, h = 64, 16
+        cw, ch = [(64, 16), (48, 40), (128, 8)][trial % 3]
+        fx = float(10.0 ** rng.uniform(0.5, 4.5))
+        di = make_intrinsics(w, h, fx, fx * rng.uniform(0.5, 2.0), rng.uniform(-50, 150), rng.uniform(-50, 60))
+        ci = make_intrinsics(cw, ch, float(10.0 ** rng.uniform(0.5, 4.5)), float(10.0 ** rng.uniform(0.5, 4.5)),
+                             rng.uniform(-1e3, 1e3), rng.uniform(-1e3, 1e3))
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = [0.0, 1e-4, 0.05, 0.6, 1.5, 3.0][trial % 6]
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        scale = float([1e-3, 1e-6, 1e-12, 2.0 ** -39, 2.0 ** -41, 1.0, 300.0, 1e5][trial % 8])
+        t = rng.normal(0, 1, 3) * [0.02, 0.02, 0.02]
+        if trial % 5 == 0:
+            t[2] = -scale * float(rng.integers(1, 5))          # P2 = Z + t2 crosses zero for small depths
+        if trial % 7 == 0:
+            t[:] = 0.0
+        m = TRANSFORMS[trial % 8].copy()
+        if trial % 9 == 0:
+            m[3] = 2.0e6                                        # world x beyond 2^31 mm
+        sc = make_stream_config(di, ci, cam_to_world=m, rotation=list(Rm.T.reshape(-1)), translation=list(t), depth_scale=scale)
+        depth = depth_vals[rng.integers(0, depth_vals.size, w * h)].reshape(h, w)
+        color = S.synth_color(cw, ch, trial)
+        want, _ = oracle.process_frames([sc], [depth], [color])
+        for flags in (0, FLAG_FORCE_IEEE):
+            with PcsContext([sc], flags=flags) as ctx:
+                if flags == 0:
+                    seen.add(ctx.stream_math(0))
+                buf, _, _ = ctx.process_frames([depth], [color])
+            d = first_diff(buf[2:2 + want.size].reshape(-1, 5), want)
+            assert d is None, f"trial {trial} flags {flags}: {d}"
+    assert 0 in seen and (seen - {0})             # both refused and accepted configurations occurred

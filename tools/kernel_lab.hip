@@ -262,20 +262,32 @@ __device__ __forceinline__ uint32_t lab_hash(uint32_t x)
 }
 
 // mode 0: raw random bit patterns (all exponents, NaN/inf/denormals); mode 1: "camera-like" magnitudes
-__global__ void verify_div2(uint32_t seed, int mode, uint64_t count, unsigned long long* bad)
+__global__ void verify_div2(uint32_t seed, int mode, uint64_t count, unsigned long long* bad, unsigned long long* zero_sign)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long local = 0;
+    unsigned long long local = 0, local_z = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const uint32_t h0 = lab_hash((uint32_t)i * 3u + seed), h1 = lab_hash((uint32_t)i * 3u + 1u + seed),
                        h2 = lab_hash((uint32_t)i * 3u + 2u + seed ^ (uint32_t)(i >> 32));
         float a0, a1, b;
-        if (mode == 0) { a0 = __uint_as_float(h0); a1 = __uint_as_float(h1); b = __uint_as_float(h2); }
-        else {
-            // mantissa random, exponent in a window around 1.0 of +-2^12
-            a0 = __uint_as_float((h0 & 0x807FFFFFu) | ((115u + (h0 >> 23) % 25u) << 23));
-            a1 = __uint_as_float((h1 & 0x807FFFFFu) | ((115u + (h1 >> 23) % 25u) << 23));
-            b  = __uint_as_float((h2 & 0x807FFFFFu) | ((115u + (h2 >> 23) % 25u) << 23));
+        if (mode == 0) {        // raw bit patterns (mostly OUTSIDE the certified window: informational only)
+            a0 = __uint_as_float(h0); a1 = __uint_as_float(h1); b = __uint_as_float(h2);
+        } else {
+            // the certified window of pcs_capi.cpp::certify_stream, in full:
+            //   2^-40 <= |b| < 2^30 ; |a| < 2^30 and (a == 0 or |a| >= 2^-70)
+            const uint32_t ea0 = 57u + (h0 >> 23) % 100u;          // biased exponents 57..156  = 2^-70 .. 2^29
+            const uint32_t ea1 = 57u + (h1 >> 23) % 100u;
+            const uint32_t eb  = 87u + (h2 >> 23) % 70u;           //                  87..156  = 2^-40 .. 2^29
+            a0 = __uint_as_float((h0 & 0x807FFFFFu) | (ea0 << 23));
+            a1 = __uint_as_float((h1 & 0x807FFFFFu) | (ea1 << 23));
+            b  = __uint_as_float((h2 & 0x807FFFFFu) | (eb << 23));
+            if (mode == 2) {    // adversarial mantissas: all-ones / all-zeros / near powers of two
+                const uint32_t m[4] = {0x007FFFFFu, 0x00000000u, 0x00000001u, 0x007FFFFEu};
+                a0 = __uint_as_float((__float_as_uint(a0) & 0xFF800000u) | m[h0 & 3u]);
+                a1 = __uint_as_float((__float_as_uint(a1) & 0xFF800000u) | m[(h1 >> 2) & 3u]);
+                b  = __uint_as_float((__float_as_uint(b) & 0xFF800000u) | m[(h2 >> 4) & 3u]);
+            }
+            if ((h0 & 0xFC0u) == 0u) a0 = (h0 & 0x40000u) ? 0.0f : -0.0f;   // exact zeros are allowed numerators
         }
         float w0, w1, g0, g1;
         IeeeMath::div2(a0, a1, b, w0, w1);
@@ -283,9 +295,14 @@ __global__ void verify_div2(uint32_t seed, int mode, uint64_t count, unsigned lo
         const uint32_t wb0 = __float_as_uint(w0), gb0 = __float_as_uint(g0), wb1 = __float_as_uint(w1), gb1 = __float_as_uint(g1);
         const bool n0 = ((wb0 & 0x7FFFFFFFu) > 0x7F800000u) && ((gb0 & 0x7FFFFFFFu) > 0x7F800000u);
         const bool n1 = ((wb1 & 0x7FFFFFFFu) > 0x7F800000u) && ((gb1 & 0x7FFFFFFFu) > 0x7F800000u);
-        if ((wb0 != gb0 && !n0) || (wb1 != gb1 && !n1)) local++;
+        // a quotient that is zero in both but with the other sign is tallied separately
+        const bool z0 = ((wb0 | gb0) << 1) == 0u, z1 = ((wb1 | gb1) << 1) == 0u;
+        const bool d0 = wb0 != gb0 && !n0, d1 = wb1 != gb1 && !n1;
+        if ((d0 && !z0) || (d1 && !z1)) local++;
+        else if (d0 || d1) local_z++;
     }
     if (local) atomicAdd(bad, local);
+    if (local_z) atomicAdd(zero_sign, local_z);
 }
 
 }  // namespace lab
@@ -471,12 +488,14 @@ int main(int argc, char** argv)
         CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hf, dfirst, 4, hipMemcpyDeviceToHost));
         printf("div_const c=%-5d : %llu of 2^32 numerators differ from IEEE (largest failing |a| bits 0x%08x)\n", d, hb, hf);
     }
-    for (int mode = 0; mode < 2; mode++) {
-        CK(hipMemset(dbad, 0, 8));
-        const uint64_t cnt = 1ull << 33;
-        hipLaunchKernelGGL(lab::verify_div2, dim3(8192), dim3(256), 0, st, 12345u + mode, mode, cnt, dbad);
-        unsigned long long hb; CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost));
-        printf("div2 fuzz mode %d : %llu of %llu triples differ from IEEE\n", mode, hb, (unsigned long long)cnt);
+    for (int mode = 1; mode < 3; mode++) {
+        unsigned long long* dz; CK(hipMalloc(&dz, 8));
+        CK(hipMemset(dbad, 0, 8)); CK(hipMemset(dz, 0, 8));
+        const uint64_t cnt = 1ull << 34;
+        hipLaunchKernelGGL(lab::verify_div2, dim3(8192), dim3(256), 0, st, 12345u + mode, mode, cnt, dbad, dz);
+        unsigned long long hb, hz; CK(hipMemcpy(&hb, dbad, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hz, dz, 8, hipMemcpyDeviceToHost));
+        printf("   (of which only the sign of a zero quotient differs: %llu)\n", hz);
+        printf("div2 (guard-free, certified window%s): %llu of %llu triples differ from IEEE\n", mode == 2 ? ", adversarial mantissas" : "", hb, (unsigned long long)cnt);
     }
     return 0;
 }
