@@ -238,8 +238,6 @@ __device__ __forceinline__ float world_mm(const float* __restrict__ Mr, float X,
     return __fmul_rn(a, 1000.0f);
 }
 
-struct __attribute__((packed)) Record10 { uint32_t xy, zc; uint16_t b; };   // the wire layout of one point
-
 // v_perm_b32: every result byte picks one of the 8 bytes of {hi, lo} (lo = bytes 0-3, hi = bytes 4-7).
 // Two selectors cover all the 16-bit shuffles of the record packing in ONE instruction each, with no
 // masks or shifts around them:
