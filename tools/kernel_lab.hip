@@ -239,6 +239,39 @@ void lab_fused_dense_2tiles(const StreamParams* __restrict__ params, FramePtrs f
     if (hasB) store_staged(reinterpret_cast<const uint8_t*>(stage[1]), 0u, min(kTilePoints, n - tB) * PCS_POINT_BYTES, out + (size_t)tB * PCS_POINT_BYTES);
 }
 
+
+// Skeleton with 4 pixels per lane (1024-pixel tiles, 8-byte depth loads, 40-byte lane runs staged as
+// 5 x ds_write_b64): does a lighter lane (fewer VGPRs, more waves) stream faster than the 8-pixel one?
+__global__ __launch_bounds__(kBlockThreads)
+void lab_skeleton_4px(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes)
+{
+    __shared__ uint2 stage[kBlockThreads * 5];          // 10 240 B
+    const int s = blockIdx.y;
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * 1024u;
+    if (tile0 >= n) return;
+    const uint32_t i0 = tile0 + threadIdx.x * 4;
+    const uint2 dv = *reinterpret_cast<const uint2*>(fp.depth[s] + i0);
+    const uint32_t dw[2] = {dv.x, dv.y};
+    uint32_t w[10];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t c;
+        __builtin_memcpy(&c, fp.color[s] + min((i0 + k) * 3u, P.color_bytes - 4u), 4);
+        const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+        w[(k * 5) / 2] = d ^ c;
+        w[(k * 5) / 2 + 1] = c + k;
+        if ((k & 1) == 0) w[(k * 5) / 2 + 2] = d;
+    }
+    uint2* mine = stage + threadIdx.x * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) mine[k] = make_uint2(w[2 * k], w[2 * k + 1]);
+    __syncthreads();
+    store_staged(reinterpret_cast<const uint8_t*>(stage), 0u, 1024u * PCS_POINT_BYTES,
+                 payload_bytes + ((size_t)P.out_base + tile0) * PCS_POINT_BYTES);
+}
+
 // ---- exhaustive / fuzz verification kernels ---------------------------------------------------
 __global__ void verify_div_const(float c, float rc, unsigned long long* bad, uint32_t* first_bad)
 {
@@ -434,6 +467,10 @@ int main(int argc, char** argv)
         time_it("sloppy (inexact bound)", LAUNCH((lab::lab_fused_dense<lab::SloppyMath>)));
         time_it("memory skeleton", LAUNCH(lab::lab_memory_skeleton));
         time_it("skeleton, dependent gather", LAUNCH(lab::lab_skeleton_dependent));
+        {
+            const dim3 g4((N + 1023) / 1024, S);
+            time_it("skeleton, 4 px/lane", [&](int r, uint8_t* o) { hipLaunchKernelGGL(lab::lab_skeleton_4px, g4, block, 0, st, dp, ring[r], o); });
+        }
         {
             const dim3 g2(((N + 2047) / 2048 + 1) / 2, S);
             time_it("cert+identR, 2 tiles/WG", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_2tiles<CertMath<true>>), g2, block, 0, st, dp, ring[r], o); });
