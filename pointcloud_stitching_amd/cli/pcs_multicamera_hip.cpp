@@ -13,6 +13,7 @@
 //     -f here takes a frame source (the reference's "fast" switch only thinned its PCL viewer); -s (save PLY),
 //     -v (PCL visualiser) and -n belong to the PCL viewer, which this build does not have: refused with a reason.
 //   additions: -c <list>  -N <streams>  -g <gpu>  -p <serve port>  -r <frame-sets>  -o <file>  -q (no server)
+//              -G <n>  shard the cameras of -f over n GPUs: libpcs_node (ncclCommInitAll + one grouped send/recv to GPU 0)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,12 +28,13 @@
 
 #include "pcs_synth.h"
 #include "pcs_wire.h"
+#include "../../include/pcs_node.h"
 
 typedef std::chrono::high_resolution_clock clockTime;
 typedef std::chrono::duration<double, std::milli> timeMilli;
 
 static bool timer = false, serve = true;
-static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30;
+static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30, n_gpus = 0;
 static const char* source = nullptr;
 static const char* cameras = nullptr;
 static const char* dump_path = nullptr;
@@ -46,6 +48,7 @@ static void usage()
               << " -f <src>         cameras on this node: synth:<W>x<H> or frames.pcsraw\n"
               << " -c <list>        edge servers host:port,... (pull 'Z' protocol)\n"
               << " -N <n> streams   -g <gpu>   -p <port> (default 9000)   -r <frame-sets>   -o <file>   -q no server\n"
+              << " -G <n>           shard the -f cameras over n GPUs of this node (one process, RCCL gather to GPU 0)\n"
               << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
 }
 
@@ -53,7 +56,7 @@ int main(int argc, char** argv)
 {
     signal(SIGPIPE, SIG_IGN);
     int c;
-    while ((c = getopt(argc, argv, "hf:tsvd:nc:N:g:p:r:o:q")) != -1) {
+    while ((c = getopt(argc, argv, "hf:tsvd:nc:N:g:p:r:o:qG:")) != -1) {
         switch (c) {
             case 't': timer = true; break;
             case 'd': downsample = atoi(optarg); break;
@@ -65,6 +68,7 @@ int main(int argc, char** argv)
             case 'r': max_sets = atoi(optarg); break;
             case 'o': dump_path = optarg; break;
             case 'q': serve = false; break;
+            case 'G': n_gpus = atoi(optarg); break;
             case 's': case 'v': case 'n':
                 std::cerr << "-" << (char)c << " drives the reference's PCL viewer / PLY writer, which this build does not include" << std::endl;
                 return 2;
@@ -117,6 +121,17 @@ int main(int argc, char** argv)
     int rc = pcs_create(&ctx, &cfg);
     if (rc != PCS_OK) { std::cerr << "pcs_create: " << pcs_strerror(rc) << ": " << pcs_last_error(nullptr) << std::endl; return 1; }
 
+    pcs_node* node = nullptr;
+    if (n_gpus > 0) {
+        if (!source) { std::cerr << "-G applies to cameras on this node (-f)" << std::endl; return 2; }
+        if (n_streams % n_gpus) { std::cerr << "-N " << n_streams << " streams do not divide over -G " << n_gpus << " GPUs" << std::endl; return 2; }
+        std::vector<int> ids(n_gpus);
+        for (int g = 0; g < n_gpus; g++) ids[g] = device + g;
+        rc = pcs_node_create(&node, n_gpus, ids.data(), n_streams / n_gpus, cfgs.data(), 0u, downsample);
+        if (rc != PCS_OK) { std::cerr << "pcs_node_create: " << pcs_strerror(rc) << ": " << pcs_node_last_error(nullptr) << std::endl; return 1; }
+        std::cout << "Sharding " << n_streams << " cameras over " << n_gpus << " GPU(s), RCCL gather to GPU " << device << std::endl;
+    }
+
     // ---- buffers -------------------------------------------------------------------------------
     const size_t cam_cap_bytes = (size_t)10 * 4u * 1000 * 1000;           // per-camera receive buffer (reference: 10 MB, :554)
     size_t stitched_shorts = source ? PCS_HEADER_SHORTS + pcs_max_payload_shorts(ctx)
@@ -167,8 +182,13 @@ int main(int argc, char** argv)
             }
             std::vector<const uint16_t*> dp(n_streams); std::vector<const uint8_t*> cp(n_streams);
             for (int s = 0; s < n_streams; s++) { dp[s] = depth[s].data(); cp[s] = color[s].data(); }
-            rc = pcs_process_frames(ctx, dp.data(), cp.data(), stitched.data(), stitched.size(), 1, nullptr, &size_bytes);
-            if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+            if (node) {
+                rc = pcs_node_process(node, dp.data(), cp.data(), stitched.data(), stitched.size(), 1, nullptr, &size_bytes);
+                if (rc != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
+            } else {
+                rc = pcs_process_frames(ctx, dp.data(), cp.data(), stitched.data(), stitched.size(), 1, nullptr, &size_bytes);
+                if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+            }
         } else {
             // one reader thread per camera, joined in camera order (:381-386)
             std::vector<int32_t> got(n_streams, -1);
@@ -219,6 +239,7 @@ int main(int argc, char** argv)
     if (listen_fd >= 0) ::close(listen_fd);
     for (void* p : d_cam) if (p) pcs_device_free(ctx, p);
     if (d_stitched) pcs_device_free(ctx, d_stitched);
+    if (node) pcs_node_destroy(node);
     pcs_destroy(ctx);
     return 0;
 }

@@ -89,3 +89,15 @@ def test_create_rejects_bad_configs_before_touching_the_device():
     with pytest.raises(PcsError) as e:
         PcsContext(cfgs)
     assert e.value.status == -4
+
+
+def test_node_library_exports_its_header():
+    node_h = os.path.join(L.INCLUDE_DIR, "pcs_node.h")
+    src = re.sub(r"/\*.*?\*/", "", open(node_h).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(pcs_node_[a-z0-9_]+)\s*\(", src)))
+    lib = os.path.join(os.path.dirname(L.LIB_PATH), "libpcs_node.so")
+    L.build()
+    assert os.path.exists(lib)
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = set(re.findall(r" T (pcs_node_[a-z0-9_]+)", nm))
+    assert set(declared) == exported and len(declared) >= 6

@@ -157,3 +157,34 @@ def test_central_all_gpu_mode(oracle):
     finally:
         if p.poll() is None:
             p.kill()
+
+
+@pytest.mark.gpu
+def test_central_node_mode_one_gpu(oracle):
+    """-G 1: the single-process multi-GPU layer (libpcs_node) with one device — per-device context, counts,
+    stitched buffer on the root. (The N>1 exchange is straight-line RCCL and needs a multi-GPU box.)"""
+    port = free_port()
+    p = subprocess.Popen([CENTRAL, "-f", "synth:128x96", "-N", "4", "-G", "1", "-p", str(port), "-r", "2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        sock = connect(port)
+        for frame in range(2):
+            sock.sendall(b"Z")
+            got = read_frame(sock)
+            cfgs, depth, color = frame_inputs(4, 128, 96, frame, single=False)
+            want, _ = oracle.process_frames(cfgs, depth, color)
+            assert got.shape == want.shape and (got == want).all()
+        sock.close()
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 0, err
+        assert "Sharding 4 cameras over 1 GPU(s)" in out
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.gpu
+def test_central_node_mode_rejects_more_gpus_than_present():
+    r = subprocess.run([CENTRAL, "-f", "synth:64x48", "-N", "64", "-G", "64", "-q", "-r", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 1 and "available" in r.stderr
