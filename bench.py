@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
+    ap.add_argument("--no-general-rotation", action="store_true",
+                    help="skip the extra leg that times the same workload with a non-identity depth->colour rotation")
     ap.add_argument("--debug-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: exercise the N>1 control flow on ONE GPU (all ranks on device 0, gathers staged through "
                          "host memory). For testing the script only — the numbers mean nothing.")
@@ -403,6 +405,44 @@ def main():
             out["roofline"]["traffic"] = None
         elif args.mode != "dense":
             out["config"]["mode"] = args.mode + " (diagnostic: count + scan + emit passes; not the headline workload)"
+        if world == 1 and args.mode == "dense" and not args.no_general_rotation:
+            # The synthetic configuration of SURVEY.md 8(d) has depth->colour R = I, which lets the kernel skip 15
+            # individually-rounded flops per pixel; real D400 units report a small rotation. Same rasters, same
+            # launch, R = 1 degree about a skewed axis:
+            import math
+            ang = math.radians(1.0)
+            ax = np.array([0.3, 0.9, 0.3]); ax /= np.linalg.norm(ax)
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            Rm = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+            cfgs_r = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
+            for cfg_r in cfgs_r:
+                for k, v in enumerate(Rm.T.reshape(-1)):
+                    cfg_r.depth_to_color.rotation[k] = float(v)
+            ctx_r = PcsContext(cfgs_r, device=local_rank)
+            ctx_r.set_stream(stream.cuda_stream)
+            hr = ctx_r._h
+
+            def launch_r(slot):
+                dp, cp, outp = call_args[slot]
+                if lib.pcs_process_frames_device(hr, dp, cp, outp, payload_shorts, None):
+                    raise RuntimeError(lib.pcs_last_error(hr).decode())
+            for k in range(200):
+                launch_r(k % R)
+            torch.cuda.synchronize(dev)
+            kr = max(200, args.steps)
+            ctx_r.timer_begin()
+            for k in range(kr):
+                launch_r(k % R)
+            ctx_r.timer_end()
+            ms_r = ctx_r.timer_elapsed_ms() / kr
+            ach_r = set_points * ALGO_BYTES_PER_POINT / (ms_r * 1e-3) / 1e9
+            out["general_rotation"] = {"ms_per_step": round(ms_r, 5), "value": round(set_points / ms_r / 1e3, 1),
+                                       "achieved": round(ach_r, 1), "frac": round(ach_r / HBM_PEAK_GBS, 4),
+                                       "arithmetic": {0: "ieee", 1: "certified", 2: "certified+identityR", 3: "certified+noOverflow",
+                                                      4: "certified+identityR+noOverflow"}[min(ctx_r.stream_math(s) for s in range(S))],
+                                       "note": "same rasters and launch with a 1-degree depth->colour rotation (what real cameras "
+                                               "report); the headline configuration has R = I per SURVEY.md 8(d)"}
+            ctx_r.close()
         if world == 1 and not args.no_host_api:
             # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
             # pageable numpy memory like a caller of the reference's function would have. Never `value`.
