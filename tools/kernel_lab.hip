@@ -11,6 +11,7 @@
 #include "../pointcloud_stitching_amd/csrc/pcs_kernels.hip"
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -349,6 +350,7 @@ int main(int argc, char** argv)
     const int S = 8, W = 1280, H = 720, R = 6;
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
     const uint32_t N = (uint32_t)W * H;
+    const double rot_deg = argc > 4 ? atof(argv[4]) : 0.0;        // depth->colour rotation about (0.3,0.9,0.3)
     const float tf[8][12] = {
         {-0.69888007f, -0.32213748f, 0.63858757f, -2.229f, -0.71520905f, 0.32290986f, -0.61984291f, 2.918f, -0.00653159f, -0.88991947f, -0.45607091f, 0.364f},
         {-0.96127595f, 0.09045863f, -0.26031862f, 0.317f, 0.27558764f, 0.31552831f, -0.90801615f, 2.833f, 0.0f, -0.94459469f, -0.32823906f, 0.381f},
@@ -373,6 +375,16 @@ int main(int argc, char** argv)
         memset(&p, 0, sizeof p);
         memcpy(p.M, tf[s], sizeof p.M);
         p.R[0] = p.R[4] = p.R[8] = 1.0f; p.t[0] = 0.015f;
+        if (rot_deg != 0.0) {
+            const double a = rot_deg * 3.14159265358979 / 180.0, nrm = std::sqrt(0.3 * 0.3 + 0.9 * 0.9 + 0.3 * 0.3);
+            const double ax[3] = {0.3 / nrm, 0.9 / nrm, 0.3 / nrm};
+            const double K[3][3] = {{0, -ax[2], ax[1]}, {ax[2], 0, -ax[0]}, {-ax[1], ax[0], 0}};
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                double kk = 0; for (int k = 0; k < 3; k++) kk += K[i][k] * K[k][j];
+                const double rij = (i == j ? 1.0 : 0.0) + std::sin(a) * K[i][j] + (1 - std::cos(a)) * kk;
+                p.R[j * 3 + i] = (float)rij;           // column-major
+            }
+        }
         p.depth_scale = 0.001f;
         p.d_ppx = ppx; p.d_ppy = ppy; p.d_fx = p.d_fy = fx;
         p.c_fx = p.c_fy = fx; p.c_ppx = ppx; p.c_ppy = ppy;
@@ -390,7 +402,7 @@ int main(int argc, char** argv)
     const size_t skew = argc > 3 ? (size_t)atol(argv[3]) : 0;     // extra bytes between consecutive rasters
     uint8_t* slab = nullptr; size_t slab_off = 0;
     if (packed) CK(hipMalloc(&slab, (size_t)R * S * (5 * (size_t)N + 1024 + 2 * skew) + (size_t)R * S * N * 10 + 4096 + R * (skew + 256)));
-    printf("allocation mode: %s, skew %zu\n", packed ? "one packed slab" : "one hipMalloc per raster", skew);
+    printf("allocation mode: %s, skew %zu, depth->colour rotation %.2f deg\n", packed ? "one packed slab" : "one hipMalloc per raster", skew, rot_deg);
     std::vector<FramePtrs> ring(R);
     std::vector<uint8_t*> outs(R);
     std::vector<uint16_t> hd(N); std::vector<uint8_t> hc(3 * (size_t)N + 16);
