@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -533,6 +534,7 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
 
     pcs_ctx* c = new (std::nothrow) pcs_ctx;
     if (!c) return fail(nullptr, PCS_ERR_NOMEM, "host allocation failed");
+    try {      // no exception may cross the C ABI: host allocation failures become PCS_ERR_NOMEM
     c->device = cfg->device;
     c->n_streams = cfg->n_streams;
     c->flags = cfg->flags;
@@ -648,6 +650,11 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     }
     CREATE_CHK(hipMemcpy(c->d_params, c->h_params.data(), sizeof(StreamParams) * c->n_streams, hipMemcpyHostToDevice));
 #undef CREATE_CHK
+    } catch (const std::exception& ex) {
+        const int rc = fail(nullptr, PCS_ERR_NOMEM, "pcs_create: host allocation failed (%s)", ex.what());
+        pcs_destroy(c);
+        return rc;
+    }
     *out = c;
     return PCS_OK;
 }
@@ -813,7 +820,7 @@ int pcs_send_xyzrgb_pointcloud(pcs_ctx* c, int stream, const float* vertices, co
 // ---- fused a5+a2(+a7) ------------------------------------------------------------------------
 int pcs_process_frames_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                               int16_t* d_payload, size_t payload_shorts, int32_t* d_counts)
-{
+try {
     if (!c) return PCS_ERR_INVALID_ARG;
     if (!d_depth || !d_color || !d_payload) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
     for (int s = 0; s < c->n_streams; s++)
@@ -822,11 +829,13 @@ int pcs_process_frames_device(pcs_ctx* c, const uint16_t* const* d_depth, const 
         if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
     DeviceGuard guard(c->device);
     return run_fused_device(c, d_depth, d_color, d_payload, payload_shorts, d_counts);
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_device: host allocation failed (%s)", ex.what());
 }
 
 int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* const* color, int16_t* stitched,
                        size_t stitched_shorts, int write_header, int* points_per_stream, int* out_size_bytes)
-{
+try {
     if (!c) return PCS_ERR_INVALID_ARG;
     if (!depth || !color || !stitched) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
     DeviceGuard guard(c->device);
@@ -865,6 +874,8 @@ int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* 
     if (points_per_stream) for (int s = 0; s < c->n_streams; s++) points_per_stream[s] = h[s];
     if (out_size_bytes) *out_size_bytes = size;
     return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames: host allocation failed (%s)", ex.what());
 }
 
 int pcs_deproject(pcs_ctx* c, int stream, const uint16_t* depth, float* vertices, float* texcoords)
@@ -1024,7 +1035,7 @@ int pcs_kernel_timing(pcs_ctx* c, int enable)
 }
 
 int pcs_kernel_times_ms(pcs_ctx* c, float* ms, int capacity, int* n)
-{
+try {
     if (!c || !n || (capacity > 0 && !ms)) return PCS_ERR_INVALID_ARG;
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1037,6 +1048,8 @@ int pcs_kernel_times_ms(pcs_ctx* c, float* ms, int capacity, int* n)
     c->ev_pool.clear();
     *n = k;
     return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_kernel_times_ms: host allocation failed (%s)", ex.what());
 }
 
 int pcs_host_malloc(pcs_ctx* c, void** h_ptr, size_t bytes)
