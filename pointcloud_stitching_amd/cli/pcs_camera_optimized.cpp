@@ -8,7 +8,8 @@
 //               -e <file> (camera-to-world matrices instead of the ones pasted into the reference's sources)
 //
 //   -f takes "synth:<W>x<H>" (deterministic synthetic frames; the reference's bags are LFS stubs and
-//   need librealsense) or a .pcsraw dump (see pointcloud_stitching_amd/synthetic.py: write_pcsraw).
+//   need librealsense), a .pcsraw dump (see pointcloud_stitching_amd/synthetic.py: write_pcsraw) or a
+//   librealsense recording (.bag, read by pcs_bag.h — validated only against this repo's own writer).
 //   Without -f the reference grabs from a live RealSense camera; that needs librealsense and a camera,
 //   neither of which this build has: it says so and exits non-zero.
 #include <chrono>
@@ -24,6 +25,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include "pcs_bag.h"
 #include "pcs_synth.h"
 #include "pcs_wire.h"
 
@@ -40,7 +42,7 @@ static int client_sock = 0, sockfd = 0;
 
 static void print_usage()
 {
-    printf("\nUsage: pcs-camera-optimized -f <synth:WxH | frames.pcsraw> [-m] [-t n] [-c] [-s] [-n streams] [-g gpu]\n"
+    printf("\nUsage: pcs-camera-optimized -f <synth:WxH | frames.pcsraw | recording.bag> [-m] [-t n] [-c] [-s] [-n streams] [-g gpu]\n"
            "  -f <src>  frame source (synthetic generator or raw dump)\n"
            "  -s        send data to central camera server if available (TCP push on port 8000)\n"
            "  -m        use the MI355X HIP path (the reference's SIMD switch)\n"
@@ -100,7 +102,8 @@ struct FrameSource {
     std::vector<std::vector<uint8_t>> color;
     FILE* fp = nullptr;
     int frames_in_file = 0, W = 0, H = 0;
-    bool synth = false;
+    bool synth = false, bag = false;
+    pcs_bag::Recording rec;            // -f <recording.bag>: librealsense ROS bag (what the reference plays, :168-176)
 
     bool open(const char* spec)
     {
@@ -108,6 +111,13 @@ struct FrameSource {
             if (sscanf(spec + 6, "%dx%d", &W, &H) != 2 || W <= 0 || H <= 0) return false;
             synth = true;
             for (int s = 0; s < n_streams; s++) cfg.push_back(pcs_synth::stream_config(W, H, s, n_streams == 1));
+        } else if (strlen(spec) > 4 && strcmp(spec + strlen(spec) - 4, ".bag") == 0) {
+            std::string err;
+            if (!rec.open(spec, err)) { std::cerr << spec << ": " << err << std::endl; return false; }
+            bag = true; n_streams = 1; frames_in_file = rec.frames;
+            cfg.push_back(rec.config);
+            memcpy(cfg[0].cam_to_world, pcs_synth::stream_config(8, 8, 0, true).cam_to_world, sizeof cfg[0].cam_to_world);   // tf_mat :64-67
+            W = cfg[0].depth.width; H = cfg[0].depth.height;
         } else {
             fp = fopen(spec, "rb");
             if (!fp) return false;
@@ -132,6 +142,11 @@ struct FrameSource {
             return true;
         }
         if (frame >= frames_in_file) return false;          // the reference stops when the bag loops (:276)
+        if (bag) {
+            std::string err;
+            if (!rec.read(frame, depth[0], color[0], err)) { std::cerr << "frame " << frame << ": " << err << std::endl; return false; }
+            return true;
+        }
         for (int s = 0; s < n_streams; s++) {
             depth[s].resize((size_t)cfg[s].depth.width * cfg[s].depth.height);
             color[s].resize((size_t)cfg[s].color_stride * cfg[s].color.height);
@@ -148,7 +163,7 @@ int main(int argc, char** argv)
     signal(SIGINT, sigintHandler);
     if (filename == NULL) {
         std::cerr << "Live capture needs librealsense2 and a RealSense camera, which this build does not link.\n"
-                     "Use -f synth:<W>x<H> or -f <frames.pcsraw>." << std::endl;
+                     "Use -f synth:<W>x<H>, -f <frames.pcsraw> or -f <recording.bag>." << std::endl;
         return 2;
     }
     std::cout << "Reading Frames from File: " << filename << std::endl;

@@ -1,0 +1,173 @@
+"""pcs_bag.h (librealsense ROS-bag reader) against bags written by tests/bag_writer.py: container, LZ4
+chunks, message decoding, extrinsics composition, frame pairing, malformed input. The writer follows the
+published layouts; no real recording is available, so this pins reader == writer, not reader == librealsense."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from pointcloud_stitching_amd import synthetic as S
+from tests import bag_writer as BW
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI_DIR = os.path.join(ROOT, "pointcloud_stitching_amd", "cli")
+INFO = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-bag-info")
+CAM = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-camera-optimized")
+
+
+@pytest.fixture(scope="module")
+def tools():
+    subprocess.run(["make", "-C", CLI_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return INFO
+
+
+def fnv1a(b):
+    h = 1469598103934665603
+    for x in bytes(b):
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def frames_for(cfg, n, W, H):
+    out = []
+    for k in range(n):
+        out.append((S.synth_depth(W, H, 0, seed=S.SEED + 7919 * k), S.synth_color(W, H, 0, seed=S.SEED + 7919 * k)))
+    return out
+
+
+def info(tools, path, *extra):
+    r = subprocess.run([tools, path, *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    return r
+
+
+@pytest.mark.parametrize("compression", ["none", "lz4"])
+def test_reader_returns_what_the_writer_stored(tools, tmp_path, compression):
+    W, H = 64, 48
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    frames = frames_for(cfg, 5, W, H)
+    path = str(tmp_path / "rec.bag")
+    BW.write_bag(path, cfg, frames, depth_units=0.00025, compression=compression, frames_per_chunk=2)
+    r = info(tools, path)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout)
+    for name, intr in (("depth", cfg.depth), ("color", cfg.color)):
+        assert j[name]["width"] == intr.width and j[name]["height"] == intr.height
+        for k in ("fx", "fy", "ppx", "ppy"):
+            assert np.float32(j[name][k]) == np.float32(getattr(intr, k))
+        assert j[name]["model"] == intr.model
+    assert np.float32(j["depth_scale"]) == np.float32(0.00025)
+    assert j["color_bpp"] == 3 and j["color_stride"] == cfg.color_stride
+    assert j["rotation"] == [1, 0, 0, 0, 1, 0, 0, 0, 1] and j["translation"] == [0, 0, 0]
+    assert len(j["frames"]) == 5
+    for k, (d, c) in enumerate(frames):
+        assert j["frames"][k] == [fnv1a(d.tobytes()), fnv1a(c.tobytes())], k
+
+
+def test_lz4_chunks_are_really_compressed_and_decode(tools, tmp_path):
+    # a smooth raster compresses: exercises matches (incl. overlapping ones) in the decoder, not only literals
+    W, H = 96, 64
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    d = (np.arange(W * H, dtype=np.uint32) // 7 % 4000).astype(np.uint16).reshape(H, W)
+    c = np.zeros(cfg.color_stride * H, np.uint8); c[::5] = 200
+    pn, pl = str(tmp_path / "n.bag"), str(tmp_path / "l.bag")
+    BW.write_bag(pn, cfg, [(d, c)] * 3, compression="none")
+    BW.write_bag(pl, cfg, [(d, c)] * 3, compression="lz4")
+    assert os.path.getsize(pl) < os.path.getsize(pn) // 3
+    a, b = info(tools, pn), info(tools, pl)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert json.loads(a.stdout) == json.loads(b.stdout)
+    assert json.loads(a.stdout)["frames"][0] == [fnv1a(d.tobytes()), fnv1a(c.tobytes())]
+
+
+def test_extrinsics_are_composed_depth_to_colour(tools, tmp_path):
+    # colour -> reference (= depth): rotation of 90 deg about z, translation (0.1, 0.2, 0.3).
+    # depth -> colour must be the inverse: R^T, -R^T t; stored column-major like rs2_extrinsics.
+    W, H = 32, 24
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    s = np.sqrt(0.5)
+    BW.write_bag(str(tmp_path / "e.bag"), cfg, frames_for(cfg, 1, W, H), tf_color=((0.1, 0.2, 0.3), (0, 0, s, s)))
+    j = json.loads(info(tools, str(tmp_path / "e.bag")).stdout)
+    Rc = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], float)        # colour -> ref
+    R = Rc.T
+    t = -Rc.T @ np.array([0.1, 0.2, 0.3])
+    got_R = np.array(j["rotation"]).reshape(3, 3).T                   # column-major -> matrix
+    assert np.allclose(got_R, R, atol=1e-6) and np.allclose(j["translation"], t, atol=1e-6)
+
+
+def test_defaults_and_colour_pairing(tools, tmp_path):
+    W, H = 32, 24
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    frames = frames_for(cfg, 4, W, H)
+    # colour lags depth by 40 % of a frame period: nearest-in-time still pairs k with k
+    BW.write_bag(str(tmp_path / "p.bag"), cfg, frames, depth_units=None, color_lag_ns=13_000_000)
+    j = json.loads(info(tools, str(tmp_path / "p.bag")).stdout)
+    assert np.float32(j["depth_scale"]) == np.float32(0.001)          # option absent -> D400 default
+    assert [f[1] for f in j["frames"]] == [fnv1a(c.tobytes()) for _, c in frames]
+    # colour lags by 70 %: frame k's nearest colour image is k-1's (k >= 1)
+    BW.write_bag(str(tmp_path / "q.bag"), cfg, frames, color_lag_ns=23_400_000)
+    j = json.loads(info(tools, str(tmp_path / "q.bag")).stdout)
+    want = [fnv1a(frames[max(k - 1, 0)][1].tobytes()) for k in range(4)]
+    assert [f[1] for f in j["frames"]] == want
+
+
+def test_malformed_files_are_rejected_not_crashed(tools, tmp_path):
+    W, H = 32, 24
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    path = str(tmp_path / "ok.bag")
+    BW.write_bag(path, cfg, frames_for(cfg, 2, W, H), compression="lz4")
+    blob = open(path, "rb").read()
+    cases = {
+        "magic": b"#ROSBAG V1.2\n" + blob[13:],
+        "truncated": blob[: len(blob) * 2 // 3],
+        "bz2": blob.replace(b"compression=lz4", b"compression=bz2"),
+        "empty": b"",
+    }
+    # corrupt the first lz4 frame's payload: flip bytes inside the chunk body
+    at = blob.index(struct.pack("<I", 0x184D2204)) + 40
+    cases["lz4-corrupt"] = blob[:at] + bytes(255 - x for x in blob[at:at + 64]) + blob[at + 64:]
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".bag"))
+        open(p, "wb").write(data)
+        r = info(tools, p)
+        assert r.returncode == 1 and r.stderr.strip(), name
+    r = info(tools, str(tmp_path / "missing.bag"))
+    assert r.returncode == 1
+
+
+def test_convert_to_pcsraw_round_trips(tools, tmp_path):
+    W, H = 64, 48
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    frames = frames_for(cfg, 2, W, H)
+    BW.write_bag(str(tmp_path / "r.bag"), cfg, frames, compression="lz4")
+    raw = str(tmp_path / "r.pcsraw")
+    assert info(tools, str(tmp_path / "r.bag"), "-x", raw).returncode == 0
+    b = open(raw, "rb").read()
+    assert b[:8] == b"PCSRAW1\0" and struct.unpack("<ii", b[8:16]) == (1, 2)
+    import ctypes as C
+    off = 16 + C.sizeof(cfg)
+    for d, c in frames:
+        assert b[off:off + d.nbytes] == d.tobytes(); off += d.nbytes
+        assert b[off:off + c.nbytes] == c.tobytes(); off += c.nbytes
+    assert off == len(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compression", ["none", "lz4"])
+def test_camera_cli_plays_a_bag(tools, oracle, tmp_path, compression):
+    """`pcs-camera-optimized -f rec.bag -m` (the reference's config 1 invocation, readme.md:45-49): bit-exact
+    against the oracle on the frames stored in the recording, tf_mat as the extrinsic."""
+    W, H = 160, 120
+    cfg = S.synth_stream_config(W, H, 0, single=True)
+    frames = frames_for(cfg, 3, W, H)
+    path = str(tmp_path / "rec.bag")
+    BW.write_bag(path, cfg, frames, compression=compression)
+    out = str(tmp_path / "o.bin")
+    r = subprocess.run([CAM, "-f", path, "-m", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "### Total Frames = 3" in r.stdout and "### Video Frames H x W : 120 x 160" in r.stdout
+    want, _ = oracle.process_frames([cfg], [frames[2][0]], [frames[2][1]])
+    got = np.fromfile(out, dtype=np.uint8)[4:4 + want.nbytes].view(np.int16).reshape(-1, 5)
+    assert (got == want).all()
