@@ -163,7 +163,9 @@ def test_camera_cli_plays_a_bag(tools, oracle, tmp_path, compression):
     cfg = S.synth_stream_config(W, H, 0, single=True)
     frames = frames_for(cfg, 3, W, H)
     path = str(tmp_path / "rec.bag")
-    BW.write_bag(path, cfg, frames, compression=compression)
+    # the synthetic rig's depth -> colour extrinsic is R = I, t = (0.015, 0, 0): stored as colour -> reference = -t
+    t = [-float(cfg.depth_to_color.translation[k]) for k in range(3)]
+    BW.write_bag(path, cfg, frames, compression=compression, tf_color=(t, (0, 0, 0, 1)))
     out = str(tmp_path / "o.bin")
     r = subprocess.run([CAM, "-f", path, "-m", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
