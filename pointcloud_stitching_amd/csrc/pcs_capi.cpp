@@ -51,6 +51,7 @@ struct pcs_ctx {
     uint32_t*                       d_error = nullptr;
     uint32_t                        compact_seq = 0;
     bool                            single_pass_ok = true;     // cleared if a look-back ever timed out
+    bool                            compact_tickets = false;   // tile ids by atomic ticket instead of blockIdx
     bool                            dense_ok = false;          // every stream has n % 8 == 0
     bool                            any_ddist = false, any_cdist = false;
     std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 + identity R, 3/4 = 1/2 + no-overflow
@@ -370,16 +371,16 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
     if (single_pass) {
         if (!c->d_ticket) {
             HIPCHK(c, hipMalloc((void**)&c->d_ticket, sizeof(unsigned long long)));
-            HIPCHK(c, hipMalloc((void**)&c->d_desc, sizeof(uint64_t) * std::max<uint32_t>(c->total_tiles, 1)));
+            HIPCHK(c, hipMalloc((void**)&c->d_desc, sizeof(uint64_t) * ((size_t)c->total_tiles + PCS_MAX_STREAMS)));
             HIPCHK(c, hipMalloc((void**)&c->d_stream_end, sizeof(uint32_t) * c->n_streams));
             HIPCHK(c, hipMalloc((void**)&c->d_error, sizeof(uint32_t)));
             HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(unsigned long long), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * std::max<uint32_t>(c->total_tiles, 1), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * ((size_t)c->total_tiles + PCS_MAX_STREAMS), c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_error, 0, sizeof(uint32_t), c->stream));
         }
         c->compact_seq++;
         if ((c->compact_seq & 0x3FFFFFFFu) == 0) {       // generation wrapped: old descriptors could alias
-            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * std::max<uint32_t>(c->total_tiles, 1), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * ((size_t)c->total_tiles + PCS_MAX_STREAMS), c->stream));
             c->compact_seq++;
         }
         for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
@@ -393,9 +394,10 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
                 m = std::min(m, c->h_params[s0 + k].cert_fast);
             }
             CompactLaunch cl{};
-            cl.d_ticket = c->d_ticket; cl.ticket_base = c->tickets_issued;
+            cl.d_ticket = c->compact_tickets ? c->d_ticket : nullptr; cl.ticket_base = c->tickets_issued;
             cl.d_desc = c->d_desc + c->h_params[s0].tile_base;
             cl.d_stream_end = c->d_stream_end;
+            cl.d_stream_desc = c->d_desc + c->total_tiles;
             cl.d_chain_in = s0 > 0 ? c->d_stream_end + (s0 - 1) : nullptr;
             cl.d_error = c->d_error; cl.gen = c->compact_seq; cl.flags = c->flags;
             HIPCHK(c, launch_fused_compact(c->d_params, s0, nl, tiles, m >= 1 ? MathSel::Cert : MathSel::Ieee, fp, cl,
@@ -640,9 +642,12 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         }
         if (d_bad) (void)hipFree(d_bad);
     }
-    // The single-pass (decoupled look-back) compaction is correct but measured slower than the three-pass
-    // one on MI355X: opt-in for experiments only.
+    // Single-pass compaction (one launch, direct-sum placement): 27.3-28.6 us against 30.3-32.2 us
+    // for count + scan + emit on 8x720p, but its forward progress assumes workgroups are dispatched in
+    // blockIdx order (bounded waits + three-pass re-run catch a violation) -> opt-in. PCS_COMPACT_TICKETS=1
+    // hands tile ids out in start order instead (dispatch-order independent; the contended atomic makes it 63 us).
     { const char* e = getenv("PCS_COMPACT_SINGLE_PASS"); c->single_pass_ok = e && e[0] == '1'; }
+    { const char* e = getenv("PCS_COMPACT_TICKETS"); c->compact_tickets = e && e[0] == '1'; }
     c->math.resize(c->n_streams);
     for (int s = 0; s < c->n_streams; s++) {
         const StreamParams& q = c->h_params[s];

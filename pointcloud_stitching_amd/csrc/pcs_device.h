@@ -91,6 +91,7 @@ struct CompactLaunch {
     unsigned long long* d_ticket;       // device counter, never reset
     unsigned long long  ticket_base;    // tickets issued before this launch
     uint64_t*           d_desc;         // launch_tiles descriptors
+    uint64_t*           d_stream_desc;  // all streams: per-stream totals
     uint32_t*           d_stream_end;   // all streams
     const uint32_t*     d_chain_in;     // total of earlier launches of the same frame-set, or nullptr
     uint32_t*           d_error;

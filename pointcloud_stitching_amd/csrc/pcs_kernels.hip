@@ -401,6 +401,14 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t c, uint32_t& wa
     return inc - c;
 }
 
+// Wavefront-wide sum (every lane gets it).
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 64);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Point sources. A source hands each lane its 8 consecutive points of the tile.
 // ------------------------------------------------------------------------------------------------
@@ -680,23 +688,23 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
 
 // ------------------------------------------------------------------------------------------------
 // SINGLE-PASS ordered compaction (predicate active, stride 1): one launch instead of count + scan + emit,
-// and the Z16 raster is read once. Chained scan with decoupled look-back over ALL tiles of the launch
-// in (stream, tile) order, so the global exclusive prefix of a tile IS its output point index and the
-// camera-order concatenation (a7) falls out of the same scan.
+// and the Z16 raster is read once.
 //
 //  * Tile ids are handed out by an atomic ticket in the order workgroups START, never by blockIdx: a tile
-//    only ever waits for lower tickets, whose workgroups are already running and wait for nothing later
-//    -> no dependence on the (unspecified) dispatch order, no deadlock.
-//  * One 64-bit descriptor per tile: [63:34] launch generation, [33:32] status (1 = the tile's own count,
-//    2 = inclusive prefix), [31:0] value. Flag and payload travel in ONE naturally aligned 8-byte
-//    agent-scope relaxed store / load, so no separate release/acquire is needed, and stale descriptors of
-//    earlier launches read as "not ready" without clearing the array.
-//  * The first wavefront looks back 64 tiles at a time (ballot for the nearest inclusive prefix, sum the
-//    aggregates in front of it) while the other wavefronts already compute their records.
-//  * Every spin is bounded; on expiry the error word is set and the host re-runs the frame with the
+//    only ever waits for lower tickets, whose workgroups are already running -> no dependence on the
+//    (unspecified) dispatch order, no deadlock.
+//  * Every tile publishes ONE 64-bit descriptor {[63:34] launch generation, [33:32] ready, [31:0] kept
+//    count} as soon as it has counted — flag and payload travel in one naturally aligned agent-scope 8-byte
+//    store, stale descriptors of earlier launches read as "not ready", nothing is ever cleared.
+//  * Placement is a DIRECT SUM, not a chained scan: a tile adds up the counts of its own stream's earlier
+//    tiles (all 256 lanes stride over <= a few hundred descriptors) plus one total per earlier stream
+//    (published by that stream's last tile). Nobody waits on anything but first-level publications, which
+//    happen within the first microseconds of a workgroup's life; a chained look-back, which this replaces,
+//    crawled ~64 tiles per microsecond through ~1500 resident tiles (65-70 us per frame-set).
+//  * Every wait is bounded; on expiry the error word is set and the host re-runs the frame with the
 //    three-pass path.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kDescAggregate = 1u, kDescPrefix = 2u;
+constexpr uint32_t kDescReady = 1u;
 constexpr uint32_t kSpinLimit = 1u << 18;
 
 __device__ __forceinline__ uint64_t desc_pack(uint32_t gen, uint32_t status, uint32_t value)
@@ -704,49 +712,24 @@ __device__ __forceinline__ uint64_t desc_pack(uint32_t gen, uint32_t status, uin
     return ((uint64_t)((gen << 2) | status) << 32) | (uint64_t)value;
 }
 
-// Exclusive prefix of tile `gtile` (first wavefront only, all 64 lanes participate).
-__device__ __forceinline__ uint32_t lookback(const uint64_t* __restrict__ desc, uint32_t gen, int32_t gtile,
-                                             uint32_t chain, uint32_t* __restrict__ error)
+// Value of a descriptor once its writer has published it for this launch generation (bounded wait).
+__device__ __forceinline__ uint32_t desc_wait(const uint64_t* __restrict__ d, uint32_t gen, uint32_t* __restrict__ error)
 {
-    const int lane = threadIdx.x & 63;
-    uint32_t acc = 0;
-    int32_t base = gtile - 1;
-    for (;;) {
-        const int32_t idx = base - lane;                 // lane 0 = nearest predecessor
-        uint32_t value = 0;
-        uint64_t pmask = 0, need = ~0ull;
-        for (uint32_t spins = 0;; spins++) {
-            uint64_t d;
-            if (idx >= 0) d = __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else d = desc_pack(gen, kDescPrefix, chain);         // before the first tile: what earlier launches wrote
-            const uint32_t hi = (uint32_t)(d >> 32);
-            const uint32_t st = ((hi >> 2) == gen) ? (hi & 3u) : 0u;
-            value = (uint32_t)d;
-            const uint64_t rmask = __ballot(st != 0u);
-            pmask = __ballot(st == kDescPrefix);
-            const uint64_t first = pmask & (0ull - pmask);       // nearest inclusive prefix, if any
-            need = pmask ? (first | (first - 1ull)) : ~0ull;     // lanes up to and including it
-            if ((rmask & need) == need) break;
-            if (spins > kSpinLimit) {
-                if (lane == 0) atomicExch(error, 1u);
-                return 0u;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        uint32_t c = ((need >> lane) & 1ull) ? value : 0u;
-#pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
-        acc += c;
-        if (pmask) return acc;
-        base -= 64;
+    for (uint32_t spins = 0;; spins++) {
+        const uint64_t v = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t hi = (uint32_t)(v >> 32);
+        if ((hi >> 2) == gen && (hi & 3u) == kDescReady) return (uint32_t)v;
+        if (spins > kSpinLimit) { atomicExch(error, 1u); return 0u; }
+        __builtin_amdgcn_s_sleep(2);
     }
 }
 
 struct CompactArgs {
     unsigned long long* ticket;       // never reset; ticket_base = its value when this launch was enqueued
     unsigned long long  ticket_base;
-    uint64_t*           desc;         // one descriptor per tile of this launch
-    uint32_t*           stream_end;   // [stream] inclusive prefix at the stream's last tile
+    uint64_t*           desc;         // one descriptor per tile of this launch: the tile's kept count
+    uint64_t*           stream_desc;  // [stream] kept count of the whole stream (published by its last tile)
+    uint32_t*           stream_end;   // [stream] inclusive global prefix at the stream's last tile (plain, for counts)
     const uint32_t*     chain_in;     // output points written by earlier launches of this frame-set (or null)
     uint32_t*           error;
     uint32_t            gen;
@@ -760,11 +743,17 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t bcast[2];
+    __shared__ uint32_t psum[8];
+    __shared__ uint32_t bcast[1];
 
-    if (threadIdx.x == 0) bcast[0] = (uint32_t)(atomicAdd(a.ticket, 1ull) - a.ticket_base);
-    __syncthreads();
-    const uint32_t gtile = bcast[0];
+    uint32_t gtile;
+    if (a.ticket) {         // tile ids in workgroup START order (dispatch-order independent, but 3600 returning
+        if (threadIdx.x == 0) bcast[0] = (uint32_t)(atomicAdd(a.ticket, 1ull) - a.ticket_base);   // atomics on one line)
+        __syncthreads();
+        gtile = bcast[0];
+    } else {
+        gtile = blockIdx.x; // relies on in-order dispatch for progress; the bounded waits catch anything else
+    }
 
     // ticket -> (stream, tile): tiles are numbered stream-major
     int s = 0;
@@ -795,21 +784,13 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
     const uint32_t tile_kept = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     const uint32_t lane_first = before + ex;
 
-    if (wave == 0) {
-        const uint32_t chain = a.chain_in ? *a.chain_in : 0u;
-        if (lane == 0)
-            __hip_atomic_store(a.desc + gtile, desc_pack(a.gen, kDescAggregate, tile_kept), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t excl = lookback(a.desc, a.gen, (int32_t)gtile, chain, a.error);
-        if (lane == 0) {
-            __hip_atomic_store(a.desc + gtile, desc_pack(a.gen, kDescPrefix, excl + tile_kept), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            bcast[1] = excl;
-            if (t == tiles_s - 1) a.stream_end[stream0 + s] = excl + tile_kept;
-        }
-    }
+    // publish this tile's kept count as early as possible: later tiles only ever wait for this store
+    if (threadIdx.x == 0)
+        __hip_atomic_store(a.desc + gtile, desc_pack(a.gen, kDescReady, tile_kept), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 
-    // records for all 8 points, straight-line (the predicate only gates the staging below)
+    // records for all 8 points, straight-line (the predicate only gates the staging below); the tiles in
+    // front of this one publish their counts meanwhile
     Record rec[8];
     auto fill = [&](auto& cv) {
 #pragma unroll
@@ -827,9 +808,29 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
         ExactCvt exact;
         fill(exact);
     }
-    __syncthreads();
 
-    const uint32_t q_lo = bcast[1];                       // global output point index of the tile's first kept point
+    // placement: kept points of this stream's earlier tiles (<= a few hundred descriptors, all 256 lanes
+    // stride over them) + the totals of the earlier streams (published once by each stream's last tile).
+    // No chain: nobody waits for anything but first-level publications. (Issuing these loads before the
+    // records, to hide their round trip, measured 38-42 us instead of 27-29: most of the neighbours have not
+    // published yet at that point and everything is polled twice.)
+    uint32_t own = 0, tot = 0;
+    const uint32_t first = gtile - t;
+    for (uint32_t j = first + threadIdx.x; j < gtile; j += kBlockThreads) own += desc_wait(a.desc + j, a.gen, a.error);
+    if ((int)threadIdx.x < s) tot = desc_wait(a.stream_desc + stream0 + threadIdx.x, a.gen, a.error);
+    own = wave_sum(own);
+    tot = wave_sum(tot);
+    if (lane == 0) { psum[wave] = own; psum[4 + wave] = tot; }
+    __syncthreads();
+    const uint32_t own_excl = psum[0] + psum[1] + psum[2] + psum[3];
+    const uint32_t chain = a.chain_in ? *a.chain_in : 0u;
+    const uint32_t q_lo = chain + psum[4] + psum[5] + psum[6] + psum[7] + own_excl;   // global output point index
+    if (threadIdx.x == 0 && t == tiles_s - 1) {
+        __hip_atomic_store(a.stream_desc + stream0 + s, desc_pack(a.gen, kDescReady, own_excl + tile_kept), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        a.stream_end[stream0 + s] = q_lo + tile_kept;
+    }
+
     uint8_t* gdst = payload_bytes + (size_t)q_lo * PCS_POINT_BYTES;
     const uint32_t head = (uint32_t)((uintptr_t)gdst & 15u);
     uint32_t rank = lane_first;
@@ -1194,7 +1195,8 @@ hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n
 {
     if (n_launch <= 0 || launch_tiles == 0) return hipSuccess;
     CompactArgs a;
-    a.ticket = cl.d_ticket; a.ticket_base = cl.ticket_base; a.desc = cl.d_desc; a.stream_end = cl.d_stream_end;
+    a.ticket = cl.d_ticket; a.ticket_base = cl.ticket_base; a.desc = cl.d_desc; a.stream_desc = cl.d_stream_desc;
+    a.stream_end = cl.d_stream_end;
     a.chain_in = cl.d_chain_in; a.error = cl.d_error; a.gen = cl.gen & 0x3FFFFFFFu; a.flags = cl.flags;
     uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
     if (math != MathSel::Ieee)
