@@ -50,7 +50,7 @@ struct pcs_ctx {
     uint32_t*                       d_stream_end = nullptr;    // n_streams
     uint32_t*                       d_error = nullptr;
     uint32_t                        compact_seq = 0;
-    bool                            single_pass_ok = true;     // cleared if a look-back ever timed out
+    bool                            single_pass_ok = true;     // cleared if a placement wait ever timed out
     bool                            compact_tickets = false;   // tile ids by atomic ticket instead of blockIdx
     bool                            dense_ok = false;          // every stream has n % 8 == 0
     bool                            any_ddist = false, any_cdist = false;
@@ -860,7 +860,7 @@ try {
     if (rc) return rc;
     bool timed_out = false;
     if ((rc = take_compact_error(c, timed_out))) return rc;
-    if (timed_out) {      // a look-back spin expired: redo this frame-set with the count + scan + emit passes
+    if (timed_out) {      // a placement wait expired: redo this frame-set with the count + scan + emit passes
         rc = run_fused_device(c, c->s_depth.data(), c->s_color.data(), c->s_payload,
                               c->max_payload_points * PCS_POINT_SHORTS, c->d_counts, true);
         if (rc) return rc;
@@ -1002,7 +1002,7 @@ int pcs_synchronize(pcs_ctx* c)
     int rc = take_compact_error(c, timed_out);
     if (rc) return rc;
     if (timed_out)
-        return fail(c, PCS_ERR_HIP, "single-pass compaction: a look-back wait expired; the payload of the frame-set(s) since "
+        return fail(c, PCS_ERR_HIP, "single-pass compaction: a placement wait expired; the payload of the frame-set(s) since "
                     "the last pcs_synchronize is invalid — re-submit them (the context now uses the three-pass path)");
     return PCS_OK;
 }

@@ -453,11 +453,11 @@ def test_lazy_convert_redo_path(oracle):
 
 
 # ---------------------------------------------------------------------------------------------
-# single-pass ordered compaction (ticketed tiles + decoupled look-back)
+# single-pass ordered compaction (published tile counts + direct-sum placement)
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(params=["three_pass", "single_pass"])
 def compaction_path(request, monkeypatch):
-    """The three-pass path is the default; the single-pass (decoupled look-back) one is opt-in by environment."""
+    """The three-pass path is the default; the single-pass one is opt-in by environment."""
     if request.param == "single_pass":
         monkeypatch.setenv("PCS_COMPACT_SINGLE_PASS", "1")
     else:
