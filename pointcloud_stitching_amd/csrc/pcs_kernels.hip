@@ -62,7 +62,7 @@ __device__ __forceinline__ int32_t cvt_sat(float f)
 // Float->int conversion policies. The five conversions of a point (world x,y,z; colour column,row) are
 // consumed only as `& 0xFFFF` or as clamp(., 0, dim-1). Under those two uses the saturating hardware
 // convert differs from cvttss2si in exactly one case: f >= 2^31 (hardware INT_MAX, x86 INT_MIN); NaN
-// gives 0 vs INT_MIN, which agree both in the low 16 bits and after the clamp. LazyCvt therefore uses
+// gives 0 vs INT_MIN, which agree both in the low 16 bits and after the clamp. FastCvt therefore uses
 // the 1-instruction hardware convert and keeps a running maximum of everything it converted (v_max3
 // ignores NaN); the tile code re-does a lane's points with ExactCvt in the (practically never taken)
 // case that the maximum reached 2^31.
