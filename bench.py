@@ -443,6 +443,19 @@ def main():
                                        "note": "same rasters and launch with a 1-degree depth->colour rotation (what real cameras "
                                                "report); the headline configuration has R = I per SURVEY.md 8(d)"}
             ctx_r.close()
+        if world == 1 and args.mode != "pack":
+            # per-launch distribution (SURVEY.md 8d asks for median + min): a separate leg with a hipEvent pair
+            # around every launch, so the event records stay out of the timed region above
+            ctx.kernel_timing(True)
+            for k in range(300):
+                launch(k % R)
+            per = np.sort(ctx.kernel_times_ms())       # synchronises the stream
+            ctx.kernel_timing(False)
+            if per.size:
+                out["roofline"]["per_launch_ms"] = {"n": int(per.size), "median": round(float(np.median(per)), 5),
+                                                    "min": round(float(per[0]), 5), "p95": round(float(per[int(per.size * 0.95)]), 5),
+                                                    "note": "one hipEvent pair per launch (includes event overhead); "
+                                                            "avg_launch_ms above is the contract figure"}
         if world == 1 and not args.no_host_api:
             # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
             # pageable numpy memory like a caller of the reference's function would have. Never `value`.
@@ -459,8 +472,27 @@ def main():
                 a[...] = b
             po = ctx.host_array((2 + payload_shorts,), np.int16)
             tp = time_host(pd, pc, po)
+            # the two directions on their own (page-locked buffers), SURVEY.md 8d: "H2D/D2H reported separately"
+            d_tmp = ctx.device_malloc(payload_shorts * 2)
+            def time_copy(fn, reps=5):
+                fn()
+                t0c = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                return (time.perf_counter() - t0c) / reps
+            up_bytes = sum(a.nbytes for a in pd + pc)
+            def all_up():
+                o = 0
+                for a in pd + pc:
+                    ctx.memcpy_h2d(d_tmp + o, a); o += (a.nbytes + 255) & ~255
+            t_up = time_copy(all_up)
+            pay = po[2:]
+            t_dn = time_copy(lambda: ctx.memcpy_d2h(pay, d_tmp))
+            ctx.device_free(d_tmp)
             out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
                                "pinned_ms_per_step": round(tp * 1e3, 3), "pinned_value": round(set_points / tp / 1e6, 1),
+                               "h2d_ms": round(t_up * 1e3, 3), "h2d_GBps": round(up_bytes / t_up / 1e9, 1),
+                               "d2h_ms": round(t_dn * 1e3, 3), "d2h_GBps": round(pay.nbytes / t_dn / 1e9, 1),
                                "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous: H2D (36.9 MB) + kernel + D2H (73.7 MB) per "
                                "frame-set, with pageable host buffers and with buffers from pcs_host_malloc; bounded by the host link, "
                                "not by the kernel"}
