@@ -218,8 +218,9 @@ int   pcs_kernel_timing(pcs_ctx* ctx, int enable);
 int   pcs_kernel_times_ms(pcs_ctx* ctx, float* ms, int capacity, int* n);
 
 /* Page-locked host memory for the buffers that cross PCIe every frame (the reference mallocs its `buffer`
- * once, src/pcs-camera-optimized.cpp:157 — allocating it here instead lets the D2H of the payload run at
- * link speed instead of through the runtime's pageable bounce buffers). Plain host pointers otherwise. */
+ * once, src/pcs-camera-optimized.cpp:157). Optional: with long-lived, already-touched malloc'd buffers the
+ * ROCm runtime's pageable path measured within 3 % of this (2.25 vs 2.19 ms per 8x720p frame-set); what is
+ * expensive is handing over a freshly allocated buffer every call (first-touch page faults, 7.5 ms). */
 int   pcs_host_malloc(pcs_ctx* ctx, void** h_ptr, size_t bytes);
 int   pcs_host_free(pcs_ctx* ctx, void* h_ptr);
 
