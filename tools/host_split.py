@@ -1,3 +1,8 @@
+"""Host-pointer API (pcs_process_frames, PCIe both ways) by buffer kind — run on the GPU box:
+    python tools/host_split.py
+Shows that long-lived pageable buffers cost the same as page-locked ones (2.25 vs 2.19 ms per 8x720p
+frame-set on MI355X / ROCm 7.2) and that a freshly allocated output buffer per call is what is slow
+(first-touch page faults, ~7.5 ms). DESIGN.md section 11."""
 import time, numpy as np, sys
 sys.path.insert(0, '.')
 from pointcloud_stitching_amd.api import PcsContext
