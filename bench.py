@@ -473,6 +473,19 @@ def main():
                 a[...] = b
             po = ctx.host_array((2 + payload_shorts,), np.int16)
             tp = time_host(pd, pc, po)
+            # software-pipelined loop (pcs_submit_frames / pcs_collect_frames): upload of k+1 overlaps download of k
+            po2 = ctx.host_array((2 + payload_shorts,), np.int16)
+            def time_pipe(reps=8):
+                ta, tb = ctx.submit_frames(pd, pc), ctx.submit_frames(pd, pc)     # warm both slots
+                ctx.collect_frames(ta, po); ctx.collect_frames(tb, po2)
+                t0p = time.perf_counter()
+                t_prev = ctx.submit_frames(pd, pc)
+                for k in range(1, reps + 1):
+                    t_next = ctx.submit_frames(pd, pc) if k < reps else None
+                    ctx.collect_frames(t_prev, po if k & 1 else po2)
+                    t_prev = t_next
+                return (time.perf_counter() - t0p) / reps
+            tpipe = time_pipe()
             # the two directions on their own (page-locked buffers), SURVEY.md 8d: "H2D/D2H reported separately"
             d_tmp = ctx.device_malloc(payload_shorts * 2)
             def time_copy(fn, reps=5):
@@ -492,6 +505,7 @@ def main():
             ctx.device_free(d_tmp)
             out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
                                "pinned_ms_per_step": round(tp * 1e3, 3), "pinned_value": round(set_points / tp / 1e6, 1),
+                               "pipelined_ms_per_step": round(tpipe * 1e3, 3), "pipelined_value": round(set_points / tpipe / 1e6, 1),
                                "h2d_ms": round(t_up * 1e3, 3), "h2d_GBps": round(up_bytes / t_up / 1e9, 1),
                                "d2h_ms": round(t_dn * 1e3, 3), "d2h_GBps": round(pay.nbytes / t_dn / 1e9, 1),
                                "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous: H2D (36.9 MB) + kernel + D2H (73.7 MB) per "

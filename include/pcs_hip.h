@@ -175,6 +175,20 @@ int pcs_process_frames(pcs_ctx* ctx, const uint16_t* const* depth, const uint8_t
                        int16_t* stitched, size_t stitched_shorts, int write_header,
                        int* points_per_stream, int* out_size_bytes);
 
+/* Software-pipelined form of pcs_process_frames for frame loops (same inputs, same stitched layout, same
+ * bytes). pcs_submit_frames queues the uploads and the kernel(s) of one frame-set into one of
+ * PCS_PIPELINE_DEPTH device slots and returns a ticket; pcs_collect_frames waits for that frame-set and
+ * downloads it. Writing the loop as  submit(k+1); collect(k);  lets the upload of the next frame-set run
+ * while the previous payload downloads (PCIe is full duplex; the two directions use separate HIP streams).
+ * The overlap needs page-locked host buffers (pcs_host_malloc): with pageable memory the runtime copies
+ * synchronously and the pair simply costs what pcs_process_frames costs. depth[s] / color[s] must stay
+ * valid and unmodified until the matching collect returns. Tickets must be collected in submission order.
+ * PCS_ERR_CAPACITY from submit = all slots in flight (collect first).                              */
+#define PCS_PIPELINE_DEPTH 2
+int pcs_submit_frames(pcs_ctx* ctx, const uint16_t* const* depth, const uint8_t* const* color, int* ticket);
+int pcs_collect_frames(pcs_ctx* ctx, int ticket, int16_t* stitched, size_t stitched_shorts, int write_header,
+                       int* points_per_stream, int* out_size_bytes);
+
 /* Device-resident form: pointers are device pointers, d_payload is the PAYLOAD pointer
  * (no header), payload_shorts its capacity. d_counts (optional) receives n_streams+1 int32:
  * per-stream point counts followed by the total. Asynchronous on the context stream.

@@ -164,6 +164,39 @@ class PcsContext:
                                                  counts, C.byref(size)))
         return buf, [int(x) for x in counts], size.value
 
+    def submit_frames(self, depth: Sequence[np.ndarray], color: Sequence[np.ndarray]) -> int:
+        """Queue one frame-set (uploads + kernel) and return its ticket; see pcs_submit_frames. The arrays must be
+        C-contiguous uint16 / uint8 already (no conversion copy is made) and stay alive until collect_frames."""
+        if len(depth) != self.n_streams or len(color) != self.n_streams:
+            raise ValueError("need one depth and one colour raster per stream")
+        for s in range(self.n_streams):
+            d, c = depth[s], color[s]
+            if d.dtype != np.uint16 or c.dtype != np.uint8 or not d.flags["C_CONTIGUOUS"] or not c.flags["C_CONTIGUOUS"]:
+                raise ValueError("submit_frames wants contiguous uint16 depth and uint8 colour arrays")
+            if d.size != self.streams[s].n_points or c.size < self.streams[s].color_bytes:
+                raise ValueError(f"stream {s}: raster size mismatch")
+        dp = (C.c_void_p * self.n_streams)(*[_ptr(x) for x in depth])
+        cp = (C.c_void_p * self.n_streams)(*[_ptr(x) for x in color])
+        t = C.c_int(-1)
+        self._check(self._lib.pcs_submit_frames(self._h, dp, cp, C.byref(t)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[t.value] = (depth, color)          # keep the rasters alive
+        return t.value
+
+    def collect_frames(self, ticket: int, out: Optional[np.ndarray] = None,
+                       write_header: bool = True) -> Tuple[np.ndarray, List[int], int]:
+        buf = out if out is not None else np.zeros(HEADER_SHORTS + self.max_payload_shorts, np.int16)
+        if buf.dtype != np.int16 or not buf.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a contiguous int16 array")
+        counts = (C.c_int * self.n_streams)()
+        size = C.c_int(0)
+        try:
+            self._check(self._lib.pcs_collect_frames(self._h, int(ticket), _ptr(buf), buf.size, int(write_header),
+                                                     counts, C.byref(size)))
+        finally:
+            getattr(self, "_inflight", {}).pop(ticket, None)
+        return buf, [int(x) for x in counts], size.value
+
     def process_frames_device(self, d_depth: Sequence[int], d_color: Sequence[int], d_payload: int,
                               payload_shorts: int, d_counts: int = 0) -> None:
         """Asynchronous launch on device pointers (ints). See pcs_process_frames_device."""

@@ -82,6 +82,21 @@ struct pcs_ctx {
     int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
     uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
 
+    // pcs_submit_frames / pcs_collect_frames: device slots, download stream
+    struct PipeSlot {
+        uint8_t*               slab = nullptr;
+        std::vector<uint16_t*> depth;
+        std::vector<uint8_t*>  color;
+        int16_t*               payload = nullptr;
+        int32_t*               counts = nullptr;       // device, n_streams + 1
+        hipEvent_t             done = nullptr;
+        bool                   busy = false;
+        int                    ticket = -1;
+    };
+    PipeSlot                        pipe[PCS_PIPELINE_DEPTH];
+    hipStream_t                     dl_stream = nullptr;
+    int                             next_ticket = 0, next_collect = 0;
+
     std::string                     err;
 };
 
@@ -311,10 +326,9 @@ int ensure(pcs_ctx* c, T*& p, size_t& cap, size_t bytes)
     return PCS_OK;
 }
 
-// Lazily allocate the packed raster slab of the host-pointer entry points (sizes are fixed by the config).
-int ensure_rasters(pcs_ctx* c)
+// One slab for all streams' rasters, carved at 256-byte granularity (see the comment at s_slab).
+int alloc_raster_slab(pcs_ctx* c, uint8_t*& slab, std::vector<uint16_t*>& depth, std::vector<uint8_t*>& color)
 {
-    if (c->s_slab) return PCS_OK;
     const auto up = [](size_t b) { return (b + 16 + 255) & ~(size_t)255; };
     size_t total = 0;
     for (int s = 0; s < c->n_streams; s++)
@@ -322,15 +336,23 @@ int ensure_rasters(pcs_ctx* c)
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, total + 256);
     if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
-    c->s_slab = static_cast<uint8_t*>(q);
+    slab = static_cast<uint8_t*>(q);
+    depth.assign(c->n_streams, nullptr); color.assign(c->n_streams, nullptr);
     size_t off = 0;
     for (int s = 0; s < c->n_streams; s++) {
-        c->s_depth[s] = reinterpret_cast<uint16_t*>(c->s_slab + off);
+        depth[s] = reinterpret_cast<uint16_t*>(slab + off);
         off += up((size_t)c->h_params[s].n_points * sizeof(uint16_t));
-        c->s_color[s] = c->s_slab + off;
+        color[s] = slab + off;
         off += up(c->h_params[s].color_bytes);
     }
     return PCS_OK;
+}
+
+// Lazily allocate the packed raster slab of the host-pointer entry points (sizes are fixed by the config).
+int ensure_rasters(pcs_ctx* c)
+{
+    if (c->s_slab) return PCS_OK;
+    return alloc_raster_slab(c, c->s_slab, c->s_depth, c->s_color);
 }
 
 struct DeviceGuard {
@@ -671,6 +693,14 @@ void pcs_destroy(pcs_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (float* p : c->d_lut) if (p) (void)hipFree(p);
     if (c->s_slab) (void)hipFree(c->s_slab);
+    if (c->dl_stream) (void)hipStreamSynchronize(c->dl_stream);
+    for (auto& sl : c->pipe) {
+        if (sl.slab) (void)hipFree(sl.slab);
+        if (sl.payload) (void)hipFree(sl.payload);
+        if (sl.counts) (void)hipFree(sl.counts);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
                        c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
@@ -881,6 +911,88 @@ try {
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames: host allocation failed (%s)", ex.what());
+}
+
+// ---- software-pipelined host form ------------------------------------------------------------
+int pcs_submit_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* const* color, int* ticket)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!depth || !color || !ticket) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    for (int s = 0; s < c->n_streams; s++)
+        if (!depth[s] || !color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+    DeviceGuard guard(c->device);
+    pcs_ctx::PipeSlot* sl = nullptr;
+    for (auto& cand : c->pipe) if (!cand.busy) { sl = &cand; break; }
+    if (!sl) return fail(c, PCS_ERR_CAPACITY, "all %d pipeline slots are in flight: collect a frame-set first", PCS_PIPELINE_DEPTH);
+    if (!c->dl_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+    if (!sl->slab) {
+        int rc = alloc_raster_slab(c, sl->slab, sl->depth, sl->color);
+        if (rc) return rc;
+        const size_t max_bytes = c->max_payload_points * PCS_POINT_BYTES;
+        hipError_t e = hipMalloc((void**)&sl->payload, max_bytes + 256);
+        if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", max_bytes, hipGetErrorString(e));
+        e = hipMalloc((void**)&sl->counts, sizeof(int32_t) * (c->n_streams + 1));
+        if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+        HIPCHK(c, hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+    }
+    for (int s = 0; s < c->n_streams; s++) {
+        const StreamParams& P = c->h_params[s];
+        HIPCHK(c, hipMemcpyAsync(sl->depth[s], depth[s], (size_t)P.n_points * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sl->color[s], color[s], P.color_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    // the three-pass compaction only: its result never needs a host-side retry
+    int rc = run_fused_device(c, sl->depth.data(), sl->color.data(), sl->payload, c->max_payload_points * PCS_POINT_SHORTS,
+                              sl->counts, true);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(sl->done, c->stream));
+    sl->busy = true;
+    sl->ticket = c->next_ticket++;
+    *ticket = sl->ticket;
+    return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_submit_frames: host allocation failed (%s)", ex.what());
+}
+
+int pcs_collect_frames(pcs_ctx* c, int ticket, int16_t* stitched, size_t stitched_shorts, int write_header,
+                       int* points_per_stream, int* out_size_bytes)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!stitched) return fail(c, PCS_ERR_INVALID_ARG, "stitched is NULL");
+    pcs_ctx::PipeSlot* sl = nullptr;
+    for (auto& cand : c->pipe) if (cand.busy && cand.ticket == ticket) { sl = &cand; break; }
+    if (!sl) return fail(c, PCS_ERR_INVALID_ARG, "ticket %d is not in flight", ticket);
+    if (ticket != c->next_collect) return fail(c, PCS_ERR_INVALID_ARG, "tickets are collected in submission order: %d is next", c->next_collect);
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamWaitEvent(c->dl_stream, sl->done, 0));
+    std::vector<int32_t> h(c->n_streams + 1);
+    size_t total;
+    if (has_pred(c->flags)) {        // the payload size is data dependent: counts first
+        HIPCHK(c, hipMemcpyAsync(h.data(), sl->counts, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->dl_stream));
+        HIPCHK(c, hipStreamSynchronize(c->dl_stream));
+        total = (size_t)h[c->n_streams];
+    } else {
+        for (int s = 0; s < c->n_streams; s++) h[s] = (int32_t)((c->h_params[s].n_points + c->downsample - 1) / c->downsample);
+        total = c->max_payload_points;
+        h[c->n_streams] = (int32_t)total;
+    }
+    if (stitched_shorts < PCS_HEADER_SHORTS + total * PCS_POINT_SHORTS) {
+        (void)hipStreamSynchronize(c->dl_stream);
+        sl->busy = false; c->next_collect++;          // the frame-set is dropped; the slot is usable again
+        return fail(c, PCS_ERR_CAPACITY, "stitched buffer holds %zu shorts, %zu needed", stitched_shorts,
+                    PCS_HEADER_SHORTS + total * PCS_POINT_SHORTS);
+    }
+    if (total)
+        HIPCHK(c, hipMemcpyAsync(stitched + PCS_HEADER_SHORTS, sl->payload, total * PCS_POINT_BYTES, hipMemcpyDeviceToHost, c->dl_stream));
+    HIPCHK(c, hipStreamSynchronize(c->dl_stream));
+    sl->busy = false;
+    c->next_collect++;
+    const int32_t size = (int32_t)(total * PCS_POINT_BYTES);
+    if (write_header) std::memcpy(stitched, &size, sizeof size);
+    if (points_per_stream) for (int s = 0; s < c->n_streams; s++) points_per_stream[s] = h[s];
+    if (out_size_bytes) *out_size_bytes = size;
+    return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_collect_frames: host allocation failed (%s)", ex.what());
 }
 
 int pcs_deproject(pcs_ctx* c, int stream, const uint16_t* depth, float* vertices, float* texcoords)

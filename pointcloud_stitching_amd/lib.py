@@ -40,6 +40,8 @@ SYMBOLS = [
     ("pcs_process_frames", C.c_int,
      [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_process_frames_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _VP]),
+    ("pcs_submit_frames", C.c_int, [_VP, _P(_VP), _P(_VP), _P(C.c_int)]),
+    ("pcs_collect_frames", C.c_int, [_VP, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_deproject", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("pcs_stitch_device", C.c_int, [_VP, _P(_VP), _P(C.c_int), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_voxel_grid_device", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),

@@ -595,3 +595,60 @@ def test_adversarial_configurations_near_certificate_thresholds(oracle):
             d = first_diff(buf[2:2 + want.size].reshape(-1, 5), want)
             assert d is None, f"trial {trial} flags {flags}: {d}"
     assert 0 in seen and (seen - {0})             # both refused and accepted configurations occurred
+
+
+# ---------------------------------------------------------------------------------------------
+# software-pipelined host form (pcs_submit_frames / pcs_collect_frames)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submit_collect_pipeline_matches_synchronous_calls(oracle, flags, pinned):
+    cfgs, _, _ = S.synth_frame_set(3, 320, 240)
+    frames = [([S.synth_depth(320, 240, s, seed=500 + k) for s in range(3)],
+               [S.synth_color(320, 240, s, seed=500 + k) for s in range(3)]) for k in range(5)]
+    with PcsContext(cfgs, flags=flags) as ctx:
+        if pinned:                                             # what makes the two directions overlap
+            staged = []
+            for dep, col in frames:
+                pd = [ctx.host_array(d.shape, np.uint16) for d in dep]
+                pc = [ctx.host_array(c.shape, np.uint8) for c in col]
+                for a, b in zip(pd + pc, dep + col):
+                    a[...] = b
+                staged.append((pd, pc))
+            out = ctx.host_array((2 + ctx.max_payload_shorts,), np.int16)
+        else:
+            staged = frames
+            out = np.zeros(2 + ctx.max_payload_shorts, np.int16)
+        results = []
+        t_prev = ctx.submit_frames(*staged[0])
+        for k in range(1, len(staged) + 1):                   # submit(k+1); collect(k)
+            t_next = ctx.submit_frames(*staged[k]) if k < len(staged) else None
+            buf, counts, nbytes = ctx.collect_frames(t_prev, out)
+            results.append((buf[2:2 + nbytes // 2].reshape(-1, 5).copy(), counts, int(buf[:2].view(np.int32)[0]), nbytes))
+            t_prev = t_next
+    for k, (dep, col) in enumerate(frames):
+        want, wcounts = oracle.process_frames(cfgs, dep, col, flags)
+        got, counts, header, nbytes = results[k]
+        assert counts == wcounts and header == nbytes == want.nbytes, k
+        assert_same(got, want)
+
+
+def test_submit_collect_misuse_is_reported():
+    cfgs, depth, color = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        out = np.zeros(2 + ctx.max_payload_shorts, np.int16)
+        with pytest.raises(PcsError, match="not in flight"):
+            ctx.collect_frames(0, out)
+        t0 = ctx.submit_frames(depth, color)
+        t1 = ctx.submit_frames(depth, color)
+        with pytest.raises(PcsError, match="in flight"):      # PCS_PIPELINE_DEPTH = 2
+            ctx.submit_frames(depth, color)
+        with pytest.raises(PcsError, match="submission order"):
+            ctx.collect_frames(t1, out)
+        ctx.collect_frames(t0, out)
+        small = np.zeros(10, np.int16)
+        with pytest.raises(PcsError, match="stitched buffer"):
+            ctx.collect_frames(t1, small)
+        t2 = ctx.submit_frames(depth, color)                   # the slot of the dropped frame-set is free again
+        buf, counts, _ = ctx.collect_frames(t2, out)
+        assert counts == [64 * 48]
