@@ -426,10 +426,12 @@ def main():
                 dp, cp, outp = call_args[slot]
                 if lib.pcs_process_frames_device(hr, dp, cp, outp, payload_shorts, None):
                     raise RuntimeError(lib.pcs_last_error(hr).decode())
-            for k in range(200):
-                launch_r(k % R)
-            torch.cuda.synchronize(dev)
-            kr = max(200, args.steps)
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms / 2:      # same clock settling as the headline leg
+                for k in range(50):
+                    launch_r(k % R)
+                torch.cuda.synchronize(dev)
+            kr = max(400, args.steps)
             ctx_r.timer_begin()
             for k in range(kr):
                 launch_r(k % R)

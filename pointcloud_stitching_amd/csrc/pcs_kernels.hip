@@ -858,7 +858,7 @@ __global__ void pcs_counts_kernel(const uint32_t* __restrict__ stream_end, int n
 // ------------------------------------------------------------------------------------------------
 
 template <bool DDIST, bool CDIST, class Mth>
-__global__ __launch_bounds__(kBlockThreads)
+__global__ __launch_bounds__(kBlockThreads, 7)     // <= 72 VGPRs for every instantiation (one landed on 73 -> 6 waves/SIMD); A/B on one box: no measurable change, 8 spills and is slower
 void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp,
                             uint8_t* __restrict__ payload_bytes)
 {
