@@ -14,10 +14,15 @@
 //                      emits (index = ix + iy*dx + iz*dx*dy); PCL itself averages in float, so against
 //                      PCL 1.8 this is "parity unpinned" (+-1 LSB per field expected).
 //
-// Pipeline: keys (one kernel) -> rocPRIM radix sort of (48-bit key, point index) -> rocPRIM reduce_by_key
-// over a gather iterator with an integer accumulator -> finalize (one kernel). Integer sums make the
-// result independent of reduction order. Sorting/segmented reduction are library primitives (rocPRIM,
-// header-only in /opt/rocm/include); the per-point work around them is hand-written.
+// Pipeline: pre-aggregation (one hand-written kernel: a workgroup accumulates 8192 consecutive points — a few
+// image rows of one camera, which fall into few voxels — in an LDS hash table and appends one partial
+// accumulator per voxel it saw) -> rocPRIM radix sort of (key, partial index) over the PARTIALS, an order of
+// magnitude fewer than points for realistic leaves -> rocPRIM reduce_by_key over a gather iterator ->
+// finalize (one kernel). Integer sums
+// make the result independent of reduction order and of the (atomic-append) order of the partials.
+// Sorting/segmented reduction are library primitives (rocPRIM, header-only in /opt/rocm/include); the
+// per-point work around them is hand-written. The number of runs is read back once (one stream
+// synchronisation inside the call) because the library primitives take their size from the host.
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -36,6 +41,23 @@ struct VoxelPlus {
     __host__ __device__ VoxelAcc operator()(const VoxelAcc& a, const VoxelAcc& b) const
     {
         return VoxelAcc{a.sx + b.sx, a.sy + b.sy, a.sz + b.sz, a.r + b.r, a.g + b.g, a.b + b.b, a.n + b.n};
+    }
+};
+
+// What one workgroup of the pre-aggregation kernel knows about one voxel: the sums over its (<= 8192) points
+// that fall into it (|sum| <= 8192 * 32768 = 2^28 fits an int).
+struct VoxelPartial {
+    int          sx, sy, sz;
+    unsigned int r, g, b, n;
+};
+
+// partial index -> accumulator (the gather side of reduce_by_key)
+struct LoadPartial {
+    const VoxelPartial* part;
+    __host__ __device__ VoxelAcc operator()(unsigned int i) const
+    {
+        const VoxelPartial q = part[i];
+        return VoxelAcc{q.sx, q.sy, q.sz, q.r, q.g, q.b, q.n};
     }
 };
 
@@ -66,17 +88,120 @@ __device__ __forceinline__ unsigned int voxel_index_packed(int v, int leaf, unsi
     return (unsigned int)(q + (int)bias);                            // bias = ceil(32768/leaf) -> non-negative
 }
 
-__global__ __launch_bounds__(256)
-void pcs_voxel_keys_kernel(const int16_t* __restrict__ payload, unsigned int n, int leaf, unsigned int bits,
-                           unsigned int bias, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx)
+// Pre-aggregation. A workgroup (1024 lanes) takes 8192 consecutive points of the payload — a few image rows of
+// one camera, so they fall into few voxels — and accumulates them in an LDS hash table (2048 slots, open
+// addressing, 64-bit compare-and-swap on the key, 32-bit LDS adds on the seven sums). Points that find no slot
+// within kProbe probes (dense tiny leaves) are passed through as single-point partials. One returning global
+// atomic per workgroup reserves its slice of the partial arrays (3.6 k atomics for 30 M points); the order of
+// the partials does not matter (they are sorted next, and the sums are integers).
+constexpr int kAggThreads = 1024, kAggPerLane = 8, kSlots = 2048, kProbe = 12;
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+__global__ __launch_bounds__(kAggThreads)
+void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n, int leaf, unsigned int bits,
+                               unsigned int bias, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
+                               VoxelPartial* __restrict__ part, unsigned int* __restrict__ n_runs)
 {
-    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
-    const unsigned long long kx = voxel_index_packed(p[0], leaf, bias), ky = voxel_index_packed(p[1], leaf, bias),
-                             kz = voxel_index_packed(p[2], leaf, bias);
-    keys[i] = (kz << (2 * bits)) | (ky << bits) | kx;                // z major, x fastest; order == (z,y,x) voxel order
-    idx[i] = i;
+    __shared__ unsigned long long skey[kSlots];
+    __shared__ int          ssx[kSlots], ssy[kSlots], ssz[kSlots];
+    __shared__ unsigned int sr[kSlots], sg[kSlots], sb[kSlots], sn[kSlots];
+    __shared__ unsigned int wtot[kAggThreads / 64];
+    __shared__ unsigned int base_s;
+
+    for (int j = threadIdx.x; j < kSlots; j += kAggThreads) {
+        skey[j] = kEmptyKey;
+        ssx[j] = ssy[j] = ssz[j] = 0;
+        sr[j] = sg[j] = sb[j] = sn[j] = 0u;
+    }
+    __syncthreads();
+
+    const unsigned int tile0 = blockIdx.x * (unsigned)(kAggThreads * kAggPerLane);
+    unsigned int failed = 0;                                  // bit k: point k of this lane found no slot
+#pragma unroll
+    for (int k = 0; k < kAggPerLane; k++) {
+        const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;      // lane-contiguous records
+        if (i >= n) continue;
+        const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
+        const int x = p[0], y = p[1], z = p[2];
+        const unsigned int col = (unsigned short)p[3], blue = (unsigned short)p[4] & 0xFFu;
+        const unsigned long long kx = voxel_index_packed(x, leaf, bias), ky = voxel_index_packed(y, leaf, bias),
+                                 kz = voxel_index_packed(z, leaf, bias);
+        const unsigned long long key = (kz << (2 * bits)) | (ky << bits) | kx;   // z major, x fastest: (z,y,x) voxel order
+        // Large leaves: a whole wavefront (64 neighbouring pixels) often sits in ONE voxel, and 64 lanes adding to
+        // the same LDS words serialise. If the wavefront is complete and uniform, reduce across it and let lane 0 add.
+        int ax = x, ay = y, az = z;
+        unsigned int ar = col & 0xFFu, ag = col >> 8, ab = blue, an = 1u;
+        const bool uniform = __ballot(1) == ~0ull && __all(key == __shfl(key, 0, 64));
+        if (uniform) {
+#pragma unroll
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                ax += __shfl_xor(ax, ofs, 64); ay += __shfl_xor(ay, ofs, 64); az += __shfl_xor(az, ofs, 64);
+                ar += __shfl_xor(ar, ofs, 64); ag += __shfl_xor(ag, ofs, 64); ab += __shfl_xor(ab, ofs, 64);
+                an += __shfl_xor(an, ofs, 64);
+            }
+        }
+        const bool actor = !uniform || (threadIdx.x & 63) == 0;     // who probes and adds
+        unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 53);       // 11 bits
+        bool placed = false;
+        if (actor) {
+            for (int t = 0; t < kProbe; t++) {
+                const unsigned long long old = atomicCAS(&skey[h], kEmptyKey, key);
+                if (old == kEmptyKey || old == key) { placed = true; break; }
+                h = (h + 1u) & (unsigned)(kSlots - 1);
+            }
+            if (placed) {
+                atomicAdd(&ssx[h], ax); atomicAdd(&ssy[h], ay); atomicAdd(&ssz[h], az);
+                atomicAdd(&sr[h], ar); atomicAdd(&sg[h], ag); atomicAdd(&sb[h], ab);
+                atomicAdd(&sn[h], an);
+            }
+        }
+        if (uniform) placed = __shfl((int)placed, 0, 64) != 0;      // lane 0's verdict holds for the whole wavefront
+        if (!placed) failed |= 1u << k;
+    }
+    __syncthreads();
+
+    // every lane owns two slots; count what this workgroup will append: occupied slots + passed-through points
+    unsigned int c = __popc(failed);
+#pragma unroll
+    for (int q = 0; q < kSlots / kAggThreads; q++) c += skey[threadIdx.x * (kSlots / kAggThreads) + q] != kEmptyKey;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = c;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const unsigned int t = __shfl_up(inc, ofs, 64);
+        if (lane >= ofs) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int w = 0; w < kAggThreads / 64; w++) { const unsigned int t = wtot[w]; wtot[w] = tot; tot += t; }
+        base_s = tot ? atomicAdd(n_runs, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int pos = base_s + wtot[wave] + inc - c;
+#pragma unroll
+    for (int q = 0; q < kSlots / kAggThreads; q++) {
+        const int j = threadIdx.x * (kSlots / kAggThreads) + q;
+        if (skey[j] != kEmptyKey) {
+            keys[pos] = skey[j]; idx[pos] = pos;
+            part[pos] = VoxelPartial{ssx[j], ssy[j], ssz[j], sr[j], sg[j], sb[j], sn[j]};
+            pos++;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kAggPerLane; k++) {
+        if (!((failed >> k) & 1u)) continue;
+        const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;
+        const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
+        const int x = p[0], y = p[1], z = p[2];
+        const unsigned int col = (unsigned short)p[3], blue = (unsigned short)p[4] & 0xFFu;
+        const unsigned long long kx = voxel_index_packed(x, leaf, bias), ky = voxel_index_packed(y, leaf, bias),
+                                 kz = voxel_index_packed(z, leaf, bias);
+        keys[pos] = (kz << (2 * bits)) | (ky << bits) | kx; idx[pos] = pos;
+        part[pos] = VoxelPartial{x, y, z, col & 0xFFu, col >> 8, blue, 1u};
+        pos++;
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -104,14 +229,14 @@ size_t voxel_workspace_bytes(uint32_t n_points, size_t* sort_tmp, size_t* reduce
     size_t st = 0, rt = 0;
     unsigned long long* k = nullptr; unsigned int* v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, st, k, k, v, v, (size_t)n_points, 0u, 51u);
-    auto values = rocprim::make_transform_iterator(v, LoadPoint{nullptr});
+    auto values = rocprim::make_transform_iterator(v, LoadPartial{nullptr});
     VoxelAcc* agg = nullptr; unsigned int* cnt = nullptr;
     (void)rocprim::reduce_by_key(nullptr, rt, k, values, (size_t)n_points, k, agg, cnt, VoxelPlus{});
     if (sort_tmp) *sort_tmp = st;
     if (reduce_tmp) *reduce_tmp = rt;
     const size_t n = n_points;
-    // keys in/out, idx in/out, unique keys, aggregates, voxel count, temp
-    return 2 * n * 8 + 2 * n * 4 + n * 8 + n * sizeof(VoxelAcc) + 256 + ((st > rt ? st : rt) + 255);
+    // keys in/out, idx in/out, partials, aggregates, counters, temp (worst case: every point its own run / voxel)
+    return 2 * n * 8 + 2 * n * 4 + n * sizeof(VoxelPartial) + n * sizeof(VoxelAcc) + 512 + ((st > rt ? st : rt) + 255) + 8 * 256;
 }
 
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
@@ -131,25 +256,37 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
     unsigned long long* keys_b = (unsigned long long*)take(n * 8);
     unsigned int* idx_a = (unsigned int*)take(n * 4);
     unsigned int* idx_b = (unsigned int*)take(n * 4);
+    VoxelPartial* part = (VoxelPartial*)take(n * sizeof(VoxelPartial));
     VoxelAcc* agg = (VoxelAcc*)take(n * sizeof(VoxelAcc));
     unsigned int* nvox = (unsigned int*)take(256);
+    unsigned int* nruns = (unsigned int*)take(256);
     void* tmp = take(sort_tmp > reduce_tmp ? sort_tmp : reduce_tmp);
 
     const unsigned int bits = axis_bits(leaf_mm);
     const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
-    hipLaunchKernelGGL(pcs_voxel_keys_kernel, dim3((n_points + 255) / 256), dim3(256), 0, st, d_payload, n_points, leaf_mm,
-                       bits, bias, keys_a, idx_a);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipMemsetAsync(nruns, 0, sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
+    const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
+    const dim3 grid((n_points + per_block - 1) / per_block);
+    hipLaunchKernelGGL(pcs_voxel_partials_kernel, grid, dim3(kAggThreads), 0, st, d_payload, n_points, leaf_mm,
+                       bits, bias, keys_a, idx_a, part, nruns);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    unsigned int m = 0;                                  // the library primitives take their size from the host
+    e = hipMemcpyAsync(&m, nruns, sizeof m, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    if (m == 0 || m > n_points) return hipErrorUnknown;      // a workgroup appends at most one partial per point
     size_t s1 = sort_tmp;
-    e = rocprim::radix_sort_pairs(tmp, s1, keys_a, keys_b, idx_a, idx_b, n, 0u, 3u * bits, st);
+    e = rocprim::radix_sort_pairs(tmp, s1, keys_a, keys_b, idx_a, idx_b, (size_t)m, 0u, 3u * bits, st);
     if (e != hipSuccess) return e;
-    auto values = rocprim::make_transform_iterator(idx_b, LoadPoint{d_payload});
+    auto values = rocprim::make_transform_iterator(idx_b, LoadPartial{part});
     size_t s2 = reduce_tmp;
-    e = rocprim::reduce_by_key(tmp, s2, keys_b, values, n, keys_a /* unique keys, reuse */, agg, nvox, VoxelPlus{},
+    e = rocprim::reduce_by_key(tmp, s2, keys_b, values, (size_t)m, keys_a /* unique keys, reuse */, agg, nvox, VoxelPlus{},
                                rocprim::equal_to<unsigned long long>(), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pcs_voxel_finalize_kernel, dim3((n_points + 255) / 256), dim3(256), 0, st, agg, nvox, d_out, d_out_points);
+    hipLaunchKernelGGL(pcs_voxel_finalize_kernel, dim3((m + 255) / 256), dim3(256), 0, st, agg, nvox, d_out, d_out_points);
     return hipGetLastError();
 }
 
