@@ -81,6 +81,36 @@ def test_gpu_voxel_grid_matches_oracle(oracle, n, leaf, span):
 
 
 @pytest.mark.gpu
+def test_gpu_voxel_grid_preaggregation_paths(oracle):
+    """The pre-aggregation kernel's special paths: wavefront-uniform runs (reduced across the wavefront, lane 0
+    adds), the same with a FULL hash table (the whole wavefront must pass its points through), ragged tails."""
+    rng = np.random.default_rng(5)
+    n = 3 * 8192 + 777
+    p = np.zeros((n, 5), np.int16)
+    p[:, 3] = rng.integers(0, 65536, n).astype(np.uint16).view(np.int16)
+    p[:, 4] = rng.integers(0, 256, n)
+    # workgroup 0: 4096 points in distinct voxels fill the 2048-slot table, then 4096 points inside ONE new voxel
+    p[:4096, 0] = (np.arange(4096) % 64) * 100 - 3200
+    p[:4096, 1] = (np.arange(4096) // 64) * 100 - 3200
+    p[:4096, 2] = 0
+    p[4096:8192, :3] = rng.integers(20000, 20090, (4096, 3))
+    # workgroup 1: long runs, a few voxels in total (large-leaf case), with a run boundary inside a wavefront
+    p[8192:16384, 0] = np.repeat(np.arange(8192 // 500 + 1) * 100, 500)[:8192] - 900
+    p[8192:16384, 1:3] = rng.integers(0, 50, (8192, 2))
+    # workgroup 2 + ragged tail: image-like smooth surface with noise
+    m = n - 16384
+    p[16384:, 0] = np.linspace(-3000, 3000, m).astype(np.int16)
+    p[16384:, 1] = 5
+    p[16384:, 2] = 2000 + rng.integers(-8, 9, m)
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        for leaf in (100, 25, 3000):
+            got = ctx.voxel_grid(p, leaf)
+            want = oracle.voxel_grid(p, leaf)
+            assert got.shape == want.shape and (got == want).all(), leaf
+
+
+@pytest.mark.gpu
 def test_config5_pipeline_compaction_then_voxel_grid(oracle):
     """BASELINE configs[4] in miniature: 1080p-shaped streams, invalid-depth compaction, voxel grid on the
     stitched cloud — all on the device, compared end to end with the oracle."""
