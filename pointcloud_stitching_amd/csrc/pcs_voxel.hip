@@ -61,17 +61,6 @@ struct LoadPartial {
     }
 };
 
-// point index -> accumulator of that single point (the gather side of reduce_by_key)
-struct LoadPoint {
-    const int16_t* payload;
-    __host__ __device__ VoxelAcc operator()(unsigned int i) const
-    {
-        const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
-        const unsigned int c = (unsigned short)p[3];
-        return VoxelAcc{p[0], p[1], p[2], c & 0xFFu, c >> 8, (unsigned int)((unsigned short)p[4] & 0xFFu), 1u};
-    }
-};
-
 // Bits one axis needs: voxel indices run over 0 .. floor(32767/leaf) + ceil(32768/leaf) <= 65536/leaf + 1.
 // Packing the three axes into 3*bits (instead of a fixed 51) saves whole radix passes for realistic leaves.
 inline unsigned int axis_bits(int leaf)
