@@ -107,6 +107,9 @@ typedef struct pcs_stream_config {
 #define PCS_FLAG_DROP_INVALID   0x4u  /* drop depth==0 pixels (not in the reference; north-star compaction) */
 #define PCS_FLAG_FORCE_IEEE     0x8u  /* never use the certified reduced-instruction arithmetic (A/B testing);
                                          results are identical either way */
+#define PCS_FLAG_TEXCOORD_HALF_PIXEL 0x10u /* deprojection: u = (px + 0.5)/W, v = (py + 0.5)/H as older librealsense
+                                         releases computed texture coordinates; default is
+                                         u = px/W, v = py/H. The reference's +0.5 and clamp (:434-444) follow either way */
 
 typedef struct pcs_config {
     int32_t                  device;      /* HIP device ordinal */

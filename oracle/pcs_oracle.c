@@ -19,6 +19,13 @@ void pcs_oracle_deproject(const pcs_stream_config* sc, const uint16_t* depth,
     for (int r = 0; r < sc->depth.height; r++) pcs_o_deproject_row(sc, depth, r, vertices, texcoords);
 }
 
+void pcs_oracle_deproject_flags(const pcs_stream_config* sc, const uint16_t* depth, uint32_t flags,
+                                float* vertices, float* texcoords)
+{
+    const int half = (flags & PCS_FLAG_TEXCOORD_HALF_PIXEL) != 0;
+    for (int r = 0; r < sc->depth.height; r++) pcs_o_deproject_row_ex(sc, depth, r, vertices, texcoords, half);
+}
+
 /* -c predicate :398-401, :504-511 on CAMERA-frame z and x. */
 static int in_range(const float* vtx)
 {
@@ -132,7 +139,7 @@ int pcs_oracle_process_frames(const pcs_stream_config* streams, int n_streams,
         float* vtx = (float*)malloc(n * 3 * sizeof(float) + 16);
         float* tex = (float*)malloc(n * 2 * sizeof(float) + 16);
         if (!vtx || !tex) { free(vtx); free(tex); return -1; }
-        pcs_oracle_deproject(sc, depth[s], vtx, tex);
+        pcs_oracle_deproject_flags(sc, depth[s], flags, vtx, tex);
         int c = pcs_oracle_pack(sc, vtx, tex, (int)n, color[s], flags, downsample,
                                 payload + PCS_POINT_SHORTS * total);
         if (counts) counts[s] = c;

@@ -35,6 +35,9 @@ int32_t pcs_oracle_cvtt(float f);
 /* a5 restated: Z16 -> vertices[N*3], texcoords[N*2]. */
 void pcs_oracle_deproject(const pcs_stream_config* sc, const uint16_t* depth,
                           float* vertices, float* texcoords);
+/* same, honouring PCS_FLAG_TEXCOORD_HALF_PIXEL in flags (the older librealsense texcoord formula) */
+void pcs_oracle_deproject_flags(const pcs_stream_config* sc, const uint16_t* depth, uint32_t flags,
+                                float* vertices, float* texcoords);
 
 /* a2 restated: src/pcs-camera-optimized.cpp:363-616 (`-m`). flags = PCS_FLAG_*; downsample>=1
  * applies a7's stride to the kept sequence. Returns points written to out (5 shorts each). */

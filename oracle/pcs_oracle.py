@@ -72,13 +72,16 @@ def cvtt(f: float) -> int:
     return int(lib().pcs_oracle_cvtt(C.c_float(f)))
 
 
-def deproject(sc: StreamConfig, depth: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+def deproject(sc: StreamConfig, depth: np.ndarray, flags: int = 0) -> Tuple[np.ndarray, np.ndarray]:
     depth = np.ascontiguousarray(depth, dtype=np.uint16).reshape(-1)
     n = sc.n_points
     assert depth.size == n
     vtx = np.empty((n, 3), np.float32)
     tex = np.empty((n, 2), np.float32)
-    lib().pcs_oracle_deproject(C.byref(sc), _p(depth), _p(vtx), _p(tex))
+    L = lib()
+    L.pcs_oracle_deproject_flags.restype = None
+    L.pcs_oracle_deproject_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.pcs_oracle_deproject_flags(C.byref(sc), _p(depth), flags, _p(vtx), _p(tex))
     return vtx, tex
 
 

@@ -31,8 +31,8 @@ static inline int pcs_o_distortion_active(const pcs_intrinsics* in)
  * rs2_transform_point_to_point, rs2_project_point_to_pixel; pointcloud.cpp pixel_to_texcoord).
  * All products and sums are individually rounded, evaluated left to right. One raster row.
  * ------------------------------------------------------------------------------------------ */
-static inline void pcs_o_deproject_row(const pcs_stream_config* sc, const uint16_t* depth, int r,
-                                       float* vertices, float* texcoords)
+static inline void pcs_o_deproject_row_ex(const pcs_stream_config* sc, const uint16_t* depth, int r,
+                                          float* vertices, float* texcoords, int half_pixel)
 {
     const pcs_intrinsics* di = &sc->depth;
     const pcs_intrinsics* ci = &sc->color;
@@ -76,13 +76,20 @@ static inline void pcs_o_deproject_row(const pcs_stream_config* sc, const uint16
             }
             float px = x * ci->fx + ci->ppx;
             float py = y * ci->fy + ci->ppy;
-            /* pixel_to_texcoord */
+            /* pixel_to_texcoord; older librealsense releases: (pixel + 0.5) / size  (PCS_FLAG_TEXCOORD_HALF_PIXEL) */
+            if (half_pixel) { px = px + 0.5f; py = py + 0.5f; }
             u = px / wc;
             v = py / hc;
         }
         vertices[3 * i + 0] = X; vertices[3 * i + 1] = Y; vertices[3 * i + 2] = Z;
         texcoords[2 * i + 0] = u; texcoords[2 * i + 1] = v;
     }
+}
+
+static inline void pcs_o_deproject_row(const pcs_stream_config* sc, const uint16_t* depth, int r,
+                                       float* vertices, float* texcoords)
+{
+    pcs_o_deproject_row_ex(sc, depth, r, vertices, texcoords, 0);
 }
 
 /* colour lookup :431-452 - x = fma(u, W, .5); truncate; clamp; idx = x*bpp + y*stride */

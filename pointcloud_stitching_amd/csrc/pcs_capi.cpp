@@ -284,8 +284,8 @@ bool certify_no_overflow(const pcs_stream_config& s, const Certificate& c, const
         if (!(a * 1000.0 * infl < lim)) return false;
     }
     const double x = c.a_max[0] / c.p2_low * infl, y = c.a_max[1] / c.p2_low * infl;
-    const double xf = x * std::fabs((double)s.color.fx) * infl + std::fabs((double)s.color.ppx) + 1.0;
-    const double yf = y * std::fabs((double)s.color.fy) * infl + std::fabs((double)s.color.ppy) + 1.0;
+    const double xf = x * std::fabs((double)s.color.fx) * infl + std::fabs((double)s.color.ppx) + 2.0;   // + .5 rounding slack,
+    const double yf = y * std::fabs((double)s.color.fy) * infl + std::fabs((double)s.color.ppy) + 2.0;   // + .5 half-pixel option, + .5 of a2
     return xf * infl < lim && yf * infl < lim;
 }
 
@@ -455,7 +455,7 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             const StreamParams& q = c->h_params[s0 + k];
             fast &= q.cert_fast != 0; ident &= q.ident_r != 0; noovf &= q.no_overflow != 0;
             dd |= q.ddist != 0;
-            cd |= q.cdist != 0;
+            cd |= q.cdist != 0 || q.tex_half != 0;
         }
         const MathSel sel = !fast ? MathSel::Ieee
                           : noovf ? (ident ? MathSel::CertIdentRNoOvf : MathSel::CertNoOvf)
@@ -540,7 +540,8 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     if (cfg->n_streams < 1 || cfg->n_streams > PCS_MAX_STREAMS)
         return fail(nullptr, PCS_ERR_INVALID_ARG, "n_streams %d outside 1..%d", cfg->n_streams, PCS_MAX_STREAMS);
     if (cfg->downsample < 1) return fail(nullptr, PCS_ERR_INVALID_ARG, "downsample %d < 1", cfg->downsample);
-    if (cfg->flags & ~(PCS_FLAG_CUTOFF | PCS_FLAG_CUTOFF_COMPAT | PCS_FLAG_DROP_INVALID | PCS_FLAG_FORCE_IEEE))
+    if (cfg->flags & ~(PCS_FLAG_CUTOFF | PCS_FLAG_CUTOFF_COMPAT | PCS_FLAG_DROP_INVALID | PCS_FLAG_FORCE_IEEE |
+                       PCS_FLAG_TEXCOORD_HALF_PIXEL))
         return fail(nullptr, PCS_ERR_INVALID_ARG, "unknown flag bits 0x%x", cfg->flags);
     if ((cfg->flags & PCS_FLAG_CUTOFF_COMPAT) && !(cfg->flags & PCS_FLAG_CUTOFF))
         return fail(nullptr, PCS_ERR_INVALID_ARG, "PCS_FLAG_CUTOFF_COMPAT needs PCS_FLAG_CUTOFF");
@@ -591,13 +592,14 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         StreamParams& p = c->h_params[s];
         std::memset(&p, 0, sizeof p);
         fill_params(c->cfg[s], p);
+        p.tex_half = (c->flags & PCS_FLAG_TEXCOORD_HALF_PIXEL) ? 1 : 0;
         p.out_base = out_base;
         p.tile_base = tile_base;
         out_base += (p.n_points + c->downsample - 1) / c->downsample;
         tile_base += tiles_of(p.n_points);
         if (p.n_points % 8) c->dense_ok = false;
         c->any_ddist |= p.ddist != 0;
-        c->any_cdist |= p.cdist != 0;
+        c->any_cdist |= p.cdist != 0 || p.tex_half != 0;
         c->max_points = std::max(c->max_points, p.n_points);
         // deprojection LUTs: the IEEE divisions of rs2_deproject_pixel_to_point, once per column / row
         std::vector<float> mx(p.W), my(p.H);

@@ -338,8 +338,12 @@ __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32
         const float dy = bc_tangential(y, P.ck[3], P.ck[2], x, y, r2, y);
         x = dx; y = dy;
     }
-    const float px = __fadd_rn(__fmul_rn(x, P.c_fx), P.c_ppx);
-    const float py = __fadd_rn(__fmul_rn(y, P.c_fy), P.c_ppy);
+    float px = __fadd_rn(__fmul_rn(x, P.c_fx), P.c_ppx);
+    float py = __fadd_rn(__fmul_rn(y, P.c_fy), P.c_ppy);
+    if (CDIST && P.tex_half) {      // older librealsense pixel_to_texcoord: (pixel + 0.5) / size. Rides on the CDIST
+        px = __fadd_rn(px, 0.5f);   // instantiation (the host routes such streams there) so the common path pays nothing.
+        py = __fadd_rn(py, 0.5f);
+    }
     // pixel_to_texcoord; invalid depth (z == 0) -> texcoord (0,0). The quotients are computed
     // unconditionally and then selected: a conditional here becomes a divergent branch per pixel, which
     // stops the scheduler from interleaving the 8 pixels of a lane.
@@ -462,7 +466,7 @@ struct DepthSource {
             for (int k = 0; k < 8; k++) p[k] = PointIn{0, 0, 0, 0, 0};
             return;
         }
-        if ((DDIST || CDIST) && (P.ddist | P.cdist)) load8_impl<DDIST, CDIST>(P, i0, n, p);
+        if ((DDIST || CDIST) && (P.ddist | P.cdist | P.tex_half)) load8_impl<DDIST, CDIST>(P, i0, n, p);
         else load8_impl<false, false>(P, i0, n, p);
     }
     static constexpr bool kUsesLdsInput = false;
@@ -888,7 +892,7 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     if (tile0 >= n) return;
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
     uint32_t c;
-    if (flags == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
+    if ((flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
         // z = depth_scale * d is zero exactly when d is (the host checked the scale: finite, and scale*1 != 0):
         // count the non-zero Z16 values, no deprojection needed
         c = 0;

@@ -20,6 +20,7 @@ FLAG_CUTOFF = 0x1
 FLAG_CUTOFF_COMPAT = 0x2
 FLAG_DROP_INVALID = 0x4
 FLAG_FORCE_IEEE = 0x8
+FLAG_TEXCOORD_HALF_PIXEL = 0x10     # u = (px + 0.5)/W as older librealsense releases
 
 DISTORTION_NONE = 0
 DISTORTION_MODIFIED_BROWN_CONRADY = 1

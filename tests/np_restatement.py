@@ -60,7 +60,7 @@ def pack_np(sc, V, T, color):
     return out
 
 
-def deproject_np(sc, depth):
+def deproject_np(sc, depth, half_pixel=False):
     f32 = np.float32
     di, ci = sc.depth, sc.color
     W, H = di.width, di.height
@@ -78,6 +78,8 @@ def deproject_np(sc, depth):
         x = (P0 / P2).astype(f32); y = (P1 / P2).astype(f32)
         px = ((x * f32(ci.fx)).astype(f32) + f32(ci.ppx)).astype(f32)
         py = ((y * f32(ci.fy)).astype(f32) + f32(ci.ppy)).astype(f32)
+        if half_pixel:                      # PCS_FLAG_TEXCOORD_HALF_PIXEL: older librealsense pixel_to_texcoord
+            px = (px + f32(0.5)).astype(f32); py = (py + f32(0.5)).astype(f32)
         u = (px / f32(ci.width)).astype(f32); v = (py / f32(ci.height)).astype(f32)
     valid = Z != 0
     u = np.where(valid, u, f32(0)); v = np.where(valid, v, f32(0))

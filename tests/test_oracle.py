@@ -88,6 +88,30 @@ def test_numpy_restatement_agrees_deproject(oracle):
     assert (t1.view(np.uint32) == t2.view(np.uint32)).all()
 
 
+def test_half_pixel_texcoord_option(oracle):
+    """PCS_FLAG_TEXCOORD_HALF_PIXEL (older librealsense used (px + 0.5) / W): vertices are
+    untouched, valid texcoords move by half a pixel, invalid ones stay (0,0); the numpy restatement agrees; and the
+    pack then picks the pixel one to the right / below wherever the default picked floor(px + 0.5)."""
+    from pointcloud_stitching_amd.types import FLAG_TEXCOORD_HALF_PIXEL
+    cfgs, depth, color = S.synth_frame_set(1, 64, 48, single=True)
+    d = depth[0].copy()
+    d[0, :4] = [0, 1, 65535, 0]
+    v0, t0 = oracle.deproject(cfgs[0], d)
+    v1, t1 = oracle.deproject(cfgs[0], d, FLAG_TEXCOORD_HALF_PIXEL)
+    v2, t2 = deproject_np(cfgs[0], d, half_pixel=True)
+    assert (v0.view(np.uint32) == v1.view(np.uint32)).all()
+    assert (v1.view(np.uint32) == v2.view(np.uint32)).all() and (t1.view(np.uint32) == t2.view(np.uint32)).all()
+    valid = d.reshape(-1) != 0
+    assert (t1[~valid] == 0).all()
+    W, H = cfgs[0].color.width, cfgs[0].color.height
+    assert np.allclose((t1[valid, 0] - t0[valid, 0]) * W, 0.5, atol=1e-3)
+    assert np.allclose((t1[valid, 1] - t0[valid, 1]) * H, 0.5, atol=1e-3)
+    a, _ = oracle.process_frames(cfgs, [d], color)
+    b, _ = oracle.process_frames(cfgs, [d], color, FLAG_TEXCOORD_HALF_PIXEL)
+    assert (a[:, :3] == b[:, :3]).all()                  # coordinates do not depend on the texcoord convention
+    assert (a[:, 3:] != b[:, 3:]).any()                  # the colour lookup does
+
+
 def test_deproject_omp_is_bit_identical(oracle):
     cfgs, depth, _ = S.synth_frame_set(1, 640, 480, single=True)
     v1, t1 = oracle.deproject(cfgs[0], depth[0])
