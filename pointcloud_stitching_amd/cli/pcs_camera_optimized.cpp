@@ -6,6 +6,7 @@
 //   additions:  -g <dev>  -n <streams>  -d <stride>  -i (drop invalid depth)  -C (reference -c lane quirk)
 //               -r <frames>  -o <file> (dump last stitched buffer)  -p <port>
 //               -e <file> (camera-to-world matrices instead of the ones pasted into the reference's sources)
+//               -H (texture coordinates as older librealsense releases computed them: (pixel + 0.5) / size)
 //
 //   -f takes "synth:<W>x<H>" (deterministic synthetic frames; the reference's bags are LFS stubs and
 //   need librealsense), a .pcsraw dump (see pointcloud_stitching_amd/synthetic.py: write_pcsraw) or a
@@ -34,7 +35,7 @@ typedef std::chrono::duration<double, std::milli> timeMilli;
 
 static const char* filename = nullptr;
 static bool display_updates = false, send_buffer = false, cutoff = false, use_hip = false, compress = false;
-static bool cutoff_compat = false, drop_invalid = false, pull_mode = false;
+static bool cutoff_compat = false, drop_invalid = false, pull_mode = false, half_pixel = false;
 static int num_of_threads = 1, device = 0, n_streams = 1, downsample = 1, max_frames = 60, port = 8000;
 static const char* dump_path = nullptr;
 static const char* extrinsics_path = nullptr;
@@ -51,13 +52,14 @@ static void print_usage()
            "  -i        drop invalid-depth pixels   -d <n> keep every n-th point   -n <N> camera streams\n"
            "  -g <dev>  GPU ordinal   -r <frames>   -o <file> dump last stitched buffer   -p <port>\n"
            "  -P        serve frames on 'Z' pull requests (the live server's protocol) instead of pushing them\n"
-           "  -e <file> camera-to-world matrices, 16 row-major floats per line (python -m pointcloud_stitching_amd.calibration)\n\n");
+           "  -e <file> camera-to-world matrices, 16 row-major floats per line (python -m pointcloud_stitching_amd.calibration)\n"
+           "  -H        texture coordinates as older librealsense releases: (pixel + 0.5) / size\n\n");
 }
 
 static void parseArgs(int argc, char** argv)
 {
     int c;
-    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:e:P")) != -1) {
+    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:e:PH")) != -1) {
         switch (c) {
             case 'h': print_usage(); exit(0);
             case 'f': filename = optarg; break;
@@ -66,6 +68,7 @@ static void parseArgs(int argc, char** argv)
             case 't': num_of_threads = atoi(optarg); break;
             case 'c': cutoff = true; break;
             case 'C': cutoff = true; cutoff_compat = true; break;
+            case 'H': half_pixel = true; break;
             case 'm': use_hip = true; break;
             case 'z': compress = true; break;
             case 'g': device = atoi(optarg); break;
@@ -197,7 +200,8 @@ int main(int argc, char** argv)
     pcs_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.device = device; cfg.n_streams = n_streams; cfg.streams = src.cfg.data(); cfg.downsample = downsample;
-    cfg.flags = (cutoff ? PCS_FLAG_CUTOFF : 0u) | (cutoff_compat ? PCS_FLAG_CUTOFF_COMPAT : 0u) | (drop_invalid ? PCS_FLAG_DROP_INVALID : 0u);
+    cfg.flags = (cutoff ? PCS_FLAG_CUTOFF : 0u) | (cutoff_compat ? PCS_FLAG_CUTOFF_COMPAT : 0u) | (drop_invalid ? PCS_FLAG_DROP_INVALID : 0u) |
+                (half_pixel ? PCS_FLAG_TEXCOORD_HALF_PIXEL : 0u);
     pcs_ctx* ctx = nullptr;
     int rc = pcs_create(&ctx, &cfg);
     if (rc != PCS_OK) { std::cerr << "pcs_create: " << pcs_strerror(rc) << ": " << pcs_last_error(nullptr) << std::endl; return 1; }
