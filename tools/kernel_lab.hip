@@ -347,7 +347,10 @@ static uint32_t hhash(uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13
 
 int main(int argc, char** argv)
 {
-    const int S = 8, W = 1280, H = 720, R = 6;
+    // Ring of frame-sets: the INPUT rasters of the ring alone must exceed the 256 MiB Infinity Cache (36.9 MB per
+    // frame-set -> R >= 8), otherwise every read is served from it and the numbers are not HBM numbers. argv[5].
+    const int S = 8, W = 1280, H = 720;
+    const int R = argc > 5 ? atoi(argv[5]) : 16;
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
     const uint32_t N = (uint32_t)W * H;
     const double rot_deg = argc > 4 ? atof(argv[4]) : 0.0;        // depth->colour rotation about (0.3,0.9,0.3)

@@ -6,7 +6,7 @@ STEPS=${2:-200}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline"
+CMD="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-cache-leg --no-host-api"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 echo "stats rc=$?"
