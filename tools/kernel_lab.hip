@@ -54,6 +54,26 @@ void lab_fused_dense(const StreamParams* __restrict__ params, FramePtrs fp, uint
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
+// Product kernel with a staggered start: workgroups whose index has bits in `mask` sleep `units` x ~64 cycles first,
+// so that part of the chip is still reading while the rest already writes (de-phasing the two "waves" of
+// workgroups of an 8 x 720p launch).
+template <class Mth>
+__global__ __launch_bounds__(kBlockThreads, 7)
+void lab_fused_dense_stagger(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes,
+                             uint32_t mask, int units)
+{
+    __shared__ uint4 stage[kDenseStageBytes / 16];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    if ((blockIdx.x & mask) && blockIdx.y * gridDim.x + blockIdx.x < 1792u)      // first resident generation only
+        for (int k = 0; k < units; k++) __builtin_amdgcn_s_sleep(127);
+    DepthSource<false, false, Mth> src{fp.depth[s]};
+    dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
+}
+
 template <class Mth, int WAVES>
 __global__ __launch_bounds__(kBlockThreads, WAVES)
 void lab_fused_dense_lb(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes)
@@ -479,6 +499,12 @@ int main(int argc, char** argv)
         time_it("cert+identR, lb(256,7)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 7>)));
         time_it("cert+identR, lb(256,5)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 5>)));
         time_it("cert+identR, lb(256,4)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 4>)));
+        for (int units = 1; units <= 3; units++) {
+            char nm[64]; snprintf(nm, sizeof nm, "stagger odd tiles, %d x 3.4us", units);
+            time_it(nm, [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_stagger<CertIdentNoOvf>), grid, block, 0, st, dp, ring[r], o, 1u, units); });
+        }
+        time_it("stagger tiles&2, 1 x 3.4us", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_stagger<CertIdentNoOvf>), grid, block, 0, st, dp, ring[r], o, 2u, 1); });
+        time_it("stagger tiles&4, 1 x 3.4us", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_stagger<CertIdentNoOvf>), grid, block, 0, st, dp, ring[r], o, 4u, 1); });
         time_it("sloppy (inexact bound)", LAUNCH((lab::lab_fused_dense<lab::SloppyMath>)));
         time_it("memory skeleton", LAUNCH(lab::lab_memory_skeleton));
         time_it("skeleton, dependent gather", LAUNCH(lab::lab_skeleton_dependent));
