@@ -54,6 +54,67 @@ void lab_fused_dense(const StreamParams* __restrict__ params, FramePtrs fp, uint
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
+// PERSISTENT form of the product kernel: a workgroup walks tiles g, g + G, g + 2G ... (flat tile index over all
+// streams, equal-sized streams) and software-pipelines them: the raw Z16 vector of the NEXT tile is requested
+// before the current tile is deprojected, gathered, packed and stored, so the depth round trip of tile k+1
+// overlaps the colour round trip and the stores of tile k (what two overlapping launches achieve from outside).
+template <class Mth, int BLOCKS>
+__global__ __launch_bounds__(kBlockThreads, BLOCKS)
+void lab_fused_dense_persistent(const StreamParams* __restrict__ params, FramePtrs fp, uint8_t* __restrict__ payload_bytes,
+                                uint32_t tiles_per_stream, uint32_t total_tiles)
+{
+    __shared__ uint4 stage[kDenseStageBytes / 16];
+    uint32_t g = blockIdx.x;
+    if (g >= total_tiles) return;
+    uint32_t s = g / tiles_per_stream, t = g - s * tiles_per_stream;
+    uint32_t i0 = t * kTilePoints + threadIdx.x * 8;
+    uint4 dv = *reinterpret_cast<const uint4*>(fp.depth[s] + i0);
+    for (;;) {
+        const uint32_t gn = g + gridDim.x;
+        const bool more = gn < total_tiles;
+        uint32_t sn = 0, i0n = 0;
+        uint4 dvn = make_uint4(0, 0, 0, 0);
+        if (more) {                                            // request the next tile's depth first
+            sn = gn / tiles_per_stream;
+            i0n = (gn - sn * tiles_per_stream) * kTilePoints + threadIdx.x * 8;
+            dvn = *reinterpret_cast<const uint4*>(fp.depth[sn] + i0n);
+        }
+        const StreamParams& P = params[s];
+        const uint32_t n = P.n_points;
+        const uint8_t* __restrict__ color = fp.color[s];
+        // deproject the 8 pixels of this lane (fast path of DepthSource::load8_impl: one row, LUT vectors)
+        const uint32_t r = i0 / (uint32_t)P.W, c0 = i0 - r * (uint32_t)P.W;
+        const gptr<float> lut_x = as_global(P.mx);
+        const f32x4 ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
+        const f32x4 mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
+        const float my = as_global(P.my)[r];
+        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        const float mxs[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+        uint32_t w[20];
+        FastCvt<false> cv;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const uint32_t d0 = dw[k >> 1] & 0xFFFFu, d1 = dw[k >> 1] >> 16;
+            const PointIn p0 = deproject_pixel<false, false, Mth>(P, d0, mxs[k], my);
+            const PointIn p1 = deproject_pixel<false, false, Mth>(P, d1, mxs[k + 1], my);
+            const Record a = make_record(P, color, p0, cv);
+            const Record b = make_record(P, color, p1, cv);
+            uint32_t* o = w + (k >> 1) * 5;
+            o[0] = a.xy; o[1] = a.zc; o[2] = perm(b.xy, a.b, kLoLo); o[3] = perm(b.zc, b.xy, kHiLo); o[4] = perm(b.b, b.zc, kHiLo);
+        }
+        uint4* mine = stage + threadIdx.x * 5;
+#pragma unroll
+        for (int k = 0; k < 5; k++) mine[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        __syncthreads();
+        const uint32_t tile0 = i0 - threadIdx.x * 8;
+        store_staged(reinterpret_cast<const uint8_t*>(stage), 0u, min(kTilePoints, n - tile0) * PCS_POINT_BYTES,
+                     payload_bytes + ((size_t)P.out_base + tile0) * PCS_POINT_BYTES);
+        if (!more) break;
+        __syncthreads();                                       // the stage buffer is rewritten by the next tile
+        g = gn; s = sn; i0 = i0n; dv = dvn;
+    }
+}
+
 // Product kernel with a staggered start: workgroups whose index has bits in `mask` sleep `units` x ~64 cycles first,
 // so that part of the chip is still reading while the rest already writes (de-phasing the two "waves" of
 // workgroups of an 8 x 720p launch).
@@ -499,6 +560,13 @@ int main(int argc, char** argv)
         time_it("cert+identR, lb(256,7)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 7>)));
         time_it("cert+identR, lb(256,5)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 5>)));
         time_it("cert+identR, lb(256,4)", LAUNCH((lab::lab_fused_dense_lb<CertMath<true>, 4>)));
+        {
+            const uint32_t tps = (N + kTilePoints - 1) / kTilePoints, tot = tps * S;
+            for (uint32_t gsz : {1792u, 1800u, 1536u, 1200u, 900u}) {
+                char nm[64]; snprintf(nm, sizeof nm, "persistent noovf identR, grid %u", gsz);
+                time_it(nm, [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_persistent<CertIdentNoOvf, 7>), dim3(gsz), block, 0, st, dp, ring[r], o, tps, tot); });
+            }
+        }
         for (int units = 1; units <= 3; units++) {
             char nm[64]; snprintf(nm, sizeof nm, "stagger odd tiles, %d x 3.4us", units);
             time_it(nm, [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_stagger<CertIdentNoOvf>), grid, block, 0, st, dp, ring[r], o, 1u, units); });
@@ -548,6 +616,11 @@ int main(int argc, char** argv)
     {
         const dim3 g2(((N + 2047) / 2048 + 1) / 2, S);
         count_diff("cert+identR, 2 tiles/WG", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_2tiles<CertMath<true>>), g2, block, 0, st, dp, ring[r], o); });
+    }
+    {
+        const uint32_t tps = (N + kTilePoints - 1) / kTilePoints, tot = tps * S;
+        count_diff("persistent, grid 1800", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_persistent<CertIdentNoOvf, 7>), dim3(1800), block, 0, st, dp, ring[r], o, tps, tot); });
+        count_diff("persistent, grid 1200", [&](int r, uint8_t* o) { hipLaunchKernelGGL((lab::lab_fused_dense_persistent<CertIdentNoOvf, 7>), dim3(1200), block, 0, st, dp, ring[r], o, tps, tot); });
     }
     count_diff("cert (product)", LAUNCH((lab::lab_fused_dense<CertMath<false>>)));
     count_diff("cert + identity R (product)", LAUNCH((lab::lab_fused_dense<CertMath<true>>)));
