@@ -17,7 +17,7 @@ from oracle import pcs_oracle as O                                    # noqa: E4
 from pointcloud_stitching_amd import synthetic as S                    # noqa: E402
 from pointcloud_stitching_amd.api import PcsContext                    # noqa: E402
 from pointcloud_stitching_amd.types import (FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID,  # noqa: E402
-                                            FLAG_FORCE_IEEE)
+                                            FLAG_FORCE_IEEE, FLAG_TEXCOORD_HALF_PIXEL)
 from tests.test_gpu_parity import _random_config                       # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
@@ -40,7 +40,7 @@ while time.time() - t0 < budget:
         sd = int(rng.integers(0, 1 << 30))
         depth.append(S.synth_depth(w, h, s, seed=sd, mode="random" if rng.random() < 0.4 else "scene"))
         color.append(S.synth_color(cw, ch, s, seed=sd))
-    flags = FLAGS[rng.integers(0, len(FLAGS))]
+    flags = FLAGS[rng.integers(0, len(FLAGS))] | (FLAG_TEXCOORD_HALF_PIXEL if rng.random() < 0.25 else 0)
     ds = int(rng.choice([1, 1, 1, 2, 3, 7]))
     want, wcounts = O.process_frames(cfgs, depth, color, flags, ds)
     for extra in (0, FLAG_FORCE_IEEE):
