@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — Mpoints/s stitched for 8 x 1280x720 synthetic streams per GPU (BASELINE.json metric).
+"""bench.py — Mpoints/s stitched for 8 x 1280x720 synthetic streams (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the fused deproject -> transform -> RGB attach -> pack kernel over one
-frame-set (8 streams x 921 600 pixels) already resident in HBM, cycling through a ring of frame-sets
-whose INPUT rasters alone are more than twice the 256 MiB Infinity Cache (default: 16 sets = 590 MB of
-Z16+RGB8, 1.77 GB with the payloads), so every read really comes from HBM. (With a ring whose inputs fit the
-Infinity Cache — 6 sets = 221 MB — the same kernel reads 18.7 us instead of 23.6 us; that number is reported
-separately as `infinity_cache_resident_inputs` and is NOT the headline.)
-N > 1: every rank processes its own 8 streams per step (weak scaling) and the packed payloads are
-gathered to rank 0 over RCCL (double-buffered so the gather of step k overlaps the kernel of k+1).
-Rank 0 prints ONE JSON line.
+A "step" = one pass of the fused deproject -> transform -> RGB attach -> pack kernel over one frame-set
+already resident in HBM. The frame-sets live in a ring whose INPUT rasters alone are more than twice the
+256 MiB Infinity Cache, and ONE launch counter runs through pre-heat, warm-up and the timed region, so a
+slot is never re-read before at least 2 x 256 MiB of other inputs went by: every read comes from HBM.
+
+Workload (the default, `--scaling strong`): 8 streams IN TOTAL, 8/N per GPU.
+  N = 1  BASELINE.json configs[2]: 8 streams batched on one GPU (the metric's configuration).
+  N = 8  BASELINE.json configs[3]: one stream per GPU, the packed payloads gathered to rank 0 over RCCL/xGMI in
+         camera order (what /root/reference's src/pcs-multicamera-client.cpp:373-409 does over TCP).
+`--scaling weak` keeps 8 streams PER GPU (64 streams at N = 8) — not a BASELINE configuration, kept as an option.
+Rank 0 prints ONE JSON line. At N = 1 it also carries the other kernels' legs (ordered compaction, K frame-sets per
+launch, the batched a2 twin), each with its own algorithmic byte model, and the CPU baseline.
 """
 import argparse
 import ctypes as C
@@ -29,8 +32,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_POINT = 15            # 2 B Z16 + 3 B RGB8 + 10 B packed record
+PACK_BYTES_PER_POINT = 33            # a2 twin: 12 B vertex + 8 B texcoord + 3 B RGB8 + 10 B record
 HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X memory-side cache: a ring whose inputs fit it is not an HBM measurement
+POLICY = {0: "ieee", 1: "certified", 2: "certified+identityR", 3: "certified+noOverflow",
+          4: "certified+identityR+noOverflow"}
 
 
 def parse():
@@ -38,14 +44,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--streams", type=int, default=8, help="camera streams per GPU")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): --streams cameras IN TOTAL, sharded streams/N per GPU (BASELINE configs[2] at "
+                         "N=1, configs[3] at N=8); weak: --streams cameras PER GPU")
+    ap.add_argument("--streams", type=int, default=8, help="camera streams (total for strong scaling, per GPU for weak)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--ring", type=int, default=0,
-                    help="frame-sets resident in HBM (ring); default: enough that the input rasters alone are > 2x the "
-                         "256 MiB Infinity Cache (16 for 8 x 1280x720)")
+                    help="frame-sets resident in HBM (ring); default: enough that a slot is re-read only after > 2x the "
+                         "256 MiB Infinity Cache of other input rasters (16 for 8 x 1280x720)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="only the headline leg: skip compaction / batched / pack / cache-resident / two-stream / rotation legs")
     ap.add_argument("--no-cache-leg", action="store_true",
-                    help="skip the informational leg that re-times the kernel on a 6-set ring whose inputs fit the Infinity Cache")
+                    help="skip the informational legs (Infinity-Cache-resident ring, two HIP streams)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
@@ -57,8 +68,10 @@ def parse():
     ap.add_argument("--payload-skew", type=int, default=0,
                     help="diagnostic: offset the payload pointer by this many bytes (4 = the reference's buffer+2 shorts) "
                          "to force the generic (unaligned) store path")
-    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff", "pack"], default="dense",
-                    help="diagnostic: time the compaction path instead of the headline dense path")
+    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff", "pack", "pack_batch", "batch"], default="dense",
+                    help="diagnostic: make another kernel the headline of the line (for profiling one kernel at a time): "
+                         "the compaction path, the a2 twin per stream / batched, or K frame-sets per launch")
+    ap.add_argument("--batch-sets", type=int, default=4, help="frame-sets per launch of the batched-dense leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--preheat-ms", type=float, default=400.0,
                     help="untimed launches before the warm-up steps so clocks/power state settle (the first "
@@ -66,6 +79,36 @@ def parse():
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/traffic.json")
     return ap.parse_args()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    """Distinct (socket, core) pairs of /proc/cpuinfo — the host's PHYSICAL core count, SMT siblings not counted."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        return len(pairs) or None
+    except OSError:
+        return None
 
 
 def cpu_baseline(cfgs, depth, color, budget_s):
@@ -81,13 +124,19 @@ def cpu_baseline(cfgs, depth, color, budget_s):
     S = len(cfgs)
     npts = cfgs[0].n_points
     vt = [O.deproject(cfgs[s], depth[s]) for s in range(S)]
-    buf = np.zeros(5_000_000, np.int16)          # the reference's 10 MB buffer
+    # the reference's 5 000 000-short buffer (:157) holds 999 999 points; larger frames (1080p) would overflow it
+    # there — size ours from the geometry so the port measures the same work without corrupting the heap
+    buf_shorts = max(5_000_000, 2 + 5 * npts)
+    buf = np.zeros(buf_shorts, np.int16)
+
+    def send(cfg, v, t, col, threads):
+        if L.pcs_oracle_send_simd_omp(C.byref(cfg), v.ctypes.data, t.ctypes.data, npts, col.ctypes.data,
+                                      buf.ctypes.data, buf_shorts, threads) < 0:
+            raise RuntimeError("cpu baseline: buffer too small")
 
     def run_a(threads):
         for s in range(S):
-            v, t = vt[s]
-            L.pcs_oracle_send_simd_omp(C.byref(cfgs[s]), v.ctypes.data, t.ctypes.data, npts,
-                                       color[s].ctypes.data, buf.ctypes.data, threads)
+            send(cfgs[s], vt[s][0], vt[s][1], color[s], threads)
 
     vv = np.empty((npts, 3), np.float32); tt = np.empty((npts, 2), np.float32)
 
@@ -95,8 +144,7 @@ def cpu_baseline(cfgs, depth, color, budget_s):
         for s in range(S):
             d = np.ascontiguousarray(depth[s]).reshape(-1)
             L.pcs_oracle_deproject_omp(C.byref(cfgs[s]), d.ctypes.data, vv.ctypes.data, tt.ctypes.data, threads)
-            L.pcs_oracle_send_simd_omp(C.byref(cfgs[s]), vv.ctypes.data, tt.ctypes.data, npts,
-                                       color[s].ctypes.data, buf.ctypes.data, threads)
+            send(cfgs[s], vv, tt, color[s], threads)
 
     def best(fn, threads, share):
         fn(threads)                                # warm
@@ -106,9 +154,12 @@ def cpu_baseline(cfgs, depth, color, budget_s):
             t0 = time.perf_counter(); fn(threads); b = min(b, time.perf_counter() - t0); reps += 1
         return b, reps
 
-    # The reference's schedule(static,10000) splits a 720p frame into 24 chunks, so more than 24 threads
-    # cannot help it; sweep -t and report the best (thread counts beyond the cgroup's cores only thrash).
-    sweep = sorted({t for t in (1, 2, 4, 8, 12, 16, 24, 32) if t <= max(avail, 1)})
+    # The reference's schedule(static,10000) over its four-point iterations yields 24 chunks per 720p frame
+    # (230 400 / 10 000), so more than 24 threads cannot help it; the sweep still runs up to the PHYSICAL core count
+    # (thread counts beyond the cgroup's cores only thrash) and the best is reported.
+    phys = _physical_cores() or avail
+    cand = (1, 2, 4, 8, 12, 16, 24, 32, 48, 64)
+    sweep = sorted({t for t in cand if t <= max(min(avail, phys), 1)})
     share = budget_s / (2.0 * len(sweep))
     res_a = {t: best(run_a, t, share) for t in sweep}
     res_b = {t: best(run_b, t, share) for t in sweep}
@@ -127,19 +178,10 @@ def cpu_baseline(cfgs, depth, color, budget_s):
         "with_deprojection_value": round(pts / res_b[tb][0] / 1e6, 2),
         "with_deprojection_cores": tb,
         "with_deprojection_t1_value": round(pts / res_b[1][0] / 1e6, 2),
+        "host_physical_cores": phys,
         "host_logical_cpus": avail,
         "cpu_model": _cpu_model(),
     }
-
-
-def _cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
 
 
 def main():
@@ -156,7 +198,7 @@ def main():
     import torch.distributed as dist
     from pointcloud_stitching_amd import synthetic as Syn
     from pointcloud_stitching_amd.api import PcsContext
-    from pointcloud_stitching_amd.types import POINT_SHORTS
+    from pointcloud_stitching_amd.types import POINT_SHORTS, FLAG_CUTOFF, FLAG_DROP_INVALID
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
@@ -172,15 +214,27 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    S, W, H = args.streams, args.width, args.height
+    W, H = args.width, args.height
+    strong = args.scaling == "strong"
+    if strong:
+        if args.streams % world:
+            raise SystemExit(f"--scaling strong shards {args.streams} streams over {world} GPUs: not divisible")
+        S = args.streams // world            # cameras on this GPU
+        total_streams = args.streams
+    else:
+        S = args.streams
+        total_streams = args.streams * world
     in_bytes_per_set = S * (W * H * 2 + W * H * 3)
-    R = max(args.ring, 2) if args.ring else max(4, -(-2 * INFINITY_CACHE_BYTES // in_bytes_per_set) + 1)
+    # a slot is re-read after R-1 other sets: (R-1) * inputs > 2 x Infinity Cache
+    R = max(args.ring, 2) if args.ring else max(4, -(-2 * INFINITY_CACHE_BYTES // in_bytes_per_set) + 2)
+    ring_cold = (R - 1) * in_bytes_per_set >= 2 * INFINITY_CACHE_BYTES
+    if not args.ring:
+        assert ring_cold, "default ring must keep every re-read >= 2 x 256 MiB of input traffic apart"
     npts = W * H
     set_points = S * npts
     # global camera index = rank*S + s  -> extrinsic transform[(rank*S+s) % 8], distinct seeds per camera
     cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
-    from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_DROP_INVALID
-    mode_flags = {"dense": 0, "drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF, "pack": 0}[args.mode]
+    mode_flags = {"drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}.get(args.mode, 0)
     ctx = PcsContext(cfgs, device=local_rank, flags=mode_flags)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
@@ -214,6 +268,7 @@ def main():
         sk = args.payload_skew & ~1
         d_out.append(slab[off + sk:off + sk + payload_shorts * 2].view(torch.int16)); off += out_b
     ring_bytes = R * (set_points * ALGO_BYTES_PER_POINT)
+    kept_frac = float(np.mean([(d != 0).mean() for d in host0[0]]))      # rho of the invalid-drop compaction
 
     gather = world > 1 and not args.no_gather
     stitched = None
@@ -226,42 +281,100 @@ def main():
     lib = ctx._lib
     h = ctx._h
     VP = C.c_void_p
-    pack_args = None
-    if args.mode == "pack":
-        # a2 twin: copyPointCloudXYZRGBToBufferSIMD's inputs (vertices 12 B + texcoords 8 B per point) resident in HBM
-        # one copy per ring slot: re-using one set (147 MB for 8 x 720p) would keep it in the Infinity Cache
-        set_b = S * (up(npts * 12) + up(npts * 8))
-        vt_slab = torch.empty(R * set_b + 256, dtype=torch.uint8, device=dev)
-        vo = (-vt_slab.data_ptr()) % 256
-        pack_args = [[] for _ in range(R)]
-        for s in range(S):
-            v, t = ctx.deproject(s, host0[0][s])
-            hv = torch.from_numpy(v.reshape(-1).view(np.uint8)); ht = torch.from_numpy(t.reshape(-1).view(np.uint8))
-            for slot in range(R):
-                o = vo + slot * set_b
-                dv = vt_slab[o:o + npts * 12]; dv.copy_(hv if slot == 0 else vt_slab[vo:vo + npts * 12])
-                dt = vt_slab[o + up(npts * 12):o + up(npts * 12) + npts * 8]
-                dt.copy_(ht if slot == 0 else vt_slab[vo + up(npts * 12):vo + up(npts * 12) + npts * 8])
-                pack_args[slot].append((VP(dv.data_ptr()), VP(dt.data_ptr())))
-            vo += up(npts * 12) + up(npts * 8)
+
+    def check(rc, handle=None):
+        if rc:
+            raise RuntimeError(lib.pcs_last_error(handle or h).decode())
+
     call_args = []
     for slot in range(R):
         dp = (VP * S)(*[t.data_ptr() for t in d_depth[slot]])
         cp = (VP * S)(*[t.data_ptr() for t in d_color[slot]])
         call_args.append((dp, cp, VP(d_out[slot].data_ptr())))
 
-    def launch(slot):
-        dp, cp, out = call_args[slot]
-        if pack_args is not None:
+    # ---- the a2 twin's inputs (vertices 12 B + texcoords 8 B per point), one copy per ring slot -------------------
+    pack_ring = None
+
+    def build_pack_ring():
+        nonlocal pack_ring
+        if pack_ring is not None:
+            return pack_ring
+        from pointcloud_stitching_amd.types import CloudDesc
+        set_b = S * (up(npts * 12) + up(npts * 8))
+        # re-read distance as above, over everything the kernel reads (vertices + texcoords + colour)
+        Rp = max(3, -(-2 * INFINITY_CACHE_BYTES // (set_b + S * cfgs[0].color_bytes)) + 2)
+        Rp = min(Rp, R)
+        vt_slab = torch.empty(Rp * set_b + 256, dtype=torch.uint8, device=dev)
+        vo = (-vt_slab.data_ptr()) % 256
+        per_slot = [[] for _ in range(Rp)]
+        for s in range(S):
+            v, t = ctx0.deproject(s, host0[0][s])
+            hv = torch.from_numpy(v.reshape(-1).view(np.uint8)); ht = torch.from_numpy(t.reshape(-1).view(np.uint8))
+            for slot in range(Rp):
+                o = vo + slot * set_b
+                dv = vt_slab[o:o + npts * 12]; dv.copy_(hv if slot == 0 else vt_slab[vo:vo + npts * 12])
+                dt = vt_slab[o + up(npts * 12):o + up(npts * 12) + npts * 8]
+                dt.copy_(ht if slot == 0 else vt_slab[vo + up(npts * 12):vo + up(npts * 12) + npts * 8])
+                per_slot[slot].append((dv.data_ptr(), dt.data_ptr()))
+            vo += up(npts * 12) + up(npts * 8)
+        descs = []
+        for slot in range(Rp):
+            arr = (CloudDesc * S)()
             for s in range(S):
-                rc = lib.pcs_copy_pointcloud_xyzrgb_to_buffer_device(
-                    h, s, pack_args[slot][s][0], pack_args[slot][s][1], npts, cp[s], VP(out.value + s * npts * 10), None)
-                if rc:
-                    raise RuntimeError(lib.pcs_last_error(h).decode())
-            return
-        rc = lib.pcs_process_frames_device(h, dp, cp, out, payload_shorts, None)
-        if rc:
-            raise RuntimeError(lib.pcs_last_error(h).decode())
+                arr[s].stream, arr[s].n_points = s, npts
+                arr[s].vertices, arr[s].texcoords = per_slot[slot][s]
+                arr[s].color = d_color[slot][s].data_ptr()
+                arr[s].pc_buffer = d_out[slot].data_ptr() + s * npts * 10
+            descs.append(arr)
+        pack_ring = {"R": Rp, "slab": vt_slab, "per_slot": per_slot, "descs": descs}
+        return pack_ring
+
+    # a context without predicate flags for the legs that need the plain configuration (and for deproject)
+    ctx0 = ctx if mode_flags == 0 else PcsContext(cfgs, device=local_rank)
+    if ctx0 is not ctx:
+        ctx0.set_stream(stream.cuda_stream)
+
+    # ---- launch forms; ALL of them take the slot from one monotonically increasing counter ---------------------------
+    counter = [0]
+
+    def next_slot(ring=R):
+        k = counter[0]
+        counter[0] = k + 1
+        return k % ring
+
+    def launch_dense(handle=None):
+        dp, cp, out = call_args[next_slot()]
+        check(lib.pcs_process_frames_device(handle or h, dp, cp, out, payload_shorts, None), handle)
+
+    def launch_pack_single():
+        pr = build_pack_ring()
+        slot = next_slot(pr["R"])
+        for s in range(S):
+            check(lib.pcs_copy_pointcloud_xyzrgb_to_buffer_device(
+                ctx0._h, s, VP(pr["per_slot"][slot][s][0]), VP(pr["per_slot"][slot][s][1]), npts,
+                VP(d_color[slot][s].data_ptr()), VP(d_out[slot].data_ptr() + s * npts * 10), None), ctx0._h)
+
+    def launch_pack_batch():
+        pr = build_pack_ring()
+        slot = next_slot(pr["R"])
+        check(lib.pcs_copy_pointclouds_xyzrgb_to_buffer_device(ctx0._h, S, pr["descs"][slot], None), ctx0._h)
+
+    KB = max(1, min(args.batch_sets, R // 2))
+    batch_args = []
+    for g in range(R // KB):
+        slots = [g * KB + k for k in range(KB)]
+        dp = (VP * (KB * S))(*[t.data_ptr() for sl in slots for t in d_depth[sl]])
+        cp = (VP * (KB * S))(*[t.data_ptr() for sl in slots for t in d_color[sl]])
+        pp = (VP * KB)(*[d_out[sl].data_ptr() for sl in slots])
+        batch_args.append((dp, cp, pp))
+
+    def launch_batch():
+        dp, cp, pp = batch_args[next_slot(len(batch_args))]
+        check(lib.pcs_process_frames_device_batch(ctx0._h, KB, dp, cp, pp, payload_shorts, None), ctx0._h)
+
+    launch = {"dense": launch_dense, "drop_invalid": launch_dense, "cutoff": launch_dense, "pack": launch_pack_single,
+              "pack_batch": launch_pack_batch, "batch": launch_batch}[args.mode]
+    sets_per_launch = KB if args.mode == "batch" else 1
 
     pending = [None, None]
     red_dev = torch.device("cpu") if debug_gloo else dev      # where the tiny control reductions live
@@ -283,15 +396,18 @@ def main():
                 db[r * host.numel():(r + 1) * host.numel()].copy_(o)
         return _Done()
 
-    def step(k):
-        slot = k % R
+    step_no = [0]
+
+    def step():
         if gather:
+            k = step_no[0]; step_no[0] = k + 1
             if pending[k & 1] is not None:       # the buffer pair (slot's out, stitched[k&1]) is free again
                 pending[k & 1].wait()
-            launch(slot)
+            slot = counter[0] % R
+            launch()
             pending[k & 1] = gather_async(d_out[slot], stitched[k & 1] if rank == 0 else None)
         else:
-            launch(slot)
+            launch()
 
     def drain():
         for i in (0, 1):
@@ -303,8 +419,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def preheat(fn, ms):
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < ms:      # untimed: settle clocks
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize(dev)
+
+    def timed(fn, n, c=ctx):
+        """n launches of fn bracketed by a hipEvent pair on the launch stream -> ms per launch."""
+        c.timer_begin()
+        for _ in range(n):
+            fn()
+        c.timer_end()
+        return c.timer_elapsed_ms() / n
+
     # parity spot-check of slot 0 against the oracle before timing (bench must not time a wrong kernel)
-    launch(0); torch.cuda.synchronize(dev)
+    counter[0] = 0
+    launch(); torch.cuda.synchronize(dev)
     if rank == 0:
         from oracle import pcs_oracle as O
         want, _ = O.process_frames(cfgs[:1], host0[0][:1], host0[1][:1], mode_flags, 1)
@@ -312,17 +444,14 @@ def main():
         if (got != want).any():
             raise SystemExit("bench aborted: HIP output differs from the oracle")
 
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:      # untimed: settle clocks
-        for k in range(50):
-            launch(k % R)
-        torch.cuda.synchronize(dev)
+    preheat(launch, args.preheat_ms)
     gather_error = None
     if gather:
         # The exchange cannot be exercised on the single-GPU development boxes; if RCCL refuses it here the run
         # degrades to shard-only (and says so) instead of producing no line at all.
         try:
-            step(0); step(1); drain(); torch.cuda.synchronize(dev)
+            first_slot = counter[0] % R
+            step(); step(); drain(); torch.cuda.synchronize(dev)
             ok = torch.tensor([1], dtype=torch.int32, device=red_dev)
         except Exception as e:          # noqa: BLE001
             gather_error = f"{type(e).__name__}: {e}"[:300]
@@ -337,16 +466,16 @@ def main():
             gather_error = (gather_error or "") + f" | all_reduce: {e}"[:200]
         if rank == 0 and gather:
             # a7: rank r's payload must sit at [r*n, (r+1)*n) of the stitched buffer; rank 0's own slice is checkable here
-            own = stitched[1][:payload_shorts]
-            if not torch.equal(own, d_out[1 % R]):
+            own = stitched[0][:payload_shorts]
+            if not torch.equal(own, d_out[first_slot]):
                 raise SystemExit("bench aborted: gathered slice of rank 0 differs from its payload")
-    for k in range(args.warmup):
-        step(k)
+    for _ in range(args.warmup):
+        step()
     drain(); barrier()
     ctx.timer_begin()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    for _ in range(args.steps):
+        step()
     ctx.timer_end()
     drain(); barrier()
     elapsed = time.perf_counter() - t0
@@ -363,8 +492,8 @@ def main():
             barrier()
             t1 = time.perf_counter()
             ctx.timer_begin()
-            for k in range(args.steps):
-                launch(k % R)
+            for _ in range(args.steps):
+                launch()
             ctx.timer_end()
             barrier()
             shard_gpu_ms = ctx.timer_elapsed_ms()
@@ -376,15 +505,14 @@ def main():
     if traffic is None:
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("workload") == f"{S}x{W}x{H}":
+            if tj.get("workload") == f"{S}x{W}x{H}" and args.mode == "dense":
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/traffic.json (" + tj.get("tag", "?") + ")"
         except (OSError, ValueError, KeyError):
             traffic = None
-    policy = {0: "ieee", 1: "certified", 2: "certified+identityR", 3: "certified+noOverflow",
-              4: "certified+identityR+noOverflow"}[min(ctx.stream_math(s) for s in range(S))]
+    policy = POLICY[min(ctx.stream_math(s) for s in range(S))]
 
     if rank == 0:
-        total_points = set_points * world * args.steps
+        total_points = set_points * sets_per_launch * world * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
         kern_ms = gpu_ms / args.steps          # HIP-event bracket on the launch stream / launches
         roofline_timing = "hipEvent pair on the launch stream around the timed region / steps"
@@ -394,27 +522,43 @@ def main():
             kern_ms = shard_gpu_ms / args.steps
             roofline_timing = ("hipEvent pair on the launch stream around the same K launches WITHOUT the gather (rank 0); "
                                "the timed region's bracket includes waits for the exchange")
-        achieved = set_points * ALGO_BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9
+        bytes_pp = {"pack": PACK_BYTES_PER_POINT, "pack_batch": PACK_BYTES_PER_POINT,
+                    "drop_invalid": 5 + 10 * kept_frac}.get(args.mode, ALGO_BYTES_PER_POINT)
+        algo_bytes = set_points * sets_per_launch * bytes_pp
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        where = ("one GPU" if world == 1 else f"{world} GPUs, {S} per GPU") if strong else f"per GPU x {world} GPUs"
+        cfg_name = ("BASELINE.json configs[2]" if world == 1 else
+                    "BASELINE.json configs[3]" if (strong and S == 1 and total_streams == 8) else
+                    f"{total_streams} streams sharded {S}/GPU" if strong else "weak scaling (not a BASELINE configuration)")
         out = {
-            "metric": "Mpoints/s stitched (8x1280x720 streams per GPU: deproject+transform+RGB+pack)",
+            "metric": "Mpoints/s stitched (8x1280x720 streams: deproject+transform+RGB+pack)",
             "value": round(total_points / elapsed / 1e6, 1),
             "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S} synthetic {W}x{H} Z16+RGB8 streams per GPU, batched fused kernel, "
-                                   f"one extrinsic per stream (BASELINE.json configs[2])",
+            "config": {"workload": f"{total_streams} synthetic {W}x{H} Z16+RGB8 streams on {where}, batched fused kernel, "
+                                   f"one extrinsic per stream ({cfg_name})"
+                                   + (", payloads gathered to rank 0 in camera order" if gather else ""),
                        "arithmetic": "f32 deprojection + affine (bit-exact vs the -m path), u16 depth in, u8 colour in, int16 records out",
-                       "streams_per_gpu": S, "width": W, "height": H, "points_per_step_per_gpu": set_points,
+                       "streams_total": total_streams, "streams_per_gpu": S, "width": W, "height": H,
+                       "points_per_step_per_gpu": set_points * sets_per_launch,
                        "ring_frame_sets": R, "ring_mbytes": round(ring_bytes / 1e6, 1),
+                       "ring_inputs_between_rereads_mbytes": round((R - 1) * in_bytes_per_set / 1e6, 1),
+                       "ring_cold": bool(ring_cold),
                        "gather_to_rank0": bool(gather), "parallelism": f"streams sharded {S}/GPU x {world}"},
-            "per_stream_fps": round(args.steps / elapsed, 1),
+            "per_stream_fps": round(args.steps * sets_per_launch / elapsed, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src if traffic is not None else None,
-                         "kernel": "pcs_fused_dense_kernel", "arithmetic": policy, "avg_launch_ms": round(kern_ms, 5),
-                         "algorithmic_bytes_per_launch": set_points * ALGO_BYTES_PER_POINT,
+                         "kernel": {"dense": "pcs_fused_dense_kernel", "batch": "pcs_fused_dense_batch_kernel",
+                                    "pack": "pcs_pack_dense_kernel", "pack_batch": "pcs_pack_batch_kernel",
+                                    "drop_invalid": "pcs_fused_count_kernel + pcs_scan_kernel + pcs_fused_emit_kernel (PCS_COMPACT_PATH=single: pcs_fused_compact_kernel)",
+                                    "cutoff": "pcs_fused_count_kernel + pcs_scan_kernel + pcs_fused_emit_kernel (PCS_COMPACT_PATH=single: pcs_fused_compact_kernel)"}[args.mode],
+                         "arithmetic": policy, "avg_launch_ms": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": round(algo_bytes),
+                         "algorithmic_bytes_per_point": round(bytes_pp, 3),
                          "timing": roofline_timing},
         }
         if debug_gloo:
@@ -430,50 +574,106 @@ def main():
                                      "into the root, not by the kernel",
                              "shard_only_value": round(total_points / shard_only / 1e6, 1),
                              "shard_only_ms_per_step": round(shard_only * 1e3 / args.steps, 5)}
-        if args.mode == "pack":
-            out["config"]["mode"] = "pack (diagnostic: a2 twin from resident vertices/texcoords, one launch per stream, 33 B/point)"
-            out["roofline"]["achieved"] = round(set_points * 33 / (kern_ms * 1e-3) / 1e9, 1)
-            out["roofline"]["frac"] = round(out["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
-            out["roofline"]["kernel"] = "pcs_pack_dense_kernel"
-            out["roofline"]["algorithmic_bytes_per_launch"] = npts * 33
+        if args.mode != "dense":
+            out["config"]["mode"] = {
+                "pack": "diagnostic: a2 twin from resident vertices/texcoords, one launch per stream, 33 B/point",
+                "pack_batch": "diagnostic: a2 twin from resident vertices/texcoords, all streams in one launch, 33 B/point",
+                "batch": f"diagnostic: {KB} frame-sets per launch (pcs_process_frames_device_batch)",
+                "drop_invalid": f"diagnostic: ordered invalid-depth compaction, kept fraction {kept_frac:.4f}, (5 + 10 rho) B/point",
+                "cutoff": "diagnostic: ordered -c cutoff compaction (bytes priced as the dense kernel's 15 B/point: upper bound)",
+            }[args.mode]
             out["roofline"]["traffic"] = None
-        elif args.mode != "dense":
-            out["config"]["mode"] = args.mode + " (diagnostic: count + scan + emit passes; not the headline workload)"
-        if world == 1 and args.mode == "dense" and not args.no_cache_leg and R > 6:
+
+        extra = world == 1 and args.mode == "dense" and not args.no_extra_legs
+        n_leg = max(200, min(args.steps, 600))
+        if extra:
+            # ---- ordered compaction (invalid-depth drop, ~10 % of the synthetic pixels), cold ring --------------------
+            ctx_c = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
+            ctx_c.set_stream(stream.cuda_stream)
+            d_cnt = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+
+            def launch_c(cnt=None):
+                dp, cp, outp = call_args[next_slot()]
+                check(lib.pcs_process_frames_device(ctx_c._h, dp, cp, outp, payload_shorts, cnt), ctx_c._h)
+            launch_c(VP(d_cnt.data_ptr())); ctx_c.synchronize()
+            kept = int(d_cnt[S].item())
+            for _ in range(100):
+                launch_c()
+            torch.cuda.synchronize(dev)
+            ms_c = timed(launch_c, n_leg, ctx_c)
+            rho = kept / set_points
+            ach_c = set_points * (5 + 10 * rho) / (ms_c * 1e-3) / 1e9
+            out["compaction"] = {"ms_per_step": round(ms_c, 5), "value": round(set_points / ms_c / 1e3, 1), "unit": "Mpoints/s in",
+                                 "kept_fraction": round(rho, 4), "algorithmic_bytes_per_point": round(5 + 10 * rho, 3),
+                                 "achieved": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
+                                 "path": os.environ.get("PCS_COMPACT_PATH", "three (default: count + scan + emit)"),
+                                 "note": "PCS_FLAG_DROP_INVALID, order-preserving (= the reference's -c -m -t1 order), same cold ring; "
+                                         "bytes = 2 (Z16) + 3 (RGB8) + 10*rho (records)"}
+            ctx_c.close()
+            # ---- K frame-sets per launch (throughput form of the dense path) --------------------------------------------
+            if KB >= 2:
+                for _ in range(30):
+                    launch_batch()
+                torch.cuda.synchronize(dev)
+                ms_b = timed(launch_batch, max(50, n_leg // KB), ctx0) / KB
+                ach_b = set_points * ALGO_BYTES_PER_POINT / (ms_b * 1e-3) / 1e9
+                out["batched_dense"] = {"frame_sets_per_launch": KB, "ms_per_frame_set": round(ms_b, 5),
+                                        "value": round(set_points / ms_b / 1e3, 1), "achieved": round(ach_b, 1),
+                                        "frac": round(ach_b / HBM_PEAK_GBS, 4),
+                                        "note": "pcs_process_frames_device_batch: the same tiles, K frame-sets share one launch's "
+                                                "fill and drain; a throughput figure (latency of a frame-set = the whole launch), "
+                                                "NOT the headline value"}
+            # ---- the a2 twin, one launch per camera vs all cameras in one launch -----------------------------------------
+            for _ in range(20):
+                launch_pack_batch()
+            torch.cuda.synchronize(dev)
+            ms_pb = timed(launch_pack_batch, max(50, n_leg // 2), ctx0)
+            for _ in range(10):
+                launch_pack_single()
+            torch.cuda.synchronize(dev)
+            ms_ps = timed(launch_pack_single, max(30, n_leg // 4), ctx0)
+            out["pack_twin"] = {"batched_ms_per_frame_set": round(ms_pb, 5),
+                                "batched_achieved": round(set_points * PACK_BYTES_PER_POINT / (ms_pb * 1e-3) / 1e9, 1),
+                                "batched_frac": round(set_points * PACK_BYTES_PER_POINT / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "per_stream_launches_ms_per_frame_set": round(ms_ps, 5),
+                                "per_stream_launches_frac": round(set_points * PACK_BYTES_PER_POINT / (ms_ps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_point": PACK_BYTES_PER_POINT, "ring_frame_sets": pack_ring["R"],
+                                "note": "copyPointCloudXYZRGBToBufferSIMD's twin on device-resident rs2::points arrays "
+                                        "(12 B vertex + 8 B texcoord + 3 B RGB in, 10 B out): pcs_copy_pointclouds_xyzrgb_to_buffer_device "
+                                        "(one launch for all cameras) vs pcs_copy_pointcloud_xyzrgb_to_buffer_device per camera"}
+        if extra and not args.no_cache_leg and R > 6:
             # Informational: the same launches on a ring of 6 frame-sets, whose input rasters (221 MB for 8 x 720p) fit the
             # 256 MiB Infinity Cache — what the kernel reads when its inputs were produced or touched on the GPU just
             # before (and what an under-sized ring silently measures). NOT an HBM figure, NOT `value`.
-            for k in range(600):
-                launch(k % 6)
+            def launch6():
+                dp, cp, outp = call_args[next_slot(6)]
+                check(lib.pcs_process_frames_device(h, dp, cp, outp, payload_shorts, None))
+            for _ in range(600):
+                launch6()
             torch.cuda.synchronize(dev)
-            kc = max(400, args.steps)
-            ctx.timer_begin()
-            for k in range(kc):
-                launch(k % 6)
-            ctx.timer_end()
-            ms_c = ctx.timer_elapsed_ms() / kc
+            ms_c6 = timed(launch6, max(400, args.steps))
             out["infinity_cache_resident_inputs"] = {
-                "ms_per_step": round(ms_c, 5), "value": round(set_points / ms_c / 1e3, 1),
-                "algorithmic_GBps": round(set_points * ALGO_BYTES_PER_POINT / (ms_c * 1e-3) / 1e9, 1),
+                "ms_per_step": round(ms_c6, 5), "value": round(set_points / ms_c6 / 1e3, 1),
+                "algorithmic_GBps": round(set_points * ALGO_BYTES_PER_POINT / (ms_c6 * 1e-3) / 1e9, 1),
                 "ring_frame_sets": 6, "input_mbytes": round(6 * in_bytes_per_set / 1e6, 1),
                 "note": "inputs served by the 256 MiB Infinity Cache, payload written to HBM; informational, not a roofline fraction"}
-        if world == 1 and args.mode == "dense" and not args.no_cache_leg:
+        if extra and not args.no_cache_leg:
             # Informational: the same cold launches alternated over two HIP streams (two contexts), so the drain of
             # launch k overlaps the fill of launch k+1 — what a throughput-oriented frame loop can sustain. It is NOT
             # `value` and not what `roofline` prices (each individual kernel gets longer when two overlap).
             ctx2 = PcsContext(cfgs, device=local_rank)           # its own non-blocking stream
-            h2 = ctx2._h
-            def launch2(k):
-                dp, cp, outp = call_args[k % R]
-                if lib.pcs_process_frames_device(h2 if k & 1 else h, dp, cp, outp, payload_shorts, None):
-                    raise RuntimeError("two-stream leg failed")
-            for k in range(400):
-                launch2(k)
+            flip = [0]
+
+            def launch2():
+                flip[0] ^= 1
+                launch_dense(ctx2._h if flip[0] else None)
+            for _ in range(400):
+                launch2()
             torch.cuda.synchronize(dev); ctx2.synchronize()
             k2 = max(800, args.steps)
             t0o = time.perf_counter()
-            for k in range(k2):
-                launch2(k)
+            for _ in range(k2):
+                launch2()
             torch.cuda.synchronize(dev); ctx2.synchronize()
             ms_o = (time.perf_counter() - t0o) * 1e3 / k2
             ctx2.close()
@@ -482,7 +682,7 @@ def main():
                                          "aggregate_frac_of_peak": round(set_points * ALGO_BYTES_PER_POINT / (ms_o * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "note": "host clock; consecutive cold launches alternate over two HIP streams and overlap; "
                                                  "informational (not the contract's value, not a per-kernel figure)"}
-        if world == 1 and args.mode == "dense" and not args.no_general_rotation:
+        if extra and not args.no_general_rotation:
             # The synthetic configuration of SURVEY.md 8(d) has depth->colour R = I, which lets the kernel skip 15
             # individually-rounded flops per pixel; real D400 units report a small rotation. Same rasters, same
             # launch, R = 1 degree about a skewed axis:
@@ -497,37 +697,24 @@ def main():
                     cfg_r.depth_to_color.rotation[k] = float(v)
             ctx_r = PcsContext(cfgs_r, device=local_rank)
             ctx_r.set_stream(stream.cuda_stream)
-            hr = ctx_r._h
 
-            def launch_r(slot):
-                dp, cp, outp = call_args[slot]
-                if lib.pcs_process_frames_device(hr, dp, cp, outp, payload_shorts, None):
-                    raise RuntimeError(lib.pcs_last_error(hr).decode())
-            t_pre = time.perf_counter()
-            while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms / 2:      # same clock settling as the headline leg
-                for k in range(50):
-                    launch_r(k % R)
-                torch.cuda.synchronize(dev)
-            kr = max(400, args.steps)
-            ctx_r.timer_begin()
-            for k in range(kr):
-                launch_r(k % R)
-            ctx_r.timer_end()
-            ms_r = ctx_r.timer_elapsed_ms() / kr
+            def launch_r():
+                launch_dense(ctx_r._h)
+            preheat(launch_r, args.preheat_ms / 2)       # same clock settling as the headline leg
+            ms_r = timed(launch_r, max(400, args.steps), ctx_r)
             ach_r = set_points * ALGO_BYTES_PER_POINT / (ms_r * 1e-3) / 1e9
             out["general_rotation"] = {"ms_per_step": round(ms_r, 5), "value": round(set_points / ms_r / 1e3, 1),
                                        "achieved": round(ach_r, 1), "frac": round(ach_r / HBM_PEAK_GBS, 4),
-                                       "arithmetic": {0: "ieee", 1: "certified", 2: "certified+identityR", 3: "certified+noOverflow",
-                                                      4: "certified+identityR+noOverflow"}[min(ctx_r.stream_math(s) for s in range(S))],
+                                       "arithmetic": POLICY[min(ctx_r.stream_math(s) for s in range(S))],
                                        "note": "same rasters and launch with a 1-degree depth->colour rotation (what real cameras "
                                                "report); the headline configuration has R = I per SURVEY.md 8(d)"}
             ctx_r.close()
-        if world == 1 and args.mode != "pack":
+        if world == 1 and args.mode in ("dense", "drop_invalid", "cutoff"):
             # per-launch distribution (SURVEY.md 8d asks for median + min): a separate leg with a hipEvent pair
             # around every launch, so the event records stay out of the timed region above
             ctx.kernel_timing(True)
-            for k in range(300):
-                launch(k % R)
+            for _ in range(300):
+                launch()
             per = np.sort(ctx.kernel_times_ms())       # synchronises the stream
             ctx.kernel_timing(False)
             if per.size:
@@ -535,7 +722,7 @@ def main():
                                                     "min": round(float(per[0]), 5), "p95": round(float(per[int(per.size * 0.95)]), 5),
                                                     "note": "one hipEvent pair per launch (includes event overhead); "
                                                             "avg_launch_ms above is the contract figure"}
-        if world == 1 and not args.no_host_api:
+        if world == 1 and args.mode == "dense" and not args.no_host_api:
             # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
             # pageable numpy memory like a caller of the reference's function would have. Never `value`.
             def time_host(dep, col, outbuf, reps=5):
@@ -554,6 +741,7 @@ def main():
             tp = time_host(pd, pc, po)
             # software-pipelined loop (pcs_submit_frames / pcs_collect_frames): upload of k+1 overlaps download of k
             po2 = ctx.host_array((2 + payload_shorts,), np.int16)
+
             def time_pipe(reps=8):
                 ta, tb = ctx.submit_frames(pd, pc), ctx.submit_frames(pd, pc)     # warm both slots
                 ctx.collect_frames(ta, po); ctx.collect_frames(tb, po2)
@@ -567,6 +755,7 @@ def main():
             tpipe = time_pipe()
             # the two directions on their own (page-locked buffers), SURVEY.md 8d: "H2D/D2H reported separately"
             d_tmp = ctx.device_malloc(payload_shorts * 2)
+
             def time_copy(fn, reps=5):
                 fn()
                 t0c = time.perf_counter()
@@ -574,6 +763,7 @@ def main():
                     fn()
                 return (time.perf_counter() - t0c) / reps
             up_bytes = sum(a.nbytes for a in pd + pc)
+
             def all_up():
                 o = 0
                 for a in pd + pc:
@@ -592,9 +782,12 @@ def main():
                                "not by the kernel"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
-            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if args.mode == "dense":
+                out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 
+    if ctx0 is not ctx:
+        ctx0.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

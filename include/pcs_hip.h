@@ -158,6 +158,23 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer_device(pcs_ctx* ctx, int stream,
                                          const float* d_vertices, const float* d_texcoords, int n_points,
                                          const uint8_t* d_color, int16_t* d_pc_buffer, int* d_out_points);
 
+/* Batched device form of the a2 twin: n_clouds cameras' rs2::points arrays packed by ONE launch (per group of 16)
+ * instead of one latency-bound launch per camera — the reference runs copyPointCloudXYZRGBToBufferSIMD once per
+ * camera process (src/pcs-camera-optimized.cpp:363); a node that hosts all cameras hands them over together.
+ * `clouds` is a HOST array whose pointer fields are DEVICE pointers; cloud i is packed exactly as
+ * pcs_copy_pointcloud_xyzrgb_to_buffer_device(ctx, clouds[i].stream, ...) would. d_out_points (optional, device)
+ * receives n_clouds ints. Under -c (a predicate) the clouds are processed one after the other.                  */
+typedef struct pcs_cloud_desc {
+    int32_t        stream;      /* which stream's tf_mat / colour geometry applies                               */
+    int32_t        n_points;    /* pts.size()                                                                     */
+    const float*   vertices;    /* pts.get_vertices()                                                             */
+    const float*   texcoords;   /* pts.get_texture_coordinates()                                                  */
+    const uint8_t* color;       /* color.get_data()                                                               */
+    int16_t*       pc_buffer;   /* the reference's buffer + 2; 5*n_points shorts                                  */
+} pcs_cloud_desc;
+int pcs_copy_pointclouds_xyzrgb_to_buffer_device(pcs_ctx* ctx, int n_clouds, const pcs_cloud_desc* clouds,
+                                                 int* d_out_points);
+
 /* ---- a1 twin: sendXYZRGBPointcloud (:669-723) without the socket ----------------------- *
  * buffer must hold buffer_shorts shorts (the reference mallocs PCS_REF_BUF_SIZE). On return:
  * payload at buffer+2 shorts; if write_header, int32 LE payload byte count at byte 0 (:718);
@@ -199,6 +216,18 @@ int pcs_collect_frames(pcs_ctx* ctx, int ticket, int16_t* stitched, size_t stitc
  * d_counts may be NULL.                                                                       */
 int pcs_process_frames_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                               int16_t* d_payload, size_t payload_shorts, int32_t* d_counts);
+
+/* Throughput form: n_sets frame-sets of the SAME streams per call. d_depth / d_color hold n_sets * n_streams device
+ * pointers, frame-set major (entry k*n_streams + s = stream s of frame-set k); d_payload[k] is frame-set k's payload
+ * pointer (each with payload_shorts capacity), d_counts (optional) n_sets pointers as in pcs_process_frames_device.
+ * Each payload receives exactly the bytes pcs_process_frames_device would write. On the dense path (no
+ * CUTOFF/DROP_INVALID, downsample 1, 16-byte aligned payloads) up to 64 / n_streams frame-sets share ONE kernel
+ * launch, which amortises the fill and drain of a ~23 us launch (8 x 1280x720: 58 % -> ~65 % of HBM peak); other
+ * configurations are processed set by set. A caller that must hand a frame-set on as soon as it is complete keeps
+ * using pcs_process_frames_device: batching trades latency for throughput.                                     */
+int pcs_process_frames_device_batch(pcs_ctx* ctx, int n_sets, const uint16_t* const* d_depth,
+                                    const uint8_t* const* d_color, int16_t* const* d_payload, size_t payload_shorts,
+                                    int32_t* const* d_counts);
 
 /* Deprojection only (a5 restated): Z16 -> vertices (N x 3 float) and texcoords (N x 2 float),
  * i.e. what rs2::pointcloud::calculate + map_to hand to a2. Host pointers. For parity tests

@@ -77,9 +77,11 @@ int  pcs_oracle_pack_simd_omp(const pcs_stream_config* sc, const float* vertices
                               int n_points, const uint8_t* color, int16_t* out, int n_threads);
 void pcs_oracle_deproject_omp(const pcs_stream_config* sc, const uint16_t* depth,
                               float* vertices, float* texcoords, int n_threads);
-/* bracket (A) of BASELINE.md: memset(5 000 000 B) + pack, i.e. the reference's timed region :291-293 */
+/* bracket (A) of BASELINE.md: memset(5 000 000 B) + pack, i.e. the reference's timed region :291-293.
+ * buffer_shorts = capacity of `buffer`; returns -1 (nothing written) if it cannot hold the memset region and
+ * 2 + 5*n_points shorts — the reference itself has no such check and overflows beyond 999 999 points. */
 int  pcs_oracle_send_simd_omp(const pcs_stream_config* sc, const float* vertices, const float* texcoords,
-                              int n_points, const uint8_t* color, int16_t* buffer, int n_threads);
+                              int n_points, const uint8_t* color, int16_t* buffer, size_t buffer_shorts, int n_threads);
 int  pcs_oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -58,7 +58,7 @@ def lib():
         L.pcs_oracle_deproject_omp.restype = None
         L.pcs_oracle_deproject_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pcs_oracle_send_simd_omp.restype = C.c_int
-        L.pcs_oracle_send_simd_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pcs_oracle_send_simd_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _lib = L
     return _lib
 

@@ -99,8 +99,13 @@ void pcs_oracle_deproject_omp(const pcs_stream_config* sc, const uint16_t* depth
 }
 
 int pcs_oracle_send_simd_omp(const pcs_stream_config* sc, const float* vertices, const float* texcoords,
-                             int n_points, const uint8_t* color, int16_t* buffer, int n_threads)
+                             int n_points, const uint8_t* color, int16_t* buffer, size_t buffer_shorts, int n_threads)
 {
+    /* the reference has no such check (BUF_SIZE overflows beyond 999 999 points); a checker
+     * must not corrupt its caller's heap */
+    if (n_points < 0 || buffer_shorts * sizeof(int16_t) < PCS_REF_BUF_SIZE ||
+        buffer_shorts < PCS_HEADER_SHORTS + PCS_POINT_SHORTS * (size_t)n_points)
+        return -1;
     memset(buffer, 0, PCS_REF_BUF_SIZE);                                         /* :673 */
     int count = pcs_oracle_pack_simd_omp(sc, vertices, texcoords, n_points, color,
                                          buffer + PCS_HEADER_SHORTS, n_threads); /* :690 */

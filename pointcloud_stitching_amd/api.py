@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import lib as _libmod
-from .types import (Config, StreamConfig, STATUS_NAMES, POINT_SHORTS, POINT_BYTES, HEADER_SHORTS,
+from .types import (CloudDesc, Config, StreamConfig, STATUS_NAMES, POINT_SHORTS, POINT_BYTES, HEADER_SHORTS,
                     REF_BUF_SIZE, stream_array)
 
 
@@ -118,6 +118,9 @@ class PcsContext:
         if col.size < self.streams[stream].color_bytes:
             raise ValueError("colour raster smaller than stride*height")
         out = pc_buffer if pc_buffer is not None else np.zeros((max(n, 1), POINT_SHORTS), np.int16)
+        if out.dtype != np.int16 or not out.flags["C_CONTIGUOUS"] or out.size < n * POINT_SHORTS:
+            # the C entry point mirrors the reference and has no capacity argument: check here
+            raise ValueError(f"pc_buffer must be a C-contiguous int16 array of at least {n * POINT_SHORTS} elements")
         cnt = C.c_int(0)
         self._check(self._lib.pcs_copy_pointcloud_xyzrgb_to_buffer(
             self._h, stream, _ptr(vtx), _ptr(tex), n, _ptr(col), _ptr(out), C.byref(cnt)))
@@ -204,6 +207,32 @@ class PcsContext:
         cp = (C.c_void_p * self.n_streams)(*d_color)
         self._check(self._lib.pcs_process_frames_device(self._h, dp, cp, d_payload, payload_shorts,
                                                         d_counts or None))
+
+    def process_frames_device_batch(self, d_depth: Sequence[Sequence[int]], d_color: Sequence[Sequence[int]],
+                                    d_payload: Sequence[int], payload_shorts: int,
+                                    d_counts: Optional[Sequence[int]] = None) -> None:
+        """K frame-sets per call (pcs_process_frames_device_batch): d_depth[k][s], d_color[k][s], d_payload[k]."""
+        k = len(d_payload)
+        if len(d_depth) != k or len(d_color) != k:
+            raise ValueError("need one raster list per frame-set")
+        flat_d = [p for row in d_depth for p in row]
+        flat_c = [p for row in d_color for p in row]
+        if len(flat_d) != k * self.n_streams or len(flat_c) != k * self.n_streams:
+            raise ValueError("every frame-set needs one depth and one colour pointer per stream")
+        dp = (C.c_void_p * len(flat_d))(*flat_d)
+        cp = (C.c_void_p * len(flat_c))(*flat_c)
+        pp = (C.c_void_p * k)(*d_payload)
+        cc = (C.c_void_p * k)(*d_counts) if d_counts is not None else None
+        self._check(self._lib.pcs_process_frames_device_batch(self._h, k, dp, cp, pp, payload_shorts, cc))
+
+    def copy_pointclouds_xyzrgb_to_buffer_device(self, clouds: Sequence[Tuple[int, int, int, int, int, int]],
+                                                 d_out_points: int = 0) -> None:
+        """Batched a2 twin on device pointers: clouds = [(stream, n_points, d_vertices, d_texcoords, d_color, d_out)]."""
+        arr = (CloudDesc * max(len(clouds), 1))()
+        for i, (stream, n, v, t, col, out) in enumerate(clouds):
+            arr[i].stream, arr[i].n_points = int(stream), int(n)
+            arr[i].vertices, arr[i].texcoords, arr[i].color, arr[i].pc_buffer = v or None, t or None, col or None, out or None
+        self._check(self._lib.pcs_copy_pointclouds_xyzrgb_to_buffer_device(self._h, len(clouds), arr, d_out_points or None))
 
     def deproject(self, stream: int, depth) -> Tuple[np.ndarray, np.ndarray]:
         d = np.ascontiguousarray(depth, np.uint16).reshape(-1)

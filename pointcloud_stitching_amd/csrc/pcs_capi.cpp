@@ -52,6 +52,7 @@ struct pcs_ctx {
     uint32_t                        compact_seq = 0;
     bool                            single_pass_ok = true;     // cleared if a placement wait ever timed out
     bool                            compact_tickets = false;   // tile ids by atomic ticket instead of blockIdx
+    int                             compact_path = 0;          // 0 count + scan + emit (default), 1 single pass by blockIdx (opt-in)
     bool                            dense_ok = false;          // every stream has n % 8 == 0
     bool                            any_ddist = false, any_cdist = false;
     std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 + identity R, 3/4 = 1/2 + no-overflow
@@ -390,7 +391,8 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(ev.first, c->stream));
     }
-    const bool single_pass = pred && c->downsample == 1 && c->single_pass_ok && !force_three_pass;
+    const bool one_launch = pred && c->downsample == 1 && c->single_pass_ok && !force_three_pass;
+    const bool single_pass = one_launch && c->compact_path == 1;
     if (single_pass) {
         if (!c->d_ticket) {
             HIPCHK(c, hipMalloc((void**)&c->d_ticket, sizeof(unsigned long long)));
@@ -406,7 +408,7 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             HIPCHK(c, hipMemsetAsync(c->d_desc, 0, sizeof(uint64_t) * ((size_t)c->total_tiles + PCS_MAX_STREAMS), c->stream));
             c->compact_seq++;
         }
-        for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
+        for (int s0 = 0; single_pass && s0 < c->n_streams; s0 += kLaunchStreams) {
             const int nl = std::min(kLaunchStreams, c->n_streams - s0);
             FramePtrs fp{};
             uint32_t tiles = 0;
@@ -623,6 +625,16 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     }
     c->max_payload_points = out_base;
     c->total_tiles = tile_base;
+    {   // the wire header and the counts are int32 (src/pcs-camera-optimized.cpp:697, 718): bound the stitched payload
+        uint64_t all = 0;
+        for (int s = 0; s < c->n_streams; s++) all += (c->h_params[s].n_points + (uint64_t)c->downsample - 1) / c->downsample;
+        if (all * PCS_POINT_BYTES > 0x7FFFFFFFull) {
+            const int rc = fail(nullptr, PCS_ERR_UNSUPPORTED, "stitched payload of %llu points exceeds the int32 byte-count header "
+                                "(214 748 364 points)", (unsigned long long)all);
+            pcs_destroy(c);
+            return rc;
+        }
+    }
     CREATE_CHK(hipMalloc((void**)&c->d_tile_counts, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_tile_prefix, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_stream_base, sizeof(uint32_t) * (c->n_streams + 1)));
@@ -671,7 +683,19 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     // for count + scan + emit on 8x720p, but its forward progress assumes workgroups are dispatched in
     // blockIdx order (bounded waits + three-pass re-run catch a violation) -> opt-in. PCS_COMPACT_TICKETS=1
     // hands tile ids out in start order instead (dispatch-order independent; the contended atomic makes it 63 us).
-    { const char* e = getenv("PCS_COMPACT_SINGLE_PASS"); c->single_pass_ok = e && e[0] == '1'; }
+    // Ordered compaction. Default: count + scan + emit — three small launches, no inter-workgroup waiting at all, and
+    // the fastest form at large sizes (16 x 1080p: 111 us vs 129 us). PCS_COMPACT_PATH=single (older spelling:
+    // PCS_COMPACT_SINGLE_PASS=1) selects the single-pass kernel (one launch, Z16 read once; 32.6 vs 33.9 us on 8 x 720p,
+    // but its forward progress assumes workgroups are dispatched in blockIdx order — bounded waits + a three-pass re-run
+    // catch a violation), PCS_COMPACT_TICKETS=1 its dispatch-order independent but slow ticketed variant. DESIGN.md §5
+    // lists the persistent / chunked variants that were built to lift the ordering assumption and measured slower.
+    c->compact_path = 0;
+    if (const char* e = getenv("PCS_COMPACT_PATH")) {
+        if (!strcmp(e, "single")) c->compact_path = 1;
+    } else if (const char* e1 = getenv("PCS_COMPACT_SINGLE_PASS")) {
+        if (e1[0] == '1') c->compact_path = 1;
+    }
+    c->single_pass_ok = c->compact_path == 1;
     { const char* e = getenv("PCS_COMPACT_TICKETS"); c->compact_tickets = e && e[0] == '1'; }
     c->math.resize(c->n_streams);
     for (int s = 0; s < c->n_streams; s++) {
@@ -791,6 +815,62 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer_device(pcs_ctx* c, int stream, const fl
     return PCS_OK;
 }
 
+// Batched form: all cameras of a frame-set in one launch (groups of kPackBatch). With a predicate the kept counts are
+// data dependent and every cloud needs its own count + scan + emit, so that case runs the single-cloud path per entry.
+int pcs_copy_pointclouds_xyzrgb_to_buffer_device(pcs_ctx* c, int n_clouds, const pcs_cloud_desc* clouds, int* d_out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_clouds < 0 || (n_clouds > 0 && !clouds)) return fail(c, PCS_ERR_INVALID_ARG, "bad cloud list");
+    for (int i = 0; i < n_clouds; i++) {
+        const pcs_cloud_desc& q = clouds[i];
+        if (q.stream < 0 || q.stream >= c->n_streams) return fail(c, PCS_ERR_INVALID_ARG, "cloud %d: stream %d out of range", i, q.stream);
+        if (q.n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "cloud %d: n_points %d < 0", i, q.n_points);
+        if (q.n_points > 0 && (!q.vertices || !q.texcoords || !q.color || !q.pc_buffer))
+            return fail(c, PCS_ERR_INVALID_ARG, "cloud %d: NULL device pointer", i);
+        if (((uintptr_t)q.pc_buffer & 1u) || ((uintptr_t)q.vertices & 3u) || ((uintptr_t)q.texcoords & 3u))
+            return fail(c, PCS_ERR_INVALID_ARG, "cloud %d: misaligned device pointer", i);
+    }
+    DeviceGuard guard(c->device);
+    if (has_pred(c->flags)) {
+        for (int i = 0; i < n_clouds; i++) {
+            const pcs_cloud_desc& q = clouds[i];
+            int rc = pcs_copy_pointcloud_xyzrgb_to_buffer_device(c, q.stream, q.vertices, q.texcoords, q.n_points, q.color,
+                                                                 q.pc_buffer, d_out_points ? d_out_points + i : nullptr);
+            if (rc) return rc;
+        }
+        return PCS_OK;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev{};
+    if (c->kernel_timing) {
+        int rc = acquire_event_pair(c, ev);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(ev.first, c->stream));
+    }
+    for (int i0 = 0; i0 < n_clouds; i0 += kPackBatch) {
+        const int nb = std::min(kPackBatch, n_clouds - i0);
+        PackBatch pb{};
+        uint32_t mp = 0;
+        bool aligned = true;
+        for (int k = 0; k < nb; k++) {
+            const pcs_cloud_desc& q = clouds[i0 + k];
+            pb.v[k] = VertexPtrs{q.vertices, q.texcoords, q.color, (uint32_t)q.n_points};
+            pb.out[k] = reinterpret_cast<uint8_t*>(q.pc_buffer);
+            pb.stream[k] = q.stream;
+            mp = std::max(mp, (uint32_t)q.n_points);
+            aligned &= ((uintptr_t)q.pc_buffer & 15u) == 0;
+        }
+        HIPCHK(c, launch_pack_batch(c->d_params, pb, nb, mp, aligned, c->stream));
+    }
+    if (d_out_points)
+        for (int i = 0; i < n_clouds; i++)
+            HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)(d_out_points + i), clouds[i].n_points, 1, c->stream));
+    if (c->kernel_timing) {
+        HIPCHK(c, hipEventRecord(ev.second, c->stream));
+        c->ev_pool.push_back(ev);
+    }
+    return PCS_OK;
+}
+
 int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* c, int stream, const float* vertices, const float* texcoords,
                                          int n_points, const uint8_t* color, int16_t* pc_buffer, int* out_points)
 {
@@ -871,6 +951,85 @@ try {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_device: host allocation failed (%s)", ex.what());
 }
 
+// K frame-sets per launch (throughput form). The dense path (no predicate, stride 1, 16-byte aligned payloads, every
+// stream a multiple of 8 points) puts up to 64 / n_streams frame-sets into ONE launch, so the fill and drain of the
+// machine are paid once per group instead of once per frame-set; every other configuration runs the sets one after
+// the other through the same code as pcs_process_frames_device. The bytes written are identical either way.
+int pcs_process_frames_device_batch(pcs_ctx* c, int n_sets, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                    int16_t* const* d_payload, size_t payload_shorts, int32_t* const* d_counts)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_sets < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_sets %d < 0", n_sets);
+    if (n_sets == 0) return PCS_OK;
+    if (!d_depth || !d_color || !d_payload) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    const int S = c->n_streams;
+    bool aligned = true;
+    for (int k = 0; k < n_sets; k++) {
+        if (!d_payload[k]) return fail(c, PCS_ERR_INVALID_ARG, "frame-set %d: NULL payload pointer", k);
+        if ((uintptr_t)d_payload[k] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "frame-set %d: payload pointer must be 2-byte aligned", k);
+        aligned &= ((uintptr_t)d_payload[k] & 15u) == 0;
+        for (int s = 0; s < S; s++) {
+            if (!d_depth[(size_t)k * S + s] || !d_color[(size_t)k * S + s])
+                return fail(c, PCS_ERR_INVALID_ARG, "frame-set %d stream %d: NULL raster pointer", k, s);
+            if ((uintptr_t)d_depth[(size_t)k * S + s] & 1u)
+                return fail(c, PCS_ERR_INVALID_ARG, "frame-set %d stream %d: depth pointer not 2-byte aligned", k, s);
+        }
+    }
+    DeviceGuard guard(c->device);
+    const int per_launch = std::min(kBatchSets, kBatchEntries / S);
+    const bool dense = !has_pred(c->flags) && c->downsample == 1 && c->dense_ok && aligned && per_launch >= 2;
+    if (!dense) {
+        for (int k = 0; k < n_sets; k++) {
+            int rc = run_fused_device(c, d_depth + (size_t)k * S, d_color + (size_t)k * S, d_payload[k], payload_shorts,
+                                      d_counts ? d_counts[k] : nullptr);
+            if (rc) return rc;
+        }
+        return PCS_OK;
+    }
+    if (payload_shorts < c->max_payload_points * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "payload buffers hold %zu shorts, %zu needed", payload_shorts,
+                    c->max_payload_points * PCS_POINT_SHORTS);
+    bool fast = true, ident = true, noovf = true, dd = false, cd = false;
+    for (int s = 0; s < S; s++) {
+        const StreamParams& q = c->h_params[s];
+        fast &= q.cert_fast != 0; ident &= q.ident_r != 0; noovf &= q.no_overflow != 0;
+        dd |= q.ddist != 0;
+        cd |= q.cdist != 0 || q.tex_half != 0;
+    }
+    const MathSel sel = !fast ? MathSel::Ieee
+                      : noovf ? (ident ? MathSel::CertIdentRNoOvf : MathSel::CertNoOvf)
+                              : (ident ? MathSel::CertIdentR : MathSel::Cert);
+    std::pair<hipEvent_t, hipEvent_t> ev{};
+    if (c->kernel_timing) {
+        int rc = acquire_event_pair(c, ev);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(ev.first, c->stream));
+    }
+    for (int k0 = 0; k0 < n_sets; k0 += per_launch) {
+        const int nk = std::min(per_launch, n_sets - k0);
+        BatchPtrs bp{};
+        for (int k = 0; k < nk; k++) {
+            bp.payload[k] = reinterpret_cast<uint8_t*>(d_payload[k0 + k]);
+            for (int s = 0; s < S; s++) {
+                bp.depth[k * S + s] = d_depth[(size_t)(k0 + k) * S + s];
+                bp.color[k * S + s] = d_color[(size_t)(k0 + k) * S + s];
+            }
+        }
+        HIPCHK(c, launch_fused_dense_batch(c->d_params, S, nk, c->max_points, dd, cd, sel, bp, c->stream));
+    }
+    if (d_counts)
+        for (int k = 0; k < n_sets; k++)
+            if (d_counts[k])
+                HIPCHK(c, hipMemcpyAsync(d_counts[k], c->d_static_counts, sizeof(int32_t) * (S + 1), hipMemcpyDeviceToDevice, c->stream));
+    if (c->kernel_timing) {
+        HIPCHK(c, hipEventRecord(ev.second, c->stream));
+        c->ev_pool.push_back(ev);
+    }
+    return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_device_batch: host allocation failed (%s)", ex.what());
+}
+
 int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* const* color, int16_t* stitched,
                        size_t stitched_shorts, int write_header, int* points_per_stream, int* out_size_bytes)
 try {
@@ -928,15 +1087,23 @@ try {
     for (auto& cand : c->pipe) if (!cand.busy) { sl = &cand; break; }
     if (!sl) return fail(c, PCS_ERR_CAPACITY, "all %d pipeline slots are in flight: collect a frame-set first", PCS_PIPELINE_DEPTH);
     if (!c->dl_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
-    if (!sl->slab) {
-        int rc = alloc_raster_slab(c, sl->slab, sl->depth, sl->color);
+    if (!sl->slab) {      // allocate into locals; the slot is committed only when everything succeeded
+        uint8_t* slab = nullptr; std::vector<uint16_t*> dv; std::vector<uint8_t*> cv;
+        int16_t* payload = nullptr; int32_t* counts = nullptr; hipEvent_t done = nullptr;
+        int rc = alloc_raster_slab(c, slab, dv, cv);
         if (rc) return rc;
         const size_t max_bytes = c->max_payload_points * PCS_POINT_BYTES;
-        hipError_t e = hipMalloc((void**)&sl->payload, max_bytes + 256);
-        if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", max_bytes, hipGetErrorString(e));
-        e = hipMalloc((void**)&sl->counts, sizeof(int32_t) * (c->n_streams + 1));
-        if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
-        HIPCHK(c, hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+        hipError_t e = hipMalloc((void**)&payload, max_bytes + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&counts, sizeof(int32_t) * (c->n_streams + 1));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (payload) (void)hipFree(payload);
+            if (counts) (void)hipFree(counts);
+            (void)hipFree(slab);
+            return fail(c, PCS_ERR_NOMEM, "pipeline slot allocation failed: %s", hipGetErrorString(e));
+        }
+        sl->slab = slab; sl->depth = std::move(dv); sl->color = std::move(cv);
+        sl->payload = payload; sl->counts = counts; sl->done = done;
     }
     for (int s = 0; s < c->n_streams; s++) {
         const StreamParams& P = c->h_params[s];
@@ -966,6 +1133,9 @@ try {
     if (!sl) return fail(c, PCS_ERR_INVALID_ARG, "ticket %d is not in flight", ticket);
     if (ticket != c->next_collect) return fail(c, PCS_ERR_INVALID_ARG, "tickets are collected in submission order: %d is next", c->next_collect);
     DeviceGuard guard(c->device);
+    // whatever happens below, the slot is released and the ticket consumed: a failed frame-set is dropped, it must
+    // not wedge the pipeline (later tickets could otherwise never be collected)
+    struct Release { pcs_ctx* c; pcs_ctx::PipeSlot* sl; ~Release() { sl->busy = false; c->next_collect++; } } release{c, sl};
     HIPCHK(c, hipStreamWaitEvent(c->dl_stream, sl->done, 0));
     std::vector<int32_t> h(c->n_streams + 1);
     size_t total;
@@ -979,16 +1149,13 @@ try {
         h[c->n_streams] = (int32_t)total;
     }
     if (stitched_shorts < PCS_HEADER_SHORTS + total * PCS_POINT_SHORTS) {
-        (void)hipStreamSynchronize(c->dl_stream);
-        sl->busy = false; c->next_collect++;          // the frame-set is dropped; the slot is usable again
+        (void)hipStreamSynchronize(c->dl_stream);     // the frame-set is dropped; the slot is usable again
         return fail(c, PCS_ERR_CAPACITY, "stitched buffer holds %zu shorts, %zu needed", stitched_shorts,
                     PCS_HEADER_SHORTS + total * PCS_POINT_SHORTS);
     }
     if (total)
         HIPCHK(c, hipMemcpyAsync(stitched + PCS_HEADER_SHORTS, sl->payload, total * PCS_POINT_BYTES, hipMemcpyDeviceToHost, c->dl_stream));
     HIPCHK(c, hipStreamSynchronize(c->dl_stream));
-    sl->busy = false;
-    c->next_collect++;
     const int32_t size = (int32_t)(total * PCS_POINT_BYTES);
     if (write_header) std::memcpy(stitched, &size, sizeof size);
     if (points_per_stream) for (int s = 0; s < c->n_streams; s++) points_per_stream[s] = h[s];

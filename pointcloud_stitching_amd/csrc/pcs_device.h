@@ -64,6 +64,25 @@ struct VertexPtrs {          // a2 twin: one stream per launch
     uint32_t       n_points;
 };
 
+// Batched dense launch: K frame-sets of the same S streams in ONE launch (blockIdx.z = frame-set). A 23 us
+// launch spends a large share of its life filling and draining the machine; K sets per launch amortise that
+// (throughput form, pcs_process_frames_device_batch). Entry z*S + y holds the rasters of stream y in set z.
+constexpr int kBatchEntries = 64;                                      // S * K <= 64
+constexpr int kBatchSets    = 16;
+struct BatchPtrs {
+    const uint16_t* depth[kBatchEntries];
+    const uint8_t*  color[kBatchEntries];
+    uint8_t*        payload[kBatchSets];                               // payload base of frame-set z
+};
+
+// Batched a2 twin: several cameras' rs2::points arrays in ONE launch (blockIdx.y = cloud).
+constexpr int kPackBatch = 16;
+struct PackBatch {
+    VertexPtrs v[kPackBatch];
+    uint8_t*   out[kPackBatch];
+    int32_t    stream[kPackBatch];                                     // which StreamParams entry (extrinsic, colour geometry)
+};
+
 // Which arithmetic policy a launch may use (the AND over the streams of the launch).
 enum class MathSel { Ieee = 0, Cert = 1, CertIdentR = 2, CertNoOvf = 3, CertIdentRNoOvf = 4 };
 
@@ -103,6 +122,10 @@ hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n
                                 MathSel math, const FramePtrs& fp, const CompactLaunch& cl, int16_t* d_payload,
                                 hipStream_t st);
 hipError_t launch_counts(const uint32_t* d_stream_end, int n_streams, int32_t* d_counts, hipStream_t st);
+
+// K frame-sets per launch (dense path only).
+hipError_t launch_fused_dense_batch(const StreamParams* d_params, int n_streams, int n_sets, uint32_t max_points,
+                                    bool any_ddist, bool any_cdist, MathSel math, const BatchPtrs& bp, hipStream_t st);
 hipError_t launch_verify_div_const(float c, float rc, int32_t dim, unsigned long long* d_bad, hipStream_t st);
 
 // a2 twin.
@@ -114,6 +137,10 @@ hipError_t launch_pack_scan(uint32_t n_tiles, const uint32_t* d_tile_counts, uin
                             int32_t* d_out_points, uint32_t* d_arrive, hipStream_t st);
 hipError_t launch_pack_emit(const StreamParams* d_params, int stream, const VertexPtrs& vp, uint32_t flags,
                             const uint32_t* d_tile_prefix, int16_t* d_out, hipStream_t st);
+
+// batched a2 twin (no predicate): n clouds in one launch; `aligned` = every out pointer is 16-byte aligned
+hipError_t launch_pack_batch(const StreamParams* d_params, const PackBatch& pb, int n, uint32_t max_points, bool aligned,
+                             hipStream_t st);
 
 // a5 alone.
 hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n_points, const uint16_t* d_depth,

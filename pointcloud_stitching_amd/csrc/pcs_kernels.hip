@@ -391,26 +391,34 @@ __device__ __forceinline__ uint32_t keep_mask8(const PointIn (&p)[8], uint32_t i
     return keep;
 }
 
-// Wavefront-wide exclusive prefix sum of a small per-lane count (64 lanes).
+// Wavefront-wide inclusive prefix sum (64 lanes, all active) by DPP: four row_shr steps scan each row of 16 lanes,
+// row_bcast:15 / row_bcast:31 carry the row totals across (the gfx9 sequence). No lane-index registers, no LDS
+// crossbar (ds_bpermute, which __shfl_up compiles to) — and nothing loop-invariant for the compiler to hoist out of
+// a persistent tile loop and spill.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Wavefront-wide exclusive prefix sum of a small per-lane count; wave_total is wave-uniform (an SGPR).
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t c, uint32_t& wave_total)
 {
-    const int lane = threadIdx.x & 63;
-    uint32_t inc = c;
-#pragma unroll
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-        const uint32_t t = __shfl_up(inc, ofs, 64);
-        if (lane >= ofs) inc += t;
-    }
-    wave_total = __shfl(inc, 63, 64);
+    const uint32_t inc = wave_inclusive_scan(c);
+    wave_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     return inc - c;
 }
 
-// Wavefront-wide sum (every lane gets it).
+// Wavefront-wide sum (wave-uniform).
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
-#pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -876,6 +884,23 @@ void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0
     dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
 
+// K frame-sets of the same streams in one launch: blockIdx.z = frame-set, blockIdx.y = stream. Same tile code, same
+// bytes; only the fill/drain of the launch is shared by K sets (pcs_process_frames_device_batch).
+template <bool DDIST, bool CDIST, class Mth>
+__global__ __launch_bounds__(kBlockThreads, 7)
+void pcs_fused_dense_batch_kernel(const StreamParams* __restrict__ params, BatchPtrs bp)
+{
+    __shared__ uint4 stage[kDenseStageBytes / 16];
+    const int s = blockIdx.y;
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    const int e = blockIdx.z * gridDim.y + s;
+    DepthSource<DDIST, CDIST, Mth> src{bp.depth[e]};
+    dense_tile(P, src, bp.color[e], tile0, n, bp.payload[blockIdx.z] + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
+}
+
 // Count pass: kept points per tile. (Folding the per-stream scan into this launch through a last-arriver
 // counter was measured and is slower — 450 returning atomics per counter line cost more than the separate
 // 5 us scan launch)
@@ -911,8 +936,7 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
         src.load8(P, i0, n, p, nullptr);
         c = __popc(keep_mask8(p, i0, n, flags));
     }
-#pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
+    c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -1029,8 +1053,7 @@ void pcs_pack_count_kernel(const StreamParams* __restrict__ params, int stream, 
         if (i < n) { p[k].X = vp.vertices[3 * (size_t)i]; p[k].Z = vp.vertices[3 * (size_t)i + 2]; }
     }
     uint32_t c = __popc(keep_mask8(p, i0, n, flags));
-#pragma unroll
-    for (int ofs = 32; ofs > 0; ofs >>= 1) c += __shfl_xor(c, ofs, 64);
+    c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -1056,6 +1079,30 @@ void pcs_pack_emit_kernel(const StreamParams* __restrict__ params, int stream, V
     // barrier after load8 — generic_tile does (PRED path barriers in the scan; non-PRED explicitly).
     generic_tile<VertexSource, PRED, true>(P, src, vp.color, tile0, n, flags, 1u, g0, 0u, out_bytes,
                                      reinterpret_cast<uint8_t*>(lds), wsum, lds);
+}
+
+// Batched a2 twin (no predicate): blockIdx.y = cloud. One launch for all cameras of a frame-set instead of one
+// latency-bound launch per camera (the reference calls copyPointCloudXYZRGBToBufferSIMD once per camera process).
+template <bool ALIGNED>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_pack_batch_kernel(const StreamParams* __restrict__ params, PackBatch pb)
+{
+    __shared__ __attribute__((aligned(16))) float lds[VertexSource::kLdsFloats];
+    __shared__ uint32_t wsum[4];
+    const int e = blockIdx.y;
+    const VertexPtrs vp = pb.v[e];
+    const StreamParams& P = params[pb.stream[e]];
+    const uint32_t n = vp.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    VertexSource src{vp.vertices, vp.texcoords};
+    src.stage_tile(tile0, n, lds);
+    __syncthreads();
+    if (ALIGNED)
+        dense_tile(P, src, vp.color, tile0, n, pb.out[e], reinterpret_cast<uint4*>(lds), lds);
+    else
+        generic_tile<VertexSource, false, true>(P, src, vp.color, tile0, n, 0u, 1u, tile0, 0u, pb.out[e],
+                                                reinterpret_cast<uint8_t*>(lds), wsum, lds);
 }
 
 // ---- a5 alone ----------------------------------------------------------------------------------
@@ -1209,6 +1256,38 @@ hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n
     else
         hipLaunchKernelGGL((pcs_fused_compact_kernel<IeeeMath>), dim3(launch_tiles), dim3(kBlockThreads), 0, st,
                            d_params, stream0, n_launch, fp, a, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_dense_batch(const StreamParams* d_params, int n_streams, int n_sets, uint32_t max_points,
+                                    bool any_ddist, bool any_cdist, MathSel math, const BatchPtrs& bp, hipStream_t st)
+{
+    if (n_streams <= 0 || n_sets <= 0 || max_points == 0) return hipSuccess;
+    if (n_streams * n_sets > kBatchEntries || n_sets > kBatchSets) return hipErrorInvalidValue;
+    const dim3 grid((max_points + kTilePoints - 1) / kTilePoints, (unsigned)n_streams, (unsigned)n_sets);
+#define L(DD, CD, M) hipLaunchKernelGGL((pcs_fused_dense_batch_kernel<DD, CD, M>), grid, dim3(kBlockThreads), 0, st, d_params, bp)
+    if (math != MathSel::Ieee && !any_ddist) {
+        const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
+        const bool noovf = (math == MathSel::CertNoOvf || math == MathSel::CertIdentRNoOvf) && !any_cdist;
+        if (noovf)      { if (ident) L(false, false, CertIdentNoOvf); else L(false, false, CertNoOvf); }
+        else if (ident) { if (any_cdist) L(false, true, CertMath<true>); else L(false, false, CertMath<true>); }
+        else            { if (any_cdist) L(false, true, CertMath<false>); else L(false, false, CertMath<false>); }
+    } else {
+        if (any_ddist) { if (any_cdist) L(true, true, IeeeMath); else L(true, false, IeeeMath); }
+        else           { if (any_cdist) L(false, true, IeeeMath); else L(false, false, IeeeMath); }
+    }
+#undef L
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_batch(const StreamParams* d_params, const PackBatch& pb, int n, uint32_t max_points, bool aligned,
+                             hipStream_t st)
+{
+    if (n <= 0 || max_points == 0) return hipSuccess;
+    if (n > kPackBatch) return hipErrorInvalidValue;
+    const dim3 grid = tile_grid(max_points, n);
+    if (aligned) hipLaunchKernelGGL((pcs_pack_batch_kernel<true>), grid, dim3(kBlockThreads), 0, st, d_params, pb);
+    else         hipLaunchKernelGGL((pcs_pack_batch_kernel<false>), grid, dim3(kBlockThreads), 0, st, d_params, pb);
     return hipGetLastError();
 }
 

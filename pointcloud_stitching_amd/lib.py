@@ -10,7 +10,7 @@ import os
 import subprocess
 from typing import Optional
 
-from .types import Config, StreamConfig
+from .types import CloudDesc, Config, StreamConfig
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_PKG, "csrc")
@@ -35,11 +35,13 @@ SYMBOLS = [
      [_VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _P(C.c_int)]),
     ("pcs_copy_pointcloud_xyzrgb_to_buffer_device", C.c_int,
      [_VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    ("pcs_copy_pointclouds_xyzrgb_to_buffer_device", C.c_int, [_VP, C.c_int, _P(CloudDesc), _VP]),
     ("pcs_send_xyzrgb_pointcloud", C.c_int,
      [_VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, C.c_size_t, C.c_int, _P(C.c_int)]),
     ("pcs_process_frames", C.c_int,
      [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_process_frames_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _VP]),
+    ("pcs_process_frames_device_batch", C.c_int, [_VP, C.c_int, _P(_VP), _P(_VP), _P(_VP), C.c_size_t, _P(_VP)]),
     ("pcs_submit_frames", C.c_int, [_VP, _P(_VP), _P(_VP), _P(C.c_int)]),
     ("pcs_collect_frames", C.c_int, [_VP, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_deproject", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),

@@ -67,6 +67,13 @@ class Config(C.Structure):
                 ("flags", C.c_uint32), ("downsample", C.c_int32)]
 
 
+class CloudDesc(C.Structure):
+    """pcs_cloud_desc: one camera's rs2::points arrays (device pointers) for the batched a2 twin."""
+    _fields_ = [("stream", C.c_int32), ("n_points", C.c_int32),
+                ("vertices", C.c_void_p), ("texcoords", C.c_void_p),
+                ("color", C.c_void_p), ("pc_buffer", C.c_void_p)]
+
+
 # --- the reference's surveyed extrinsics (data, not code) -------------------------------------
 # src/pcs-camera-optimized.cpp:64-67
 TF_MAT = np.array([

@@ -36,7 +36,8 @@ def test_bench_line_has_the_contract_keys():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["higher_is_better"] is True
-    assert d["unit"] == "Mpoints/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["unit"] == "Mpoints/s" and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["streams_total"] == 8 and d["config"]["ring_cold"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
@@ -46,3 +47,43 @@ def test_bench_line_has_the_contract_keys():
     assert abs(d["value"] - 8 * 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mpoints/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["host_physical_cores"] >= 1 and cb["host_logical_cpus"] >= cb["host_physical_cores"]
+    # the other kernels' legs ride on the default line, each with its own byte model
+    comp = d["compaction"]
+    assert 0.85 < comp["kept_fraction"] < 0.95 and abs(comp["algorithmic_bytes_per_point"] - (5 + 10 * comp["kept_fraction"])) < 1e-2
+    assert comp["frac"] > 0.2 and d["batched_dense"]["frac"] > 0.3 and d["pack_twin"]["batched_frac"] > 0.2
+
+
+def _bench_line(*extra, launcher=()):
+    r = subprocess.run([sys.executable, *launcher, BENCH, *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_short_and_long_runs_measure_the_same_cold_launch():
+    """The driver runs --steps 20 --warmup 5. Its per-launch figure must be the one a long run (and rocprof) gives:
+    one launch counter runs through pre-heat, warm-up and the timed region, so the short run cannot start on ring
+    slots whose inputs still sit in the Infinity Cache (round 1's 5 % optimism)."""
+    quick = ("--no-extra-legs", "--no-cpu-baseline", "--no-host-api")
+    a = _bench_line("--steps", "20", "--warmup", "5", *quick)
+    b = _bench_line("--steps", "400", "--warmup", "40", *quick)
+    la, lb = a["roofline"]["avg_launch_ms"], b["roofline"]["avg_launch_ms"]
+    assert abs(la - lb) / lb < 0.03, (la, lb)
+    assert a["config"]["ring_cold"] and b["config"]["ring_cold"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_shard_the_eight_streams():
+    """N > 1 is BASELINE configs[3]'s shape: 8 streams IN TOTAL, 8/N per GPU, gathered to rank 0 in camera order.
+    Control flow only (gloo, both ranks on this one GPU, host-staged gather) — the numbers mean nothing."""
+    d = _bench_line("--gpus", "2", "--steps", "6", "--warmup", "2", "--preheat-ms", "20", "--debug-backend", "gloo",
+                    launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", "29577"))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == "streams sharded 4/GPU x 2" and d["config"]["streams_total"] == 8
+    assert d["config"]["gather_to_rank0"] is True and "gather" in d
+    assert abs(d["value"] - 8 * 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01

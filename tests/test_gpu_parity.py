@@ -458,11 +458,12 @@ def test_lazy_convert_redo_path(oracle):
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(params=["three_pass", "single_pass"])
 def compaction_path(request, monkeypatch):
-    """The three-pass path is the default; the single-pass one is opt-in by environment."""
+    """Every compaction implementation must give the reference's `-c -m -t1` order bit for bit.
+    three_pass = count + scan + emit (the default); single_pass = the one-launch kernel (opt-in by environment)."""
+    for k in ("PCS_COMPACT_PATH", "PCS_COMPACT_SINGLE_PASS", "PCS_COMPACT_TICKETS"):
+        monkeypatch.delenv(k, raising=False)
     if request.param == "single_pass":
-        monkeypatch.setenv("PCS_COMPACT_SINGLE_PASS", "1")
-    else:
-        monkeypatch.delenv("PCS_COMPACT_SINGLE_PASS", raising=False)
+        monkeypatch.setenv("PCS_COMPACT_PATH", "single")
     return request.param
 
 
@@ -691,3 +692,127 @@ def test_half_pixel_texcoords_fuzzed_configurations(oracle):
             got, _ = run_fused([sc], [depth], [color], FLAG_TEXCOORD_HALF_PIXEL | extra)
             d = first_diff(got, want)
             assert d is None, f"trial {trial} extra {extra}: {d}"
+
+
+# ---------------------------------------------------------------------------------------------
+# throughput forms: K frame-sets per launch, all cameras' rs2::points per launch
+# ---------------------------------------------------------------------------------------------
+def _upload(ctx, arrays):
+    ptrs = [ctx.device_malloc(max(a.nbytes, 16)) for a in arrays]
+    for p, a in zip(ptrs, arrays):
+        ctx.memcpy_h2d(p, a)
+    return ptrs
+
+
+@pytest.mark.parametrize("n_streams,shape,n_sets", [(3, (640, 480), 3), (8, (320, 240), 11), (1, (1280, 720), 5),
+                                                    (40, (64, 48), 3)])
+def test_batch_of_frame_sets_equals_single_calls(oracle, n_streams, shape, n_sets):
+    """pcs_process_frames_device_batch: every frame-set's payload is byte-identical to a pcs_process_frames_device
+    call on it (and to the oracle). 8 x 11 sets exceeds one launch's 64 entries -> two batched launches; 40 streams
+    leaves room for one set per launch -> the set-by-set fallback."""
+    cfgs = [S.synth_stream_config(*shape, s) for s in range(n_streams)]
+    sets = [([S.synth_depth(*shape, s, seed=S.SEED + 101 * k) for s in range(n_streams)],
+             [S.synth_color(*shape, s, seed=S.SEED + 101 * k) for s in range(n_streams)]) for k in range(n_sets)]
+    n_sh = sum(c.n_points for c in cfgs) * POINT_SHORTS
+    with PcsContext(cfgs) as ctx:
+        dd = [_upload(ctx, d) for d, _ in sets]
+        dc = [_upload(ctx, c) for _, c in sets]
+        outs = [ctx.device_malloc(n_sh * 2 + 64) for _ in range(n_sets)]
+        singles = []
+        for k in range(n_sets):
+            ctx.process_frames_device(dd[k], dc[k], outs[k], n_sh)
+            ctx.synchronize()
+            got = np.empty(n_sh, np.int16)
+            ctx.memcpy_d2h(got, outs[k])
+            singles.append(got)
+            ctx.memcpy_h2d(outs[k], np.zeros(n_sh, np.int16))
+        d_counts = [ctx.device_malloc(4 * (n_streams + 1)) for _ in range(n_sets)]
+        ctx.process_frames_device_batch(dd, dc, outs, n_sh, d_counts)
+        ctx.synchronize()
+        for k in range(n_sets):
+            got = np.empty(n_sh, np.int16)
+            ctx.memcpy_d2h(got, outs[k])
+            assert_same(got, singles[k])
+            cnt = np.empty(n_streams + 1, np.int32)
+            ctx.memcpy_d2h(cnt, d_counts[k])
+            assert list(cnt[:-1]) == [c.n_points for c in cfgs] and cnt[-1] == n_sh // POINT_SHORTS
+            if k in (0, n_sets - 1):
+                want, _ = oracle.process_frames(cfgs, sets[k][0], sets[k][1])
+                assert_same(got.reshape(-1, 5), want)
+
+
+@pytest.mark.parametrize("flags,skew", [(FLAG_DROP_INVALID, 0), (0, 4)])
+def test_batch_of_frame_sets_non_dense_configurations(oracle, flags, skew):
+    """Compaction, or the reference's payload alignment (buffer + 4 bytes): the batch call runs set by set."""
+    cfgs, _, _ = S.synth_frame_set(2, 640, 480)
+    sets = [S.synth_frame_set(2, 640, 480, seed=S.SEED + 7 * k)[1:] for k in range(3)]
+    n_sh = sum(c.n_points for c in cfgs) * POINT_SHORTS
+    with PcsContext(cfgs, flags=flags) as ctx:
+        dd = [_upload(ctx, d) for d, _ in sets]
+        dc = [_upload(ctx, c) for _, c in sets]
+        outs = [ctx.device_malloc(n_sh * 2 + 64) + skew for _ in range(3)]
+        d_counts = [ctx.device_malloc(4 * 3) for _ in range(3)]
+        ctx.process_frames_device_batch(dd, dc, outs, n_sh, d_counts)
+        ctx.synchronize()
+        for k in range(3):
+            want, wcounts = oracle.process_frames(cfgs, sets[k][0], sets[k][1], flags)
+            cnt = np.empty(3, np.int32)
+            ctx.memcpy_d2h(cnt, d_counts[k])
+            assert list(cnt[:2]) == wcounts
+            got = np.empty(want.size, np.int16)
+            ctx.memcpy_d2h(got, outs[k])
+            assert_same(got.reshape(-1, 5), want)
+
+
+@pytest.mark.parametrize("skew", [0, 4])
+def test_batched_pack_equals_single_clouds(oracle, skew):
+    """pcs_copy_pointclouds_xyzrgb_to_buffer_device: 19 cameras (two launches), ragged point counts incl. 0, each
+    cloud byte-identical to the oracle's copyPointCloudXYZRGBToBufferSIMD; skew 4 = the reference's buffer + 2 shorts."""
+    sizes = [5000, 0, 1, 2048, 2049, 8, 307200, 7, 4095, 64, 100, 12345, 3, 2047, 4096, 9, 640 * 48, 17, 921600]
+    clouds = [random_points(n, 500 + i, spread=3.0) for i, n in enumerate(sizes)]
+    cfgs = [c[0] for c in clouds]
+    with PcsContext(cfgs) as ctx:
+        descs, outs = [], []
+        for i, (sc, V, T, col) in enumerate(clouds):
+            dv, dt, dcol = _upload(ctx, [V, T, col])
+            out = ctx.device_malloc(max(V.shape[0], 1) * 10 + 64) + skew
+            outs.append(out)
+            descs.append((i, V.shape[0], dv, dt, dcol, out))
+        d_cnt = ctx.device_malloc(4 * len(sizes))
+        ctx.copy_pointclouds_xyzrgb_to_buffer_device(descs, d_cnt)
+        ctx.synchronize()
+        cnt = np.empty(len(sizes), np.int32)
+        ctx.memcpy_d2h(cnt, d_cnt)
+        assert list(cnt) == sizes
+        for i, (sc, V, T, col) in enumerate(clouds):
+            if sizes[i] == 0:
+                continue
+            got = np.empty(sizes[i] * 5, np.int16)
+            ctx.memcpy_d2h(got, outs[i])
+            assert_same(got.reshape(-1, 5), oracle.pack(sc, V, T, col))
+
+
+def test_batched_pack_with_cutoff_runs_cloud_by_cloud(oracle):
+    clouds = [random_points(n, 900 + i, spread=1.5) for i, n in enumerate([3000, 10007, 5])]
+    for _, V, _, _ in clouds:
+        V[:, 2] = np.abs(V[:, 2])
+    cfgs = [c[0] for c in clouds]
+    with PcsContext(cfgs, flags=FLAG_CUTOFF) as ctx:
+        descs, outs = [], []
+        for i, (sc, V, T, col) in enumerate(clouds):
+            dv, dt, dcol = _upload(ctx, [V, T, col])
+            out = ctx.device_malloc(V.shape[0] * 10 + 64)
+            outs.append(out)
+            descs.append((i, V.shape[0], dv, dt, dcol, out))
+        d_cnt = ctx.device_malloc(12)
+        ctx.copy_pointclouds_xyzrgb_to_buffer_device(descs, d_cnt)
+        ctx.synchronize()
+        cnt = np.empty(3, np.int32)
+        ctx.memcpy_d2h(cnt, d_cnt)
+        for i, (sc, V, T, col) in enumerate(clouds):
+            want = oracle.pack(sc, V, T, col, FLAG_CUTOFF)
+            assert cnt[i] == want.shape[0]
+            got = np.empty(want.size, np.int16)
+            if want.size:
+                ctx.memcpy_d2h(got, outs[i])
+            assert_same(got.reshape(-1, 5), want)

@@ -150,3 +150,39 @@ def test_gpu_voxel_grid_argument_errors():
         with pytest.raises(PcsError) as e:
             ctx.voxel_grid(p, 40000)
         assert e.value.status == -1
+
+
+@pytest.mark.gpu
+def test_config5_full_size_against_oracle_digests():
+    """BASELINE configs[4] at FULL size on one GPU: 16 x 1920x1080 synthetic streams -> invalid-depth compaction ->
+    camera-order stitch -> voxel grid (50 mm and 200 mm) of the 29.8 M-point cloud, all device-resident. The CPU oracle
+    needs about a minute for this, so its outputs are pinned as SHA-256 digests by
+    tests/golden/make_config5_golden.py (committed, re-runnable) and compared here."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5_digests.json")))
+    cfgs, depth, color = S.synth_frame_set(16, 1920, 1080)
+    n_max = sum(c.n_points for c in cfgs)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        dd = [ctx.device_malloc(d.nbytes) for d in depth]
+        dc = [ctx.device_malloc(c.nbytes) for c in color]
+        for ptr, a in zip(dd + dc, depth + color):
+            ctx.memcpy_h2d(ptr, a)
+        d_pay = ctx.device_malloc(n_max * 10 + 64)
+        d_cnt = ctx.device_malloc(4 * 17)
+        ctx.process_frames_device(dd, dc, d_pay, n_max * 5, d_cnt)
+        ctx.synchronize()
+        cnt = np.empty(17, np.int32); ctx.memcpy_d2h(cnt, d_cnt)
+        assert list(cnt[:16]) == gold["counts"] and int(cnt[16]) == gold["points"]
+        stitched = np.empty(int(cnt[16]) * 5, np.int16); ctx.memcpy_d2h(stitched, d_pay)
+        assert hashlib.sha256(stitched.tobytes()).hexdigest() == gold["stitched_sha256"]
+        d_vox = ctx.device_malloc(int(cnt[16]) * 10 + 64)
+        d_nv = ctx.device_malloc(4)
+        for leaf, want in sorted(gold["voxel"].items()):
+            ctx.voxel_grid_device(d_pay, int(cnt[16]), int(leaf), d_vox, int(cnt[16]) * 5, d_nv)
+            ctx.synchronize()
+            nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
+            assert int(nv[0]) == want["voxels"], leaf
+            got = np.empty(int(nv[0]) * 5, np.int16); ctx.memcpy_d2h(got, d_vox)
+            assert hashlib.sha256(got.tobytes()).hexdigest() == want["sha256"], leaf

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Print VGPR / spill / occupancy / LDS of every kernel in pcs_kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage).
+Usage: python tools/kernel_resources.py [substring ...]"""
+import os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pointcloud_stitching_amd", "csrc")
+src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "pcs_kernels.hip"
+pats = [a for a in sys.argv[1:] if not a.endswith(".hip")]
+flags = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt".split()
+if src == "pcs_kernels.hip":
+    flags.append("-fno-slp-vectorize")
+r = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
+                   cwd=CSRC, capture_output=True, text=True)
+blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+names = [b.split("\n")[0].strip(" []") for b in blocks]
+dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+for b, dn in zip(blocks, dem):
+    if pats and not any(p in dn for p in pats):
+        continue
+    g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
+    dn = dn.replace("pcs::(anonymous namespace)::", "").replace("void ", "")
+    dn = re.sub(r"\(pcs::StreamParams.*", "", dn)
+    print(f"{dn[:100]:100s} VGPR {g('VGPRs'):>3} AGPR {g('AGPRs'):>3} spill {g('VGPRs Spill'):>3} scratch {g('ScratchSize .bytes/lane.'):>4} "
+          f"occ {g('Occupancy .waves/SIMD.'):>2} LDS {g('LDS Size .bytes/block.'):>6}")
