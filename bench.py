@@ -610,6 +610,29 @@ def main():
                                  "note": "PCS_FLAG_DROP_INVALID, order-preserving (= the reference's -c -m -t1 order), same cold ring; "
                                          "bytes = 2 (Z16) + 3 (RGB8) + 10*rho (records)"}
             ctx_c.close()
+            if "PCS_COMPACT_PATH" not in os.environ:
+                # the opt-in one-launch kernel (its forward progress assumes in-order workgroup dispatch; bounded waits and a
+                # three-pass re-run catch a violation — which is why it is not the default)
+                os.environ["PCS_COMPACT_PATH"] = "single"
+                try:
+                    ctx_s = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
+                finally:
+                    del os.environ["PCS_COMPACT_PATH"]
+                ctx_s.set_stream(stream.cuda_stream)
+
+                def launch_s():
+                    dp, cp, outp = call_args[next_slot()]
+                    check(lib.pcs_process_frames_device(ctx_s._h, dp, cp, outp, payload_shorts, None), ctx_s._h)
+                for _ in range(100):
+                    launch_s()
+                torch.cuda.synchronize(dev)
+                ms_s = timed(launch_s, n_leg, ctx_s)
+                ctx_s.synchronize()          # raises if a placement wait ever expired
+                ach_s = set_points * (5 + 10 * rho) / (ms_s * 1e-3) / 1e9
+                out["compaction"]["single_pass_opt_in"] = {"ms_per_step": round(ms_s, 5), "achieved": round(ach_s, 1),
+                                                           "frac": round(ach_s / HBM_PEAK_GBS, 4),
+                                                           "note": "PCS_COMPACT_PATH=single: one launch, Z16 read once"}
+                ctx_s.close()
             # ---- K frame-sets per launch (throughput form of the dense path) --------------------------------------------
             if KB >= 2:
                 for _ in range(30):

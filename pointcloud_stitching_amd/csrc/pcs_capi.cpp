@@ -425,11 +425,12 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             cl.d_stream_desc = c->d_desc + c->total_tiles;
             cl.d_chain_in = s0 > 0 ? c->d_stream_end + (s0 - 1) : nullptr;
             cl.d_error = c->d_error; cl.gen = c->compact_seq; cl.flags = c->flags;
+            cl.d_counts = d_counts ? d_counts : c->d_counts; cl.n_total = c->n_streams;
+            cl.last_launch = (s0 + nl == c->n_streams) ? 1 : 0;
             HIPCHK(c, launch_fused_compact(c->d_params, s0, nl, tiles, m >= 1 ? MathSel::Cert : MathSel::Ieee, fp, cl,
                                            d_payload, c->stream));
             c->tickets_issued += tiles;
         }
-        HIPCHK(c, launch_counts(c->d_stream_end, c->n_streams, d_counts ? d_counts : c->d_counts, c->stream));
         if (c->kernel_timing) {
             HIPCHK(c, hipEventRecord(ev.second, c->stream));
             c->ev_pool.push_back(ev);
@@ -444,8 +445,9 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             for (int k = 0; k < nl; k++) { fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k]; mp = std::max(mp, c->h_params[s0 + k].n_points); }
             HIPCHK(c, launch_fused_count(c->d_params, s0, nl, mp, c->flags, fp, c->d_tile_counts, c->stream));
         }
+        // per-stream counts come from the scan; the grand total from the first emit launch (no last-arriver atomic)
         HIPCHK(c, launch_scan(c->d_params, c->n_streams, c->downsample, c->d_tile_counts, c->d_tile_prefix,
-                              c->d_stream_base, d_counts ? d_counts : c->d_counts, c->d_arrive, c->stream));
+                              c->d_stream_base, d_counts ? d_counts : c->d_counts, nullptr, c->stream));
     }
     for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
         const int nl = std::min(kLaunchStreams, c->n_streams - s0);
@@ -467,7 +469,8 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             HIPCHK(c, launch_fused_dense(c->d_params, s0, nl, mp, dd, cd, sel, fp, d_payload, c->stream));
         else
             HIPCHK(c, launch_fused_emit(c->d_params, s0, nl, mp, c->flags, c->downsample, sel, fp, c->d_tile_prefix,
-                                        c->d_stream_base, d_payload, c->stream));
+                                        c->d_stream_base, d_payload,
+                                        pred ? (d_counts ? d_counts : c->d_counts) + c->n_streams : nullptr, c->n_streams, c->stream));
     }
     if (!pred && d_counts)     // counts are known from the configuration: a device-to-device copy, no host sync
         HIPCHK(c, hipMemcpyAsync(d_counts, c->d_static_counts, sizeof(int32_t) * (c->n_streams + 1),

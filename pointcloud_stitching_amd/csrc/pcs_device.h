@@ -94,7 +94,9 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
 // Generic path: predicate / downsample / unaligned payload / W % 8 != 0.
 //   d_tile_counts, d_tile_prefix : one uint32 per tile of every stream (StreamParams::tile_base indexes them)
 //   d_stream_kept                : n_total_streams uint32 (kept points per stream, before the stride)
-//   d_arrive                     : one zero-initialised uint32 (scan workgroups' arrival counter; self-resetting)
+//   d_arrive                     : nullptr for the fused path (the per-stream counts come from the scan, the grand total
+//                                  from the first emit launch: d_total_out); the a2 twin's launch_pack_scan passes one
+//                                  zero-initialised uint32 (arrival counter, self-resetting) and gets the total from the scan
 //   d_counts (optional)          : n_total_streams + 1 int32 handed back to the caller
 // launch_pack_scan: d_out_points receives 2 int32 (kept, total)
 hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
@@ -105,7 +107,7 @@ hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsamp
 hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                              uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
                              const uint32_t* d_tile_prefix, const uint32_t* d_stream_kept,
-                             int16_t* d_payload, hipStream_t st);
+                             int16_t* d_payload, int32_t* d_total_out, int n_total_streams, hipStream_t st);
 // Single-pass ordered compaction (predicate, stride 1). See pcs_fused_compact_kernel.
 struct CompactLaunch {
     unsigned long long* d_ticket;       // device counter, never reset
@@ -117,11 +119,13 @@ struct CompactLaunch {
     uint32_t*           d_error;
     uint32_t            gen;
     uint32_t            flags;
+    int32_t*            d_counts;       // n_total + 1 ints: per-stream kept counts and the total (written by the kernel)
+    int32_t             n_total;        // streams of the whole frame-set
+    int32_t             last_launch;    // this launch holds the frame-set's last stream
 };
 hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n_launch, uint32_t launch_tiles,
                                 MathSel math, const FramePtrs& fp, const CompactLaunch& cl, int16_t* d_payload,
                                 hipStream_t st);
-hipError_t launch_counts(const uint32_t* d_stream_end, int n_streams, int32_t* d_counts, hipStream_t st);
 
 // K frame-sets per launch (dense path only).
 hipError_t launch_fused_dense_batch(const StreamParams* d_params, int n_streams, int n_sets, uint32_t max_points,

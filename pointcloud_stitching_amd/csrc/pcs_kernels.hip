@@ -746,6 +746,9 @@ struct CompactArgs {
     uint32_t*           error;
     uint32_t            gen;
     uint32_t            flags;
+    int32_t*            counts;       // [n_total + 1] per-stream kept counts + total, written by each launch's last tile
+    int32_t             n_total;      // streams of the whole frame-set
+    int32_t             last_launch;  // this launch holds the frame-set's last stream
 };
 
 template <class Mth>
@@ -830,6 +833,7 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
     const uint32_t first = gtile - t;
     for (uint32_t j = first + threadIdx.x; j < gtile; j += kBlockThreads) own += desc_wait(a.desc + j, a.gen, a.error);
     if ((int)threadIdx.x < s) tot = desc_wait(a.stream_desc + stream0 + threadIdx.x, a.gen, a.error);
+    const uint32_t tot_lane = tot;     // lane e < s: kept points of stream stream0 + e
     own = wave_sum(own);
     tot = wave_sum(tot);
     if (lane == 0) { psum[wave] = own; psum[4 + wave] = tot; }
@@ -841,6 +845,15 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
         __hip_atomic_store(a.stream_desc + stream0 + s, desc_pack(a.gen, kDescReady, own_excl + tile_kept), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         a.stream_end[stream0 + s] = q_lo + tile_kept;
+    }
+    // The launch's very last tile has every stream total of the launch in its lanes: it hands the counts back itself
+    // (a separate one-workgroup kernel for this cost 4.8 us of launch latency per frame-set).
+    if (a.counts && s == n_launch - 1 && t == tiles_s - 1) {
+        if ((int)threadIdx.x < s) a.counts[stream0 + threadIdx.x] = (int32_t)tot_lane;
+        if (threadIdx.x == 0) {
+            a.counts[stream0 + s] = (int32_t)(own_excl + tile_kept);
+            if (a.last_launch) a.counts[a.n_total] = (int32_t)(q_lo + tile_kept);
+        }
     }
 
     uint8_t* gdst = payload_bytes + (size_t)q_lo * PCS_POINT_BYTES;
@@ -855,14 +868,6 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
     }
     __syncthreads();
     store_staged(stage, head, tile_kept * PCS_POINT_BYTES, gdst);
-}
-
-// counts[s] = points stream s contributed, counts[n] = total; from the per-stream inclusive ends.
-__global__ void pcs_counts_kernel(const uint32_t* __restrict__ stream_end, int n_streams, int32_t* __restrict__ counts)
-{
-    const int s = threadIdx.x;
-    if (s < n_streams) counts[s] = (int32_t)(stream_end[s] - (s ? stream_end[s - 1] : 0u));
-    if (s == 0) counts[n_streams] = (int32_t)stream_end[n_streams - 1];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -904,53 +909,85 @@ void pcs_fused_dense_batch_kernel(const StreamParams* __restrict__ params, Batch
 // Count pass: kept points per tile. (Folding the per-stream scan into this launch through a last-arriver
 // counter was measured and is slower — 450 returning atomics per counter line cost more than the separate
 // 5 us scan launch)
+// A workgroup counts kCountTiles consecutive tiles: the (independent) Z16 loads of all of them are in flight together,
+// so the launch is one HBM round trip deep with a quarter of the workgroups (3 600 one-tile workgroups measured
+// 5.1 us for the 14.7 MB of 8 x 720p: latency, not bandwidth).
+constexpr int kCountTiles = 4;
 template <bool DDIST, bool CDIST>
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                             uint32_t* __restrict__ tile_counts)
 {
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[kCountTiles][4];
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
     const uint32_t n = P.n_points;
-    const uint32_t tile0 = blockIdx.x * kTilePoints;
-    if (tile0 >= n) return;
-    const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
-    uint32_t c;
+    const uint32_t tile_first = blockIdx.x * kCountTiles;
+    if (tile_first * kTilePoints >= n) return;
+    uint32_t c[kCountTiles];
+    const uint16_t* __restrict__ dp = fp.depth[s];
     if ((flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
         // z = depth_scale * d is zero exactly when d is (the host checked the scale: finite, and scale*1 != 0):
         // count the non-zero Z16 values, no deprojection needed
-        c = 0;
-        const uint16_t* __restrict__ dp = fp.depth[s];
-        if (i0 + 8 <= n && ((uintptr_t)dp & 15) == 0 && (i0 & 7u) == 0) {
-            const uint4 dv = *reinterpret_cast<const uint4*>(dp + i0);
-            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        uint4 dv[kCountTiles];
+        const bool aligned = ((uintptr_t)dp & 15) == 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) c += ((dw[k] & 0xFFFFu) != 0u) + ((dw[k] >> 16) != 0u);
-        } else {
-            for (uint32_t k = 0; k < 8 && i0 + k < n; k++) c += dp[i0 + k] != 0;
+        for (int q = 0; q < kCountTiles; q++) {
+            const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
+            dv[q] = make_uint4(0, 0, 0, 0);
+            if (aligned && i0 + 8 <= n) dv[q] = *reinterpret_cast<const uint4*>(dp + i0);
+        }
+#pragma unroll
+        for (int q = 0; q < kCountTiles; q++) {
+            const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
+            const uint32_t dw[4] = {dv[q].x, dv[q].y, dv[q].z, dv[q].w};
+            c[q] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[q] += ((dw[k] & 0xFFFFu) != 0u) + ((dw[k] >> 16) != 0u);
+            if (!(aligned && i0 + 8 <= n))
+                for (uint32_t k = 0; k < 8 && i0 + k < n; k++) c[q] += dp[i0 + k] != 0;
         }
     } else {
-        DepthSource<DDIST, CDIST> src{fp.depth[s]};
-        PointIn p[8];
-        src.load8(P, i0, n, p, nullptr);
-        c = __popc(keep_mask8(p, i0, n, flags));
+        DepthSource<DDIST, CDIST> src{dp};
+#pragma unroll
+        for (int q = 0; q < kCountTiles; q++) {
+            const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
+            PointIn p[8];
+            src.load8(P, i0, n, p, nullptr);
+            c[q] = __popc(keep_mask8(p, i0, n, flags));
+        }
     }
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+#pragma unroll
+    for (int q = 0; q < kCountTiles; q++) {
+        const uint32_t w = wave_sum(c[q]);
+        if ((threadIdx.x & 63) == 0) wsum[q][threadIdx.x >> 6] = w;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) tile_counts[P.tile_base + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x < kCountTiles && (tile_first + threadIdx.x) * kTilePoints < n)
+        tile_counts[P.tile_base + tile_first + threadIdx.x] =
+            wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
 }
 
+// (Placing the emit tiles straight from per-chunk totals of the count pass — no scan launch, four extra L2-resident loads
+// per lane riding on the tile's existing barrier — was built and measured: 32.4 vs 32.5 us on 8 x 720p and 127 vs 107 us
+// on 16 x 1080p. Whatever the scan launch costs, extra memory instructions in the emit tile cost at least as much.)
 template <bool PRED, bool DS1, class Mth>
 __global__ __launch_bounds__(kBlockThreads, 6)      // 6 waves/SIMD (<= 80 VGPRs): measured faster than the unconstrained 5
 void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                            uint32_t ds, const uint32_t* __restrict__ tile_prefix,
-                           const uint32_t* __restrict__ stream_kept, uint8_t* __restrict__ payload_bytes)
+                           const uint32_t* __restrict__ stream_kept, uint8_t* __restrict__ payload_bytes,
+                           int32_t* __restrict__ total_out, int n_total_streams)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t wsum[4];
     const int s = blockIdx.y;
+    if (PRED && total_out && blockIdx.x == 0 && stream0 + s == 0 && threadIdx.x == 0) {
+        // the grand total rides on the first workgroup of the first emit launch (the scan kernel used to compute it
+        // with a last-arriver atomic: a third of its 4.8 us)
+        uint32_t tot = 0;
+        for (int e = 0; e < n_total_streams; e++) tot += DS1 ? stream_kept[e] : (stream_kept[e] + ds - 1) / ds;
+        *total_out = (int32_t)tot;
+    }
     const StreamParams& P = params[stream0 + s];
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
@@ -1001,7 +1038,9 @@ void pcs_scan_kernel(const StreamParams* __restrict__ params, int stream0, int n
         const uint32_t kept = carry_s;
         const uint32_t outc = (kept + ds - 1) / ds;
         if (stream_kept) stream_kept[stream0 + s] = kept;
-        if (counts) {
+        if (counts && !arrive) {
+            counts[stream0 + s] = (int32_t)outc;      // the emit kernel that follows adds up the grand total
+        } else if (counts) {
             // grand total: the last workgroup to arrive adds up the per-stream outputs. The per-stream
             // counts are written with agent-scope stores and read back with agent-scope loads, and the
             // arrival counter is an agent-scope atomic, so the last arriver sees every other write.
@@ -1203,7 +1242,8 @@ hipError_t launch_fused_count(const StreamParams* d_params, int stream0, int n_l
                               uint32_t flags, const FramePtrs& fp, uint32_t* d_tile_counts, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
-    const dim3 grid = tile_grid(max_points, n_launch);
+    const uint32_t tiles = (max_points + kTilePoints - 1) / kTilePoints;
+    const dim3 grid((tiles + kCountTiles - 1) / kCountTiles, (unsigned)n_launch, 1);
     // the predicate depends on depth-side distortion only through x; always run the general form
     hipLaunchKernelGGL((pcs_fused_count_kernel<true, false>), grid, dim3(kBlockThreads), 0, st,
                        d_params, stream0, fp, flags, d_tile_counts);
@@ -1222,7 +1262,7 @@ hipError_t launch_scan(const StreamParams* d_params, int n_streams, int downsamp
 hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                              uint32_t flags, int downsample, MathSel math, const FramePtrs& fp,
                              const uint32_t* d_tile_prefix, const uint32_t* d_stream_kept,
-                             int16_t* d_payload, hipStream_t st)
+                             int16_t* d_payload, int32_t* d_total_out, int n_total_streams, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     const dim3 grid = tile_grid(max_points, n_launch);
@@ -1230,7 +1270,8 @@ hipError_t launch_fused_emit(const StreamParams* d_params, int stream0, int n_la
     const bool ds1 = downsample == 1;
     uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
 #define L(PR, D1, M) hipLaunchKernelGGL((pcs_fused_emit_kernel<PR, D1, M>), grid, dim3(kBlockThreads), 0, st, d_params, \
-                                        stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_kept, out)
+                                        stream0, fp, flags, (uint32_t)downsample, d_tile_prefix, d_stream_kept, out, \
+                                        d_total_out, n_total_streams)
 #define LM(M) do { if (pred) { if (ds1) L(true, true, M); else L(true, false, M); } \
                    else      { if (ds1) L(false, true, M); else L(false, false, M); } } while (0)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
@@ -1249,6 +1290,7 @@ hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n
     a.ticket = cl.d_ticket; a.ticket_base = cl.ticket_base; a.desc = cl.d_desc; a.stream_desc = cl.d_stream_desc;
     a.stream_end = cl.d_stream_end;
     a.chain_in = cl.d_chain_in; a.error = cl.d_error; a.gen = cl.gen & 0x3FFFFFFFu; a.flags = cl.flags;
+    a.counts = cl.d_counts; a.n_total = cl.n_total; a.last_launch = cl.last_launch;
     uint8_t* out = reinterpret_cast<uint8_t*>(d_payload);
     if (math != MathSel::Ieee)
         hipLaunchKernelGGL((pcs_fused_compact_kernel<CertMath<false>>), dim3(launch_tiles), dim3(kBlockThreads), 0, st,
@@ -1288,12 +1330,6 @@ hipError_t launch_pack_batch(const StreamParams* d_params, const PackBatch& pb, 
     const dim3 grid = tile_grid(max_points, n);
     if (aligned) hipLaunchKernelGGL((pcs_pack_batch_kernel<true>), grid, dim3(kBlockThreads), 0, st, d_params, pb);
     else         hipLaunchKernelGGL((pcs_pack_batch_kernel<false>), grid, dim3(kBlockThreads), 0, st, d_params, pb);
-    return hipGetLastError();
-}
-
-hipError_t launch_counts(const uint32_t* d_stream_end, int n_streams, int32_t* d_counts, hipStream_t st)
-{
-    hipLaunchKernelGGL(pcs_counts_kernel, dim3(1), dim3(64), 0, st, d_stream_end, n_streams, d_counts);
     return hipGetLastError();
 }
 
