@@ -245,8 +245,8 @@ int pcs_stitch_device(pcs_ctx* ctx, const int16_t* const* d_cam_payload, const i
  * payload's integer millimetre domain: voxel = floor(coord / leaf_mm) per axis; one output point per occupied
  * voxel = integer mean of x,y,z (truncating) and of R,G,B; output sorted by (z,y,x) voxel, x fastest.
  * The output needs room for n_points points in the worst case. *d_out_points / *out_points = voxels written.
- * The device form queues its work on the context stream but synchronises that stream once in the middle
- * (the number of pre-aggregated runs sizes the sort).                                               */
+ * The device form is fully asynchronous on the context stream (pre-aggregation, radix sort and segmented mean are
+ * hand-written kernels that read their sizes from device memory; no host round trip in the middle).            */
 int pcs_voxel_grid_device(pcs_ctx* ctx, const int16_t* d_payload, int n_points, int leaf_mm,
                           int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
 int pcs_voxel_grid(pcs_ctx* ctx, const int16_t* payload, int n_points, int leaf_mm,

@@ -43,6 +43,17 @@ int  pcs_node_process_device(pcs_node* node, const uint16_t* const* d_depth, con
                              int16_t* d_stitched_payload_root, size_t stitched_shorts,
                              int* points_per_stream, int* total_points);
 
+/* Pipelined device form: up to two frame-sets in flight. pcs_node_submit_device enqueues the kernels of one frame-set on
+ * every GPU's kernel stream and its exchange on per-GPU communication streams, then returns a ticket; pcs_node_wait
+ * blocks until that frame-set's stitched payload is complete on the root. Writing the loop as  submit(k+1); wait(k);
+ * overlaps the xGMI exchange of frame-set k with the kernels of k+1 (each GPU keeps two payload buffers). The two
+ * frame-sets need different stitched buffers. Without CUTOFF / DROP_INVALID nothing is read back from the GPUs;
+ * with a predicate submit synchronises each GPU once (the exchange is sized by the data dependent counts).
+ * PCS_ERR_CAPACITY from submit = two frame-sets already in flight. pcs_node_process_device = submit + wait.     */
+int  pcs_node_submit_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                            int16_t* d_stitched_payload_root, size_t stitched_shorts, int* ticket);
+int  pcs_node_wait(pcs_node* node, int ticket, int* points_per_stream, int* total_points);
+
 #ifdef __cplusplus
 }
 #endif

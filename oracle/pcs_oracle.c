@@ -182,7 +182,7 @@ int pcs_oracle_voxel_grid(const int16_t* payload, int n_points, int leaf_mm, int
     qsort(v, (size_t)n_points, sizeof(pcs_o_vk), pcs_o_vk_cmp);
     int nv = 0;
     for (int i = 0; i < n_points;) {
-        int64_t sx = 0, sy = 0, sz = 0; uint32_t r = 0, g = 0, b = 0, n = 0;
+        int64_t sx = 0, sy = 0, sz = 0; uint64_t r = 0, g = 0, b = 0; uint32_t n = 0;   /* 64-bit: > 16.8 M points can share a voxel */
         int j = i;
         for (; j < n_points && v[j].key == v[i].key; j++) {
             const int16_t* p = payload + PCS_POINT_SHORTS * (size_t)v[j].idx;

@@ -3,7 +3,7 @@
 // timing, stdout lines and the TCP push are kept; the per-frame work goes through the C ABI.
 //
 //   reference flags (getopt "hf:vst:cmz", :122):  -h  -f <file>  -v  -s  -t <n>  -c  -m  -z
-//   additions:  -g <dev>  -n <streams>  -d <stride>  -i (drop invalid depth)  -C (reference -c lane quirk)
+//   additions:  -g <dev>  -n <streams>  -d <stride>  -i (drop invalid depth)  -C (-c without the reference's lane quirk)
 //               -r <frames>  -o <file> (dump last stitched buffer)  -p <port>
 //               -e <file> (camera-to-world matrices instead of the ones pasted into the reference's sources)
 //               -H (texture coordinates as older librealsense releases computed them: (pixel + 0.5) / size)
@@ -48,7 +48,8 @@ static void print_usage()
            "  -s        send data to central camera server if available (TCP push on port 8000)\n"
            "  -m        use the MI355X HIP path (the reference's SIMD switch)\n"
            "  -t <n>    OpenMP threads of the reference path; accepted, inert on the HIP path\n"
-           "  -c        cutoff 0<z<=1.5, -2<x<=2 with compaction   -C  same with the reference's lane quirk\n"
+           "  -c        cutoff 0<z<=1.5, -2<x<=2 with compaction, exactly as the reference's -c -m computes it (point k of an\n"
+           "            aligned group of four is gated by point 3-k's test)   -C  every point by its own test\n"
            "  -i        drop invalid-depth pixels   -d <n> keep every n-th point   -n <N> camera streams\n"
            "  -g <dev>  GPU ordinal   -r <frames>   -o <file> dump last stitched buffer   -p <port>\n"
            "  -P        serve frames on 'Z' pull requests (the live server's protocol) instead of pushing them\n"
@@ -66,8 +67,8 @@ static void parseArgs(int argc, char** argv)
             case 'v': display_updates = true; break;
             case 's': send_buffer = true; break;
             case 't': num_of_threads = atoi(optarg); break;
-            case 'c': cutoff = true; break;
-            case 'C': cutoff = true; cutoff_compat = true; break;
+            case 'c': cutoff = true; cutoff_compat = true; break;     // the reference's -c -m payload, lane quirk included (:501-502, 519)
+            case 'C': cutoff = true; cutoff_compat = false; break;    // every point by its own range test
             case 'H': half_pixel = true; break;
             case 'm': use_hip = true; break;
             case 'z': compress = true; break;

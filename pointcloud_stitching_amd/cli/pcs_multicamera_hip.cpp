@@ -1,7 +1,8 @@
-// pcs-multicamera-hip — the central stitcher (src/pcs-multicamera-client.cpp, non-visual path) on MI355X.
+// pcs-multicamera-optimized — the central stitcher (src/pcs-multicamera-optimized.cpp / pcs-multicamera-client.cpp,
+// non-visual path) on MI355X. Installed under the reference's program name; `pcs-multicamera-hip` is a link to it.
 //
 // Two ways to feed it:
-//   -f synth:<W>x<H> | frames.pcsraw   all cameras' rasters are on this node: ONE fused launch produces the
+//   -i synth:<W>x<H> | frames.pcsraw   all cameras' rasters are on this node: ONE fused launch produces the
 //                                       stitched buffer (edge + central collapsed)
 //   -c host:port[,host:port...]         existing edge servers (the reference's, or pcs-camera-optimized -s):
 //                                       one reader thread per camera like readCloud (:363-371); payloads are
@@ -10,10 +11,12 @@
 // [int32 bytes][points] (:397-403). -t prints the running average like runStitching (:417-430).
 //
 //   reference flags (getopt "hftsvd:n", src/pcs-multicamera-optimized.cpp:90): -h -f -t -s -v -d <n> -n
-//     -f here takes a frame source (the reference's "fast" switch only thinned its PCL viewer); -s (save PLY),
-//     -v (PCL visualiser) and -n belong to the PCL viewer, which this build does not have: refused with a reason.
-//   additions: -c <list>  -N <streams>  -g <gpu>  -p <serve port>  -r <frame-sets>  -o <file>  -q (no server)
-//              -G <n>  shard the cameras of -f over n GPUs: libpcs_node (ncclCommInitAll + one grouped send/recv to GPU 0)
+//     -f is the reference's boolean "fast" switch (:96-98; it only dropped colour in the PCL viewer): accepted, inert,
+//     with a one-line notice — an existing `-f -t -d2` invocation keeps working. -s (save PLY), -v (PCL visualiser)
+//     and -n belong to the PCL viewer, which this build does not have: refused with a reason.
+//   additions: -i <src>  -c <list>  -N <streams>  -g <gpu>  -p <serve port>  -r <frame-sets>  -o <file>  -q (no server)
+//              -G <n>  shard the cameras of -i over n GPUs: libpcs_node (ncclCommInitAll + one grouped send/recv to GPU 0)
+//     with neither -i nor -c the cameras are 8 synthetic 1280x720 streams on this node (there are no live cameras here).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,14 +44,15 @@ static const char* dump_path = nullptr;
 
 static void usage()
 {
-    std::cout << "\nMulticamera pointcloud stitching (MI355X)\nUsage: pcs-multicamera-hip [options]\n\nOptions:\n"
+    std::cout << "\nMulticamera pointcloud stitching (MI355X)\nUsage: pcs-multicamera-optimized [options]\n\nOptions:\n"
               << " -h (help)        Display command line options\n"
+              << " -f (fast)        Accepted for compatibility (it thinned the reference's PCL viewer); no effect\n"
               << " -t (timer)       Displays the runtime of certain functions\n"
               << " -d (downsample)  Downsamples the stitched pointcloud by the specified integer\n"
-              << " -f <src>         cameras on this node: synth:<W>x<H> or frames.pcsraw\n"
+              << " -i <src>         cameras on this node: synth:<W>x<H> or frames.pcsraw (default synth:1280x720)\n"
               << " -c <list>        edge servers host:port,... (pull 'Z' protocol)\n"
               << " -N <n> streams   -g <gpu>   -p <port> (default 9000)   -r <frame-sets>   -o <file>   -q no server\n"
-              << " -G <n>           shard the -f cameras over n GPUs of this node (one process, RCCL gather to GPU 0)\n"
+              << " -G <n>           shard the -i cameras over n GPUs of this node (one process, RCCL gather to GPU 0)\n"
               << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
 }
 
@@ -56,11 +60,14 @@ int main(int argc, char** argv)
 {
     signal(SIGPIPE, SIG_IGN);
     int c;
-    while ((c = getopt(argc, argv, "hf:tsvd:nc:N:g:p:r:o:qG:")) != -1) {
+    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:")) != -1) {
         switch (c) {
             case 't': timer = true; break;
             case 'd': downsample = atoi(optarg); break;
-            case 'f': source = optarg; break;
+            case 'f':      // src/pcs-multicamera-optimized.cpp:96-98
+                std::cerr << "-f (fast) only thinned the reference's PCL viewer; accepted, no effect on the stitched cloud" << std::endl;
+                break;
+            case 'i': source = optarg; break;
             case 'c': cameras = optarg; break;
             case 'N': n_streams = atoi(optarg); break;
             case 'g': device = atoi(optarg); break;
@@ -76,7 +83,8 @@ int main(int argc, char** argv)
         }
     }
     if (downsample < 1) { std::cerr << "downsample must be >= 1" << std::endl; return 2; }
-    if ((source == nullptr) == (cameras == nullptr)) { std::cerr << "give exactly one of -f <src> or -c <edge list>" << std::endl; usage(); return 2; }
+    if (source && cameras) { std::cerr << "give at most one of -i <src> or -c <edge list>" << std::endl; usage(); return 2; }
+    if (!source && !cameras) source = "synth:1280x720";      // no live cameras on this node: the synthetic generator
 
     // ---- frame source / edge connections -------------------------------------------------------
     std::vector<pcs_stream_config> cfgs;
@@ -123,7 +131,7 @@ int main(int argc, char** argv)
 
     pcs_node* node = nullptr;
     if (n_gpus > 0) {
-        if (!source) { std::cerr << "-G applies to cameras on this node (-f)" << std::endl; return 2; }
+        if (!source) { std::cerr << "-G applies to cameras on this node (-i)" << std::endl; return 2; }
         if (n_streams % n_gpus) { std::cerr << "-N " << n_streams << " streams do not divide over -G " << n_gpus << " GPUs" << std::endl; return 2; }
         std::vector<int> ids(n_gpus);
         for (int g = 0; g < n_gpus; g++) ids[g] = device + g;

@@ -1232,7 +1232,7 @@ int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, in
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every point its own voxel) needs %zu",
                     out_shorts, (size_t)n_points * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
-    const size_t need = voxel_workspace_bytes((uint32_t)n_points, nullptr, nullptr);
+    const size_t need = voxel_workspace_bytes((uint32_t)n_points);
     if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
     int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
     if (rc) return rc;

@@ -151,7 +151,7 @@ hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n
                             float* d_vertices, float* d_texcoords, hipStream_t st);
 
 // Voxel-grid downsample (pcs_voxel.hip).
-size_t     voxel_workspace_bytes(uint32_t n_points, size_t* sort_tmp, size_t* reduce_tmp);
+size_t     voxel_workspace_bytes(uint32_t n_points);
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
                              int16_t* d_out, int32_t* d_out_points, hipStream_t st);
 

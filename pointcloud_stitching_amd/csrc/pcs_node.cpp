@@ -19,8 +19,17 @@ struct pcs_node {
     std::vector<int> dev;
     std::vector<pcs_ctx*> ctx;
     std::vector<ncclComm_t> comm;
-    std::vector<void*> d_payload;            // per device (index 0 unused: the root packs into the stitched buffer)
+    // per device, two slots (index 0 unused: the root packs into the stitched buffer): the kernel of frame-set k+1
+    // fills one payload buffer while the exchange of frame-set k drains the other
+    std::vector<void*> d_payload[2];
     std::vector<size_t> payload_shorts;      // per device capacity
+    std::vector<hipStream_t> comm_stream;    // per device: the exchange runs here, not on the kernel stream
+    std::vector<hipEvent_t> packed[2];       // per device and slot: payload packed (kernel stream -> comm stream)
+    std::vector<hipEvent_t> drained[2];      // per device and slot: exchange done (comm stream -> kernel stream / host)
+    struct Ticket { bool busy = false; int slot = 0; std::vector<std::vector<int32_t>> cnt; size_t total = 0; };
+    Ticket inflight[2];
+    int next_ticket = 0;
+    bool pred = false;
     std::vector<void*> d_counts;             // per device: per_dev + 1 int32
     std::vector<std::vector<void*>> d_depth, d_color;   // staging for the host form, per global stream
     std::vector<pcs_stream_config> cfg;
@@ -65,7 +74,12 @@ void pcs_node_destroy(pcs_node* n)
     for (size_t r = 0; r < n->ctx.size(); r++) {
         if (!n->ctx[r]) continue;
         (void)hipSetDevice(n->dev[r]);
-        if (r < n->d_payload.size() && n->d_payload[r]) pcs_device_free(n->ctx[r], n->d_payload[r]);
+        for (int sl = 0; sl < 2; sl++) {
+            if (r < n->d_payload[sl].size() && n->d_payload[sl][r]) pcs_device_free(n->ctx[r], n->d_payload[sl][r]);
+            if (r < n->packed[sl].size() && n->packed[sl][r]) (void)hipEventDestroy(n->packed[sl][r]);
+            if (r < n->drained[sl].size() && n->drained[sl][r]) (void)hipEventDestroy(n->drained[sl][r]);
+        }
+        if (r < n->comm_stream.size() && n->comm_stream[r]) (void)hipStreamDestroy(n->comm_stream[r]);
         if (r < n->d_counts.size() && n->d_counts[r]) pcs_device_free(n->ctx[r], n->d_counts[r]);
         for (int k = 0; k < n->per_dev && r < n->d_depth.size(); k++) {
             if (k < (int)n->d_depth[r].size() && n->d_depth[r][k]) pcs_device_free(n->ctx[r], n->d_depth[r][k]);
@@ -97,7 +111,13 @@ int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int st
     n->dev.assign(device_ids, device_ids + n_devices);
     n->cfg.assign(streams, streams + n->n_streams);
     n->ctx.assign(n_devices, nullptr);
-    n->d_payload.assign(n_devices, nullptr); n->payload_shorts.assign(n_devices, 0); n->d_counts.assign(n_devices, nullptr);
+    n->payload_shorts.assign(n_devices, 0); n->d_counts.assign(n_devices, nullptr);
+    n->comm_stream.assign(n_devices, nullptr);
+    for (int sl = 0; sl < 2; sl++) {
+        n->d_payload[sl].assign(n_devices, nullptr);
+        n->packed[sl].assign(n_devices, nullptr); n->drained[sl].assign(n_devices, nullptr);
+    }
+    n->pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
     n->d_depth.assign(n_devices, std::vector<void*>(streams_per_device, nullptr));
     n->d_color.assign(n_devices, std::vector<void*>(streams_per_device, nullptr));
     for (int r = 0; r < n_devices; r++) {
@@ -109,9 +129,17 @@ int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int st
         if (rc != PCS_OK) { int e = nfail(nullptr, rc, "device %d: %s", device_ids[r], pcs_last_error(nullptr)); pcs_node_destroy(n); return e; }
         n->payload_shorts[r] = pcs_max_payload_shorts(n->ctx[r]);
         if (pcs_device_malloc(n->ctx[r], &n->d_counts[r], sizeof(int32_t) * (streams_per_device + 1)) != PCS_OK ||
-            (r > 0 && pcs_device_malloc(n->ctx[r], &n->d_payload[r], n->payload_shorts[r] * sizeof(int16_t) + 64) != PCS_OK)) {
+            (r > 0 && (pcs_device_malloc(n->ctx[r], &n->d_payload[0][r], n->payload_shorts[r] * sizeof(int16_t) + 64) != PCS_OK ||
+                       pcs_device_malloc(n->ctx[r], &n->d_payload[1][r], n->payload_shorts[r] * sizeof(int16_t) + 64) != PCS_OK))) {
             int e = nfail(nullptr, PCS_ERR_NOMEM, "device %d: %s", device_ids[r], pcs_last_error(n->ctx[r])); pcs_node_destroy(n); return e;
         }
+        hipError_t he = hipSetDevice(device_ids[r]);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&n->comm_stream[r], hipStreamNonBlocking);
+        for (int sl = 0; sl < 2 && he == hipSuccess; sl++) {
+            he = hipEventCreateWithFlags(&n->packed[sl][r], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&n->drained[sl][r], hipEventDisableTiming);
+        }
+        if (he != hipSuccess) { int e = nfail(nullptr, PCS_ERR_HIP, "device %d: %s", device_ids[r], hipGetErrorString(he)); pcs_node_destroy(n); return e; }
     }
     if (n_devices > 1) {       // one communicator per GPU, all in this process
         n->comm.assign(n_devices, nullptr);
@@ -122,50 +150,100 @@ int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int st
     return PCS_OK;
 }
 
-int pcs_node_process_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color,
-                            int16_t* d_stitched, size_t stitched_shorts, int* points_per_stream, int* total_points)
+// Pipelined device form. submit: every GPU packs its cameras on its kernel stream (the root straight into the head of
+// the stitched buffer), then ONE grouped exchange — rank r ncclSend()s its payload, the root ncclRecv()s it at its
+// camera-order offset — runs on the GPUs' communication streams, so the kernels of the NEXT frame-set (other payload
+// slot) overlap it. Without a predicate the counts are the configuration's and nothing is read back; with one the
+// per-GPU counts must reach the host before the exchange can be sized (one synchronisation per GPU inside submit).
+int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                           int16_t* d_stitched, size_t stitched_shorts, int* ticket)
 {
-    if (!n || !d_depth || !d_color || !d_stitched) return nfail(n, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (!n || !d_depth || !d_color || !d_stitched || !ticket) return nfail(n, PCS_ERR_INVALID_ARG, "NULL pointer");
     if (stitched_shorts < pcs_node_max_payload_shorts(n))
         return nfail(n, PCS_ERR_CAPACITY, "stitched payload holds %zu shorts, %zu needed", stitched_shorts, pcs_node_max_payload_shorts(n));
+    const int slot = n->next_ticket & 1;
+    pcs_node::Ticket& tk = n->inflight[slot];
+    if (tk.busy) return nfail(n, PCS_ERR_CAPACITY, "two frame-sets are in flight: pcs_node_wait() the older one first");
     const int S = n->per_dev;
-    // 1. every GPU packs its cameras; the root packs straight into the head of the stitched buffer
+    tk.cnt.assign(n->n_dev, std::vector<int32_t>(S + 1, 0));
+    // 1. every GPU packs its cameras (its payload slot was drained by the exchange two submits ago)
     for (int r = 0; r < n->n_dev; r++) {
         HIPCHK(n, hipSetDevice(n->dev[r]));
-        int16_t* dst = r == 0 ? d_stitched : static_cast<int16_t*>(n->d_payload[r]);
+        hipStream_t ks = static_cast<hipStream_t>(pcs_get_stream(n->ctx[r]));
+        HIPCHK(n, hipStreamWaitEvent(ks, n->drained[slot][r], 0));
+        int16_t* dst = r == 0 ? d_stitched : static_cast<int16_t*>(n->d_payload[slot][r]);
         PCSCHK(n, n->ctx[r], pcs_process_frames_device(n->ctx[r], d_depth + (size_t)r * S, d_color + (size_t)r * S, dst,
                                                        r == 0 ? stitched_shorts : n->payload_shorts[r],
-                                                       static_cast<int32_t*>(n->d_counts[r])));
+                                                       n->pred ? static_cast<int32_t*>(n->d_counts[r]) : nullptr));
     }
-    // 2. counts to the host (needed for the offsets; with no predicate they equal the configuration's)
-    std::vector<std::vector<int32_t>> cnt(n->n_dev, std::vector<int32_t>(S + 1));
+    // 2. counts: known from the configuration unless a predicate makes them data dependent
+    for (int r = 0; r < n->n_dev; r++) {
+        if (n->pred) {
+            HIPCHK(n, hipSetDevice(n->dev[r]));
+            PCSCHK(n, n->ctx[r], pcs_memcpy_d2h(n->ctx[r], tk.cnt[r].data(), n->d_counts[r], sizeof(int32_t) * (S + 1)));   // synchronises ctx r
+        } else {
+            int64_t tot = 0;
+            for (int k = 0; k < S; k++) {
+                tk.cnt[r][k] = (pcs_stream_points(n->ctx[r], k) + n->downsample - 1) / n->downsample;
+                tot += tk.cnt[r][k];
+            }
+            tk.cnt[r][S] = (int32_t)tot;
+        }
+    }
+    // 3. the exchange, on the communication streams, behind each GPU's kernel
     for (int r = 0; r < n->n_dev; r++) {
         HIPCHK(n, hipSetDevice(n->dev[r]));
-        PCSCHK(n, n->ctx[r], pcs_memcpy_d2h(n->ctx[r], cnt[r].data(), n->d_counts[r], sizeof(int32_t) * (S + 1)));   // synchronises ctx r
+        HIPCHK(n, hipEventRecord(n->packed[slot][r], static_cast<hipStream_t>(pcs_get_stream(n->ctx[r]))));
+        HIPCHK(n, hipStreamWaitEvent(n->comm_stream[r], n->packed[slot][r], 0));
     }
-    // 3. one grouped exchange: rank r sends its payload, the root receives it at its camera-order offset
-    size_t off = (size_t)cnt[0][S];          // points
+    size_t off = (size_t)tk.cnt[0][S];          // points
     if (n->n_dev > 1) {
         NCCLCHK(n, ncclGroupStart());
         for (int r = 1; r < n->n_dev; r++) {
-            const size_t bytes = (size_t)cnt[r][S] * PCS_POINT_BYTES;
+            const size_t bytes = (size_t)tk.cnt[r][S] * PCS_POINT_BYTES;
             if (bytes) {
-                NCCLCHK(n, ncclSend(n->d_payload[r], bytes, ncclInt8, 0, n->comm[r], static_cast<hipStream_t>(pcs_get_stream(n->ctx[r]))));
+                NCCLCHK(n, ncclSend(n->d_payload[slot][r], bytes, ncclInt8, 0, n->comm[r], n->comm_stream[r]));
                 NCCLCHK(n, ncclRecv(reinterpret_cast<int8_t*>(d_stitched) + off * PCS_POINT_BYTES, bytes, ncclInt8, r, n->comm[0],
-                                    static_cast<hipStream_t>(pcs_get_stream(n->ctx[0]))));
+                                    n->comm_stream[0]));
             }
-            off += (size_t)cnt[r][S];
+            off += (size_t)tk.cnt[r][S];
         }
         NCCLCHK(n, ncclGroupEnd());
-        for (int r = 0; r < n->n_dev; r++) {
-            HIPCHK(n, hipSetDevice(n->dev[r]));
-            PCSCHK(n, n->ctx[r], pcs_synchronize(n->ctx[r]));
-        }
+    }
+    for (int r = 0; r < n->n_dev; r++) {
+        HIPCHK(n, hipSetDevice(n->dev[r]));
+        HIPCHK(n, hipEventRecord(n->drained[slot][r], n->comm_stream[r]));
+    }
+    tk.total = off; tk.slot = slot; tk.busy = true;
+    *ticket = n->next_ticket++;
+    return PCS_OK;
+}
+
+int pcs_node_wait(pcs_node* n, int ticket, int* points_per_stream, int* total_points)
+{
+    if (!n) return PCS_ERR_INVALID_ARG;
+    pcs_node::Ticket& tk = n->inflight[ticket & 1];
+    if (ticket < 0 || ticket >= n->next_ticket || ticket < n->next_ticket - 2 || !tk.busy)
+        return nfail(n, PCS_ERR_INVALID_ARG, "ticket %d is not in flight", ticket);
+    const int S = n->per_dev;
+    tk.busy = false;                                    // whatever happens below, the slot is free again
+    for (int r = 0; r < n->n_dev; r++) {
+        HIPCHK(n, hipSetDevice(n->dev[r]));
+        HIPCHK(n, hipEventSynchronize(n->drained[tk.slot][r]));
     }
     if (points_per_stream)
-        for (int r = 0; r < n->n_dev; r++) for (int k = 0; k < S; k++) points_per_stream[r * S + k] = cnt[r][k];
-    if (total_points) *total_points = (int)off;
+        for (int r = 0; r < n->n_dev; r++) for (int k = 0; k < S; k++) points_per_stream[r * S + k] = tk.cnt[r][k];
+    if (total_points) *total_points = (int)tk.total;
     return PCS_OK;
+}
+
+int pcs_node_process_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                            int16_t* d_stitched, size_t stitched_shorts, int* points_per_stream, int* total_points)
+{
+    int ticket = -1;
+    const int rc = pcs_node_submit_device(n, d_depth, d_color, d_stitched, stitched_shorts, &ticket);
+    if (rc != PCS_OK) return rc;
+    return pcs_node_wait(n, ticket, points_per_stream, total_points);
 }
 
 int pcs_node_process(pcs_node* n, const uint16_t* const* depth, const uint8_t* const* color, int16_t* stitched,

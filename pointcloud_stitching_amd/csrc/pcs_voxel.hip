@@ -14,17 +14,19 @@
 //                      emits (index = ix + iy*dx + iz*dx*dy); PCL itself averages in float, so against
 //                      PCL 1.8 this is "parity unpinned" (+-1 LSB per field expected).
 //
-// Pipeline: pre-aggregation (one hand-written kernel: a workgroup accumulates 8192 consecutive points — a few
-// image rows of one camera, which fall into few voxels — in an LDS hash table and appends one partial
-// accumulator per voxel it saw) -> rocPRIM radix sort of (key, partial index) over the PARTIALS, an order of
-// magnitude fewer than points for realistic leaves -> rocPRIM reduce_by_key over a gather iterator ->
-// finalize (one kernel). Integer sums
-// make the result independent of reduction order and of the (atomic-append) order of the partials.
-// Sorting/segmented reduction are library primitives (rocPRIM, header-only in /opt/rocm/include); the
-// per-point work around them is hand-written. The number of runs is read back once (one stream
-// synchronisation inside the call) because the library primitives take their size from the host.
+// Pipeline — every kernel hand-written, every size read from device memory, nothing waits for the host:
+//   1. pre-aggregation  a workgroup accumulates 8192 consecutive points (a few image rows of one camera, which fall
+//                       into few voxels) in an LDS hash table and appends one PARTIAL (key + 7 sums) per voxel it saw;
+//                       m = number of partials (3.0 M for the 29.8 M-point config-5 cloud at 50 mm)
+//   2. radix sort       of (key, partial index) over the m partials, least significant digit first, 11 bits per pass
+//                       (3 passes at 50 mm: the key is packed to 3 * ceil(log2(65536/leaf)) bits); per pass:
+//                       per-chunk histograms -> per-digit column scan -> stable scatter
+//   3. segmented mean   heads of equal-key runs -> voxel ordinals (block counts + scan) -> every head sums its run's
+//                       partials (short runs by one lane, long runs by the whole wavefront) and writes the record
+// Integer sums make the result independent of the order of the partials and of any reduction order.
+// (Round 1 used rocPRIM's radix_sort_pairs + reduce_by_key for steps 2-3: 0.56 ms of library kernels per call at 50 mm,
+// plus a stream synchronisation in the middle of the call to learn m.)
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "pcs_device.h"
 
@@ -32,33 +34,11 @@ namespace pcs {
 
 namespace {
 
-struct VoxelAcc {
-    long long sx, sy, sz;
-    unsigned int r, g, b, n;
-};
-
-struct VoxelPlus {
-    __host__ __device__ VoxelAcc operator()(const VoxelAcc& a, const VoxelAcc& b) const
-    {
-        return VoxelAcc{a.sx + b.sx, a.sy + b.sy, a.sz + b.sz, a.r + b.r, a.g + b.g, a.b + b.b, a.n + b.n};
-    }
-};
-
 // What one workgroup of the pre-aggregation kernel knows about one voxel: the sums over its (<= 8192) points
 // that fall into it (|sum| <= 8192 * 32768 = 2^28 fits an int).
-struct VoxelPartial {
+struct alignas(32) VoxelPartial {      // 32 B: one sector per gathered partial in the segmented mean
     int          sx, sy, sz;
-    unsigned int r, g, b, n;
-};
-
-// partial index -> accumulator (the gather side of reduce_by_key)
-struct LoadPartial {
-    const VoxelPartial* part;
-    __host__ __device__ VoxelAcc operator()(unsigned int i) const
-    {
-        const VoxelPartial q = part[i];
-        return VoxelAcc{q.sx, q.sy, q.sz, q.r, q.g, q.b, q.n};
-    }
+    unsigned int r, g, b, n, pad;
 };
 
 // Bits one axis needs: voxel indices run over 0 .. floor(32767/leaf) + ceil(32768/leaf) <= 65536/leaf + 1.
@@ -71,24 +51,73 @@ inline unsigned int axis_bits(int leaf)
     return b;
 }
 
-__device__ __forceinline__ unsigned int voxel_index_packed(int v, int leaf, unsigned int bias)
+// floor(v / leaf) + bias, bias = ceil(32768 / leaf): the biased numerator u = v + bias*leaf is in [0, 2^17), and
+// floor(u / leaf) == (u * magic) >> 32 with magic = ceil(2^32 / leaf) — checked by the host over every u before the
+// launch (magic = 0: use '/'). Three variable-divisor integer divisions per point otherwise cost ~75 instructions.
+struct VoxelDiv {
+    unsigned int leaf, bias_leaf, magic;
+    __device__ __forceinline__ unsigned int operator()(int v) const
+    {
+        const unsigned int u = (unsigned int)(v + (int)bias_leaf);
+        return magic ? __umulhi(u, magic) : u / leaf;
+    }
+};
+
+__device__ __forceinline__ unsigned long long voxel_key(const VoxelDiv& dv, int x, int y, int z, unsigned int bits)
 {
-    const int q = v >= 0 ? v / leaf : -((-v + leaf - 1) / leaf);     // floor division
-    return (unsigned int)(q + (int)bias);                            // bias = ceil(32768/leaf) -> non-negative
+    const unsigned long long kx = dv(x), ky = dv(y), kz = dv(z);
+    return (kz << (2 * bits)) | (ky << bits) | kx;      // z major, x fastest: (z,y,x) voxel order
 }
 
-// Pre-aggregation. A workgroup (1024 lanes) takes 8192 consecutive points of the payload — a few image rows of
-// one camera, so they fall into few voxels — and accumulates them in an LDS hash table (2048 slots, open
-// addressing, 64-bit compare-and-swap on the key, 32-bit LDS adds on the seven sums). Points that find no slot
-// within kProbe probes (dense tiny leaves) are passed through as single-point partials. One returning global
-// atomic per workgroup reserves its slice of the partial arrays (3.6 k atomics for 30 M points); the order of
-// the partials does not matter (they are sorted next, and the sums are integers).
+// ---- wavefront helpers (64 lanes, all active) ---------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_from(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+
+__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x)
+{
+    unsigned int v = x;
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Segmented inclusive scan step over the wavefront for the seven sums of a partial: lanes whose span already contains
+// a run head keep their value; the others add the value `ctrl` lanes below (or the row's carry) and inherit its flag.
+// A lane without a valid source (start of a row for row_shr) receives zeros / "no head", i.e. it simply keeps going.
+struct SegAcc { int x, y, z; unsigned int r, g, b, n; int head; };
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(SegAcc& a)
+{
+    const int ux = dpp_from<CTRL, ROW_MASK>(a.x), uy = dpp_from<CTRL, ROW_MASK>(a.y), uz = dpp_from<CTRL, ROW_MASK>(a.z);
+    const int ur = dpp_from<CTRL, ROW_MASK>((int)a.r), ug = dpp_from<CTRL, ROW_MASK>((int)a.g), ub = dpp_from<CTRL, ROW_MASK>((int)a.b);
+    const int un = dpp_from<CTRL, ROW_MASK>((int)a.n), uh = dpp_from<CTRL, ROW_MASK>(a.head);
+    if (!a.head) {
+        a.x += ux; a.y += uy; a.z += uz;
+        a.r += (unsigned int)ur; a.g += (unsigned int)ug; a.b += (unsigned int)ub; a.n += (unsigned int)un;
+        a.head = uh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. Pre-aggregation. A workgroup (1024 lanes) takes 8192 consecutive points of the payload and accumulates them in
+// an LDS hash table (2048 slots, open addressing, 64-bit compare-and-swap on the key, 32-bit LDS adds on the seven
+// sums). Neighbouring lanes hold neighbouring pixels, which mostly share a voxel: 64 lanes adding to the same LDS
+// words serialise, so runs of equal keys across the wavefront are summed first (segmented scan over the lanes, by DPP:
+// the ds_bpermute shuffles of the first version kept the LDS pipe busier than the table itself) and only the LAST lane
+// of a run touches the table. Points that find no slot within kProbe probes (dense tiny leaves) are passed through
+// as single-point partials. One returning global atomic per workgroup reserves its slice of the partial arrays; the
+// order of the partials does not matter (they are sorted next, and the sums are integers).
+// ------------------------------------------------------------------------------------------------
 constexpr int kAggThreads = 1024, kAggPerLane = 8, kSlots = 2048, kProbe = 12;
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 __global__ __launch_bounds__(kAggThreads)
-void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n, int leaf, unsigned int bits,
-                               unsigned int bias, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
+void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n, VoxelDiv dv, unsigned int bits,
+                               unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
                                VoxelPartial* __restrict__ part, unsigned int* __restrict__ n_runs)
 {
     __shared__ unsigned long long skey[kSlots];
@@ -105,42 +134,47 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     __syncthreads();
 
     const unsigned int tile0 = blockIdx.x * (unsigned)(kAggThreads * kAggPerLane);
+    const int lane = threadIdx.x & 63;
     unsigned int failed = 0;                                  // bit k: point k of this lane found no slot
 #pragma unroll
     for (int k = 0; k < kAggPerLane; k++) {
         const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;      // lane-contiguous records
-        if (i >= n) continue;
-        const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
-        const int x = p[0], y = p[1], z = p[2];
-        const unsigned int col = (unsigned short)p[3], blue = (unsigned short)p[4] & 0xFFu;
-        const unsigned long long kx = voxel_index_packed(x, leaf, bias), ky = voxel_index_packed(y, leaf, bias),
-                                 kz = voxel_index_packed(z, leaf, bias);
-        const unsigned long long key = (kz << (2 * bits)) | (ky << bits) | kx;   // z major, x fastest: (z,y,x) voxel order
-        // Neighbouring lanes hold neighbouring pixels, which mostly share a voxel: 64 lanes adding to the same LDS
-        // words serialise (432 us for 30 M points at a 200 mm leaf). So runs of equal keys across the wavefront are
-        // summed first (segmented inclusive scan over the lanes, 6 shuffle rounds) and only the LAST lane of each
-        // run touches the table — 2-4 lanes per wavefront for large leaves, every lane for tiny ones (as before).
-        int ax = x, ay = y, az = z;
-        unsigned int ar = col & 0xFFu, ag = col >> 8, ab = blue, an = 1u;
-        const int lane = threadIdx.x & 63;
-        const bool full = __ballot(1) == ~0ull;                  // ragged last wavefront: no cross-lane merging
-        bool actor = true;
-        const unsigned long long prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
-        bool head = lane == 0 || prev != key;                    // becomes "a head lies within the span summed so far"
-        // merging pays when the wavefront holds few runs; with many (small leaves) the 48 shuffles cost more than
-        // the conflicts they avoid (measured: +7-9 % at 20-50 mm if always on)
-        const bool merge = full && __popcll(__ballot(head)) <= 16;
+        const bool live = i < n;
+        int x = 0, y = 0, z = 0;
+        unsigned int col = 0, blue = 0;
+        if (live) {
+            const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
+            x = p[0]; y = p[1]; z = p[2];
+            col = (unsigned short)p[3]; blue = (unsigned short)p[4] & 0xFFu;
+        }
+        // dead lanes (ragged last wavefront) get a key no live point has, so they form their own runs and never act
+        const unsigned long long key = live ? voxel_key(dv, x, y, z, bits) : (kEmptyKey - 1ull - (unsigned long long)lane);
+        SegAcc a{x, y, z, col & 0xFFu, col >> 8, blue, 1u, 0};
+        const unsigned long long prev = ((unsigned long long)(unsigned int)__builtin_amdgcn_update_dpp(0, (int)(key >> 32), 0x138, 0xf, 0xf, false) << 32) |
+                                        (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const unsigned long long next = ((unsigned long long)(unsigned int)__builtin_amdgcn_update_dpp(0, (int)(key >> 32), 0x130, 0xf, 0xf, false) << 32) |
+                                        (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x130, 0xf, 0xf, false);   // wave_shl:1
+        a.head = (lane == 0 || prev != key) ? 1 : 0;
+        bool actor = live;
+        // merging pays when the wavefront holds few runs; with many (small leaves) the scan costs more than the
+        // conflicts it avoids
+        const bool merge = __popcll(__ballot(a.head != 0)) <= 24;
         if (merge) {
-            actor = lane == 63 || next != key;                   // last lane of its run
-#pragma unroll
-            for (int ofs = 1; ofs < 64; ofs <<= 1) {
-                const int ux = __shfl_up(ax, ofs, 64), uy = __shfl_up(ay, ofs, 64), uz = __shfl_up(az, ofs, 64);
-                const unsigned int ur = __shfl_up(ar, ofs, 64), ug = __shfl_up(ag, ofs, 64), ub = __shfl_up(ab, ofs, 64),
-                                   un = __shfl_up(an, ofs, 64);
-                const bool uh = __shfl_up((int)head, ofs, 64) != 0;
-                if (lane >= ofs && !head) {
-                    ax += ux; ay += uy; az += uz; ar += ur; ag += ug; ab += ub; an += un;
-                    head = uh;
+            actor = live && (lane == 63 || next != key);         // last lane of its run
+            // a lane is finished once its span holds its run's head; runs are short, so most wavefronts are done after
+            // two or three steps (wave-uniform early exit)
+            seg_step<0x111, 0xf>(a);                             // row_shr:1
+            if (__ballot(a.head == 0)) {
+                seg_step<0x112, 0xf>(a);                         // row_shr:2
+                if (__ballot(a.head == 0)) {
+                    seg_step<0x114, 0xf>(a);                     // row_shr:4
+                    if (__ballot(a.head == 0)) {
+                        seg_step<0x118, 0xf>(a);                 // row_shr:8
+                        if (__ballot(a.head == 0)) {
+                            seg_step<0x142, 0xa>(a);             // row_bcast:15 -> rows 1, 3
+                            seg_step<0x143, 0xc>(a);             // row_bcast:31 -> rows 2, 3
+                        }
+                    }
                 }
             }
         }
@@ -153,9 +187,9 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
                 h = (h + 1u) & (unsigned)(kSlots - 1);
             }
             if (placed) {
-                atomicAdd(&ssx[h], ax); atomicAdd(&ssy[h], ay); atomicAdd(&ssz[h], az);
-                atomicAdd(&sr[h], ar); atomicAdd(&sg[h], ag); atomicAdd(&sb[h], ab);
-                atomicAdd(&sn[h], an);
+                atomicAdd(&ssx[h], a.x); atomicAdd(&ssy[h], a.y); atomicAdd(&ssz[h], a.z);
+                atomicAdd(&sr[h], a.r); atomicAdd(&sg[h], a.g); atomicAdd(&sb[h], a.b);
+                atomicAdd(&sn[h], a.n);
             }
         }
         if (merge) {
@@ -163,10 +197,10 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
             // own point through). Runs are contiguous, so "the next actor at or after me" decides.
             const unsigned long long actors = __ballot(actor), ok = __ballot(actor && placed);
             const unsigned long long at_or_after = actors & (~0ull << lane);
-            const int mine_actor = __ffsll((long long)at_or_after) - 1;            // always exists: lane 63 is an actor
-            placed = (ok >> mine_actor) & 1ull;
+            const int mine_actor = __ffsll((long long)at_or_after) - 1;            // -1 only for dead lanes
+            placed = mine_actor >= 0 && ((ok >> mine_actor) & 1ull);
         }
-        if (!placed) failed |= 1u << k;
+        if (live && !placed) failed |= 1u << k;
     }
     __syncthreads();
 
@@ -174,13 +208,8 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     unsigned int c = __popc(failed);
 #pragma unroll
     for (int q = 0; q < kSlots / kAggThreads; q++) c += skey[threadIdx.x * (kSlots / kAggThreads) + q] != kEmptyKey;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int inc = c;
-#pragma unroll
-    for (int ofs = 1; ofs < 64; ofs <<= 1) {
-        const unsigned int t = __shfl_up(inc, ofs, 64);
-        if (lane >= ofs) inc += t;
-    }
+    const int wave = threadIdx.x >> 6;
+    const unsigned int inc = wave_incl_scan(c);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -195,7 +224,7 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
         const int j = threadIdx.x * (kSlots / kAggThreads) + q;
         if (skey[j] != kEmptyKey) {
             keys[pos] = skey[j]; idx[pos] = pos;
-            part[pos] = VoxelPartial{ssx[j], ssy[j], ssz[j], sr[j], sg[j], sb[j], sn[j]};
+            part[pos] = VoxelPartial{ssx[j], ssy[j], ssz[j], sr[j], sg[j], sb[j], sn[j], 0u};
             pos++;
         }
     }
@@ -206,48 +235,406 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
         const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
         const int x = p[0], y = p[1], z = p[2];
         const unsigned int col = (unsigned short)p[3], blue = (unsigned short)p[4] & 0xFFu;
-        const unsigned long long kx = voxel_index_packed(x, leaf, bias), ky = voxel_index_packed(y, leaf, bias),
-                                 kz = voxel_index_packed(z, leaf, bias);
-        keys[pos] = (kz << (2 * bits)) | (ky << bits) | kx; idx[pos] = pos;
-        part[pos] = VoxelPartial{x, y, z, col & 0xFFu, col >> 8, blue, 1u};
+        keys[pos] = voxel_key(dv, x, y, z, bits); idx[pos] = pos;
+        part[pos] = VoxelPartial{x, y, z, col & 0xFFu, col >> 8, blue, 1u, 0u};
         pos++;
     }
 }
 
-__global__ __launch_bounds__(256)
-void pcs_voxel_finalize_kernel(const VoxelAcc* __restrict__ acc, const unsigned int* __restrict__ n_voxels,
-                               int16_t* __restrict__ out, int32_t* __restrict__ out_points)
+// ------------------------------------------------------------------------------------------------
+// 2. LSD radix sort of (key, index) pairs, 11 bits per pass, element count read from device memory.
+//    Chunks of 4096 elements; persistent grids (the kernels loop over chunks), so a launch costs the same whether the
+//    pre-aggregation left 90 k or 17 M partials and needs no size from the host.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRadixBits = 11, kRadix = 1 << kRadixBits;
+constexpr unsigned int kSortChunk = 4096, kSortThreads = 256, kSortGrid = 4096, kSortBatch = 8;
+
+__device__ __forceinline__ unsigned int digit_of(unsigned long long key, unsigned int shift) { return (unsigned int)(key >> shift) & (kRadix - 1); }
+
+// table[chunk][digit] = occurrences of the digit in the chunk
+__global__ __launch_bounds__(kSortThreads)
+void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ m_ptr,
+                           unsigned int shift, unsigned int* __restrict__ table)
 {
-    const unsigned int nv = *n_voxels;
-    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0 && out_points) *out_points = (int32_t)nv;
-    if (i >= nv) return;
-    const VoxelAcc a = acc[i];
-    const long long n = (long long)a.n;
-    int16_t* o = out + (size_t)i * PCS_POINT_SHORTS;
-    o[0] = (int16_t)(a.sx / n);
-    o[1] = (int16_t)(a.sy / n);
-    o[2] = (int16_t)(a.sz / n);
-    o[3] = (int16_t)(unsigned short)((a.r / a.n) | ((a.g / a.n) << 8));
-    o[4] = (int16_t)(a.b / a.n);
+    __shared__ unsigned int hist[kRadix];
+    const unsigned int m = *m_ptr;
+    const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
+    for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        for (unsigned int j = threadIdx.x; j < kRadix; j += kSortThreads) hist[j] = 0u;
+        __syncthreads();
+        const unsigned int c0 = chunk * kSortChunk;
+        for (unsigned int it0 = 0; it0 < kSortChunk / kSortThreads; it0 += kSortBatch) {
+            unsigned long long k[kSortBatch];       // the batch's loads are in flight together
+#pragma unroll
+            for (unsigned int q = 0; q < kSortBatch; q++) {
+                const unsigned int e = c0 + (it0 + q) * kSortThreads + threadIdx.x;
+                k[q] = e < m ? keys[e] : 0ull;
+            }
+#pragma unroll
+            for (unsigned int q = 0; q < kSortBatch; q++) {
+                const unsigned int e = c0 + (it0 + q) * kSortThreads + threadIdx.x;
+                if (e < m) atomicAdd(&hist[digit_of(k[q], shift)], 1u);
+            }
+        }
+        __syncthreads();
+        for (unsigned int j = threadIdx.x; j < kRadix; j += kSortThreads) table[(size_t)chunk * kRadix + j] = hist[j];
+        __syncthreads();
+    }
+}
+
+// One wavefront per digit: exclusive scan of the digit's column over the chunks (in place) + the digit's total. The
+// column is strided (one row per chunk), so up to 16 x 64 entries are requested before any is used.
+__global__ __launch_bounds__(256)
+void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned int* __restrict__ m_ptr,
+                              unsigned int* __restrict__ digit_total)
+{
+    constexpr unsigned int kCols = 16;
+    const unsigned int m = *m_ptr;
+    const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
+    const unsigned int digit = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    unsigned int carry = 0;
+    for (unsigned int c0 = 0; c0 < chunks; c0 += 64 * kCols) {
+        unsigned int v[kCols];
+#pragma unroll
+        for (unsigned int q = 0; q < kCols; q++) {
+            const unsigned int c = c0 + q * 64 + lane;
+            v[q] = c < chunks ? table[(size_t)c * kRadix + digit] : 0u;
+        }
+#pragma unroll
+        for (unsigned int q = 0; q < kCols; q++) {
+            const unsigned int c = c0 + q * 64 + lane;
+            if (c0 + q * 64 < chunks) {                           // wave-uniform
+                const unsigned int inc = wave_incl_scan(v[q]);
+                if (c < chunks) table[(size_t)c * kRadix + digit] = carry + inc - v[q];
+                carry += (unsigned int)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+        }
+    }
+    if (lane == 0) digit_total[digit] = carry;
+}
+
+// Stable scatter. Wavefront w of the workgroup owns the w-th quarter of the chunk and walks it 64 elements at a time,
+// so "earlier in memory" = (lower wavefront, lower round, lower lane):
+//   destination = digit base (all smaller digits) + this digit in earlier chunks (column scan)
+//               + this digit in earlier wavefronts of the chunk + in earlier rounds of this wavefront + in lower lanes.
+// The last three come from per-(wavefront, digit) LDS counters: counted first (LDS adds), turned into starting offsets,
+// then advanced round by round by the lowest lane of each group of equal digits (found with 11 ballots).
+__global__ __launch_bounds__(kSortThreads)
+void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ idx_in,
+                              unsigned long long* __restrict__ keys_out, unsigned int* __restrict__ idx_out,
+                              const unsigned int* __restrict__ m_ptr, unsigned int shift,
+                              const unsigned int* __restrict__ table, const unsigned int* __restrict__ digit_total)
+{
+    __shared__ unsigned int cnt[4][kRadix];      // 32 KiB
+    __shared__ unsigned int dbase[kRadix];       //  8 KiB
+    __shared__ unsigned int wsum[4];
+    const unsigned int m = *m_ptr;
+    const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
+    if (blockIdx.x >= chunks) return;
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    constexpr unsigned int kPer = kRadix / kSortThreads;      // 8 consecutive digits per thread
+
+    {   // digit bases: exclusive scan of the 2048 digit totals
+        unsigned int v[kPer], s = 0;
+#pragma unroll
+        for (unsigned int j = 0; j < kPer; j++) { v[j] = digit_total[threadIdx.x * kPer + j]; s += v[j]; }
+        const unsigned int inc = wave_incl_scan(s);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned int run = inc - s;
+        for (unsigned int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+        for (unsigned int j = 0; j < kPer; j++) { dbase[threadIdx.x * kPer + j] = run; run += v[j]; }
+        __syncthreads();
+    }
+
+    for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        for (unsigned int j = threadIdx.x; j < 4 * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
+        __syncthreads();
+        const unsigned int w0 = chunk * kSortChunk + wave * (kSortChunk / 4);
+        // count: this wavefront's occurrences of every digit
+        constexpr unsigned int kRounds = kSortChunk / 4 / 64;
+        for (unsigned int r0 = 0; r0 < kRounds; r0 += kSortBatch) {
+            unsigned long long k[kSortBatch];
+#pragma unroll
+            for (unsigned int q = 0; q < kSortBatch; q++) {
+                const unsigned int e = w0 + (r0 + q) * 64 + lane;
+                k[q] = e < m ? keys_in[e] : 0ull;
+            }
+#pragma unroll
+            for (unsigned int q = 0; q < kSortBatch; q++) {
+                const unsigned int e = w0 + (r0 + q) * 64 + lane;
+                if (e < m) atomicAdd(&cnt[wave][digit_of(k[q], shift)], 1u);
+            }
+        }
+        __syncthreads();
+        // starting offsets per (wavefront, digit)
+        for (unsigned int j = threadIdx.x; j < kRadix; j += kSortThreads) {
+            unsigned int start = dbase[j] + table[(size_t)chunk * kRadix + j];
+#pragma unroll
+            for (unsigned int w = 0; w < 4; w++) { const unsigned int c = cnt[w][j]; cnt[w][j] = start; start += c; }
+        }
+        __syncthreads();
+        // place: one round of 64 elements at a time, in order (the loads of a batch of rounds go out together)
+        for (unsigned int r0 = 0; r0 < kRounds; r0 += kSortBatch) {
+            unsigned long long k[kSortBatch];
+            unsigned int id[kSortBatch];
+#pragma unroll
+            for (unsigned int q = 0; q < kSortBatch; q++) {
+                const unsigned int e = w0 + (r0 + q) * 64 + lane;
+                k[q] = 0ull; id[q] = 0u;
+                if (e < m) { k[q] = keys_in[e]; id[q] = idx_in[e]; }
+            }
+#pragma unroll
+            for (unsigned int q = 0; q < kSortBatch; q++) {
+                const unsigned int e = w0 + (r0 + q) * 64 + lane;
+                const bool live = e < m;
+                const unsigned int d = digit_of(k[q], shift);
+                unsigned long long peers = __ballot(live);
+#pragma unroll
+                for (int b = 0; b < kRadixBits; b++) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    peers &= bit ? bal : ~bal;
+                }
+                if (live) {
+                    const unsigned int below = __popcll(peers & ((1ull << lane) - 1ull));
+                    const unsigned int start = cnt[wave][d];
+                    if (below == 0) cnt[wave][d] = start + __popcll(peers);       // the group's lowest lane advances the counter
+                    const unsigned int dst = start + below;
+                    keys_out[dst] = k[q];
+                    idx_out[dst] = id[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. Segmented mean over the sorted partials. Every lane gathers ONE partial (all loads in flight at once); equal-key
+//    runs are summed by a segmented scan across the wavefront (DPP) and across the block's four wavefronts (LDS
+//    carries). A run that lies inside one block of 256 sorted elements — almost all of them — is finished there.
+//    Pieces of runs that cross block boundaries are left per block as {lead: the part of a run begun earlier, trail:
+//    the open run at the block's end}; a second, tiny kernel adds trail[b] + lead[b+1] + ... and writes those voxels.
+//    No lane ever walks a run serially (the first version did: 231 us at 50 mm, most lanes idle, the rest latency-bound).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned int kSegThreads = 256, kSegGrid = 4096;
+
+// heads[b] = runs that START in block b (block = 256 consecutive sorted elements)
+__global__ __launch_bounds__(kSegThreads)
+void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ m_ptr,
+                            unsigned int* __restrict__ heads)
+{
+    __shared__ unsigned int wsum[4];
+    const unsigned int m = *m_ptr;
+    const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
+    for (unsigned int b = blockIdx.x; b < blocks; b += gridDim.x) {
+        const unsigned int g = b * kSegThreads + threadIdx.x;
+        const bool head = g < m && (g == 0 || keys[g] != keys[g - 1]);
+        const unsigned int c = __popcll(__ballot(head));
+        if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) heads[b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+// exclusive scan of heads[] (in place) by one workgroup, four entries per lane; the total is the number of voxels
+__global__ __launch_bounds__(1024)
+void pcs_voxel_blockscan_kernel(unsigned int* __restrict__ heads, const unsigned int* __restrict__ m_ptr,
+                                unsigned int* __restrict__ n_voxels, int32_t* __restrict__ out_points)
+{
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int carry_s;
+    const unsigned int m = *m_ptr;
+    const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (unsigned int b0 = 0; b0 < blocks; b0 += 4096) {
+        const unsigned int b = b0 + threadIdx.x * 4u;
+        unsigned int v[4];
+#pragma unroll
+        for (unsigned int q = 0; q < 4; q++) v[q] = b + q < blocks ? heads[b + q] : 0u;
+        const unsigned int s = v[0] + v[1] + v[2] + v[3];
+        const unsigned int inc = wave_incl_scan(s);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned int run = carry_s + inc - s;
+        for (unsigned int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+        for (unsigned int q = 0; q < 4; q++) { if (b + q < blocks) heads[b + q] = run; run += v[q]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *n_voxels = carry_s;
+        if (out_points) *out_points = (int32_t)carry_s;
+    }
+}
+
+// Sums of a piece of a run inside one block: 256 partials of <= 8192 points each -> the colour sums and the count fit
+// 32 bits, the coordinate sums need 64.
+struct SegSum {
+    long long x, y, z;
+    unsigned int r, g, b, n;
+    int head;                       // a run head lies inside the span summed so far
+};
+__device__ __forceinline__ void seg_add(SegSum& a, const SegSum& u)
+{
+    a.x += u.x; a.y += u.y; a.z += u.z; a.r += u.r; a.g += u.g; a.b += u.b; a.n += u.n;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_from64(long long v)
+{
+    const unsigned int lo = (unsigned int)dpp_from<CTRL, ROW_MASK>((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)dpp_from<CTRL, ROW_MASK>((int)(unsigned int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step64(SegSum& a)
+{
+    SegSum u;
+    u.x = dpp_from64<CTRL, ROW_MASK>(a.x); u.y = dpp_from64<CTRL, ROW_MASK>(a.y); u.z = dpp_from64<CTRL, ROW_MASK>(a.z);
+    u.r = (unsigned int)dpp_from<CTRL, ROW_MASK>((int)a.r); u.g = (unsigned int)dpp_from<CTRL, ROW_MASK>((int)a.g);
+    u.b = (unsigned int)dpp_from<CTRL, ROW_MASK>((int)a.b); u.n = (unsigned int)dpp_from<CTRL, ROW_MASK>((int)a.n);
+    u.head = dpp_from<CTRL, ROW_MASK>(a.head);
+    if (!a.head) { seg_add(a, u); a.head = u.head; }
+}
+
+// What a block leaves behind for runs that cross its borders (64-bit throughout: a run may span thousands of blocks).
+struct BlockPiece {
+    long long x, y, z;
+    unsigned long long r, g, b;
+    unsigned int n;
+    unsigned int flag;              // lead: 1 = the run goes on into the next block; trail: 1 = there is an open run
+    unsigned int ordinal;           // trail: the voxel the open run belongs to
+    unsigned int pad;
+};
+
+__device__ __forceinline__ void write_voxel(int16_t* __restrict__ out, unsigned int ordinal, long long sx, long long sy,
+                                            long long sz, unsigned long long r, unsigned long long g, unsigned long long b,
+                                            unsigned int n)
+{
+    int16_t* o = out + (size_t)ordinal * PCS_POINT_SHORTS;
+    o[0] = (int16_t)(sx / (long long)n);
+    o[1] = (int16_t)(sy / (long long)n);
+    o[2] = (int16_t)(sz / (long long)n);
+    o[3] = (int16_t)(unsigned short)((r / n) | ((g / n) << 8));
+    o[4] = (int16_t)(b / n);
+}
+
+__global__ __launch_bounds__(kSegThreads)
+void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ idx,
+                             const VoxelPartial* __restrict__ part, const unsigned int* __restrict__ m_ptr,
+                             const unsigned int* __restrict__ block_base, int16_t* __restrict__ out,
+                             BlockPiece* __restrict__ lead, BlockPiece* __restrict__ trail)
+{
+    __shared__ SegSum wv[4];
+    __shared__ unsigned int wheads[4];
+    const unsigned int m = *m_ptr;
+    const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (unsigned int b = blockIdx.x; b < blocks; b += gridDim.x) {
+        const unsigned int g = b * kSegThreads + threadIdx.x;
+        const bool live = g < m;
+        unsigned long long key = 0, kprev = 0, knext = 0;
+        VoxelPartial q{0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            key = keys[g];
+            kprev = g ? keys[g - 1] : ~key;
+            knext = g + 1 < m ? keys[g + 1] : ~key;
+            q = part[idx[g]];
+        }
+        const bool head = !live || kprev != key;          // dead lanes (past m) are heads of empty runs: they absorb nothing
+        const bool tail = live && knext != key;
+        SegSum a{q.sx, q.sy, q.sz, q.r, q.g, q.b, q.n, head ? 1 : 0};
+        seg_step64<0x111, 0xf>(a);                        // row_shr:1
+        seg_step64<0x112, 0xf>(a);                        // row_shr:2
+        seg_step64<0x114, 0xf>(a);                        // row_shr:4
+        seg_step64<0x118, 0xf>(a);                        // row_shr:8
+        seg_step64<0x142, 0xa>(a);                        // row_bcast:15 -> rows 1, 3
+        seg_step64<0x143, 0xc>(a);                        // row_bcast:31 -> rows 2, 3
+        const unsigned long long hb = __ballot(head && live);
+        if (lane == 63) wv[wave] = a;
+        if (lane == 0) wheads[wave] = __popcll(hb);
+        __syncthreads();
+        // carry from the earlier wavefronts of the block: back to (and including) the nearest one that holds a head
+        SegSum c{0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned int heads_before = __popcll(hb & ((2ull << lane) - 1ull));       // heads at positions <= mine, this wavefront
+        for (int u = (int)wave - 1; u >= 0; u--) {
+            heads_before += wheads[u];
+            if (!c.head) { seg_add(c, wv[u]); c.head = wv[u].head; }
+        }
+        if (!a.head) { seg_add(a, c); a.head = c.head; }
+        // a.head now says: my run's head lies inside this block
+        const unsigned int ordinal = block_base[b] + heads_before - 1u;
+        const unsigned int last = (m - b * kSegThreads < kSegThreads ? m - b * kSegThreads : kSegThreads) - 1u;   // last live lane
+        if (tail && a.head) write_voxel(out, ordinal, a.x, a.y, a.z, a.r, a.g, a.b, a.n);
+        if (live && !a.head && (tail || threadIdx.x == last))       // the run begun in an earlier block: its piece in here
+            lead[b] = BlockPiece{a.x, a.y, a.z, a.r, a.g, a.b, a.n, tail ? 0u : 1u, 0u, 0u};
+        if (threadIdx.x == 0 && head) lead[b] = BlockPiece{0, 0, 0, 0, 0, 0, 0, 0u, 0u, 0u};       // nothing reaches into this block
+        if (threadIdx.x == last)
+            trail[b] = (!tail && a.head) ? BlockPiece{a.x, a.y, a.z, a.r, a.g, a.b, a.n, 1u, ordinal, 0u}
+                                         : BlockPiece{0, 0, 0, 0, 0, 0, 0, 0u, 0u, 0u};
+        __syncthreads();
+    }
+}
+
+// one lane per block with an open trailing run: add the pieces the following blocks hold of it
+__global__ __launch_bounds__(256)
+void pcs_voxel_fixup_kernel(const unsigned int* __restrict__ m_ptr, const BlockPiece* __restrict__ lead,
+                            const BlockPiece* __restrict__ trail, int16_t* __restrict__ out)
+{
+    const unsigned int m = *m_ptr;
+    const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
+    for (unsigned int b = blockIdx.x * blockDim.x + threadIdx.x; b < blocks; b += gridDim.x * blockDim.x) {
+        BlockPiece t = trail[b];
+        if (!t.flag) continue;
+        for (unsigned int bb = b + 1; bb < blocks; bb++) {
+            const BlockPiece l = lead[bb];
+            t.x += l.x; t.y += l.y; t.z += l.z; t.r += l.r; t.g += l.g; t.b += l.b; t.n += l.n;
+            if (!l.flag) break;
+        }
+        write_voxel(out, t.ordinal, t.x, t.y, t.z, t.r, t.g, t.b, t.n);
+    }
+}
+
+struct Workspace {
+    unsigned long long *keys_a, *keys_b;
+    unsigned int *idx_a, *idx_b;
+    VoxelPartial* part;
+    unsigned int *table, *digit_total, *heads, *ctl;      // ctl[0] = m (partials), ctl[1] = voxels
+    BlockPiece *lead, *trail;
+    size_t bytes;
+};
+
+inline Workspace carve(uint8_t* base, size_t n)
+{
+    Workspace w{};
+    uint8_t* p = base;
+    auto take = [&](size_t bytes) { uint8_t* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    w.keys_a = (unsigned long long*)take(n * 8);
+    w.keys_b = (unsigned long long*)take(n * 8);
+    w.idx_a = (unsigned int*)take(n * 4);
+    w.idx_b = (unsigned int*)take(n * 4);
+    w.part = (VoxelPartial*)take(n * sizeof(VoxelPartial));
+    w.table = (unsigned int*)take(((n + kSortChunk - 1) / kSortChunk) * (size_t)kRadix * 4);
+    w.digit_total = (unsigned int*)take((size_t)kRadix * 4);
+    w.heads = (unsigned int*)take(((n + kSegThreads - 1) / kSegThreads) * 4);
+    w.lead = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
+    w.trail = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
+    w.ctl = (unsigned int*)take(256);
+    w.bytes = (size_t)(p - base);
+    return w;
 }
 
 }  // namespace
 
-size_t voxel_workspace_bytes(uint32_t n_points, size_t* sort_tmp, size_t* reduce_tmp)
-{
-    size_t st = 0, rt = 0;
-    unsigned long long* k = nullptr; unsigned int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, st, k, k, v, v, (size_t)n_points, 0u, 51u);
-    auto values = rocprim::make_transform_iterator(v, LoadPartial{nullptr});
-    VoxelAcc* agg = nullptr; unsigned int* cnt = nullptr;
-    (void)rocprim::reduce_by_key(nullptr, rt, k, values, (size_t)n_points, k, agg, cnt, VoxelPlus{});
-    if (sort_tmp) *sort_tmp = st;
-    if (reduce_tmp) *reduce_tmp = rt;
-    const size_t n = n_points;
-    // keys in/out, idx in/out, partials, aggregates, counters, temp (worst case: every point its own run / voxel)
-    return 2 * n * 8 + 2 * n * 4 + n * sizeof(VoxelPartial) + n * sizeof(VoxelAcc) + 512 + ((st > rt ? st : rt) + 255) + 8 * 256;
-}
+// worst case: every point its own partial
+size_t voxel_workspace_bytes(uint32_t n_points) { return carve(nullptr, n_points).bytes + 256; }
 
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
                              int16_t* d_out, int32_t* d_out_points, hipStream_t st)
@@ -256,47 +643,56 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
         if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
         return hipSuccess;
     }
-    size_t sort_tmp = 0, reduce_tmp = 0;
-    const size_t need = voxel_workspace_bytes(n_points, &sort_tmp, &reduce_tmp);
-    if (ws_bytes < need) return hipErrorInvalidValue;
-    const size_t n = n_points;
-    uint8_t* w = static_cast<uint8_t*>(d_ws);
-    auto take = [&](size_t bytes) { uint8_t* p = w; w += (bytes + 255) & ~(size_t)255; return p; };
-    unsigned long long* keys_a = (unsigned long long*)take(n * 8);
-    unsigned long long* keys_b = (unsigned long long*)take(n * 8);
-    unsigned int* idx_a = (unsigned int*)take(n * 4);
-    unsigned int* idx_b = (unsigned int*)take(n * 4);
-    VoxelPartial* part = (VoxelPartial*)take(n * sizeof(VoxelPartial));
-    VoxelAcc* agg = (VoxelAcc*)take(n * sizeof(VoxelAcc));
-    unsigned int* nvox = (unsigned int*)take(256);
-    unsigned int* nruns = (unsigned int*)take(256);
-    void* tmp = take(sort_tmp > reduce_tmp ? sort_tmp : reduce_tmp);
+    if (ws_bytes < voxel_workspace_bytes(n_points)) return hipErrorInvalidValue;
+    uint8_t* base = static_cast<uint8_t*>(d_ws);
+    base += (256 - ((uintptr_t)base & 255)) & 255;
+    const Workspace w = carve(base, n_points);
 
     const unsigned int bits = axis_bits(leaf_mm);
     const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
-    hipError_t e = hipMemsetAsync(nruns, 0, sizeof(unsigned int), st);
+    VoxelDiv dv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
+    {   // floor(u / leaf) == umulhi(u, magic) for every biased coordinate u = v + bias*leaf, v in [-32768, 32767]:
+        // verified here over all 65 536 of them (once per leaf per host thread), magic = 0 -> the kernel divides
+        thread_local int cached_leaf = 0;
+        thread_local unsigned int cached_magic = 0;
+        if (cached_leaf != leaf_mm) {
+            const unsigned long long magic = ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
+            bool ok = magic < (1ull << 32);
+            const unsigned int lo = dv.bias_leaf - 32768u, hi = dv.bias_leaf + 32767u;
+            for (unsigned int u = lo; ok && u <= hi; u++)
+                ok = (unsigned int)(((unsigned long long)u * magic) >> 32) == u / (unsigned)leaf_mm;
+            cached_leaf = leaf_mm;
+            cached_magic = ok ? (unsigned int)magic : 0u;
+        }
+        dv.magic = cached_magic;
+    }
+    hipError_t e = hipMemsetAsync(w.ctl, 0, 2 * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
     const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
-    const dim3 grid((n_points + per_block - 1) / per_block);
-    hipLaunchKernelGGL(pcs_voxel_partials_kernel, grid, dim3(kAggThreads), 0, st, d_payload, n_points, leaf_mm,
-                       bits, bias, keys_a, idx_a, part, nruns);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    unsigned int m = 0;                                  // the library primitives take their size from the host
-    e = hipMemcpyAsync(&m, nruns, sizeof m, hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return e;
-    if (m == 0 || m > n_points) return hipErrorUnknown;      // a workgroup appends at most one partial per point
-    size_t s1 = sort_tmp;
-    e = rocprim::radix_sort_pairs(tmp, s1, keys_a, keys_b, idx_a, idx_b, (size_t)m, 0u, 3u * bits, st);
-    if (e != hipSuccess) return e;
-    auto values = rocprim::make_transform_iterator(idx_b, LoadPartial{part});
-    size_t s2 = reduce_tmp;
-    e = rocprim::reduce_by_key(tmp, s2, keys_b, values, (size_t)m, keys_a /* unique keys, reuse */, agg, nvox, VoxelPlus{},
-                               rocprim::equal_to<unsigned long long>(), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pcs_voxel_finalize_kernel, dim3((m + 255) / 256), dim3(256), 0, st, agg, nvox, d_out, d_out_points);
+    hipLaunchKernelGGL(pcs_voxel_partials_kernel, dim3((n_points + per_block - 1) / per_block), dim3(kAggThreads), 0, st,
+                       d_payload, n_points, dv, bits, w.keys_a, w.idx_a, w.part, w.ctl);
+
+    // grids sized for what the launch can need at most, capped: the kernels loop over chunks / blocks
+    const unsigned int max_chunks = (n_points + kSortChunk - 1) / kSortChunk;
+    const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
+    unsigned long long *kin = w.keys_a, *kout = w.keys_b;
+    unsigned int *iin = w.idx_a, *iout = w.idx_b;
+    for (unsigned int shift = 0; shift < 3u * bits; shift += kRadixBits) {
+        hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, w.ctl, shift, w.table);
+        hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, w.ctl, w.digit_total);
+        hipLaunchKernelGGL(pcs_voxel_scatter_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, w.ctl, shift,
+                           w.table, w.digit_total);
+        unsigned long long* tk = kin; kin = kout; kout = tk;
+        unsigned int* ti = iin; iin = iout; iout = ti;
+    }
+    const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
+    const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
+    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, w.ctl, w.heads);
+    hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, w.ctl, w.ctl + 1, d_out_points);
+    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, iin, w.part, w.ctl, w.heads, d_out,
+                       w.lead, w.trail);
+    const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
+    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, w.ctl, w.lead, w.trail, d_out);
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from pointcloud_stitching_amd import synthetic as S
-from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_DROP_INVALID
+from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI_DIR = os.path.join(ROOT, "pointcloud_stitching_amd", "cli")
@@ -48,7 +48,10 @@ def test_fails_loudly_without_a_gpu(cli, gpu_present):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra,flags,ds", [([], 0, 1), (["-i"], FLAG_DROP_INVALID, 1), (["-c", "-d", "3"], FLAG_CUTOFF, 3)])
+@pytest.mark.parametrize("extra,flags,ds", [([], 0, 1), (["-i"], FLAG_DROP_INVALID, 1),
+                                            # -c is the reference's -c -m payload, lane-reversed mask included (:501-502, 519);
+                                            # -C gates every point by its own range test
+                                            (["-c", "-d", "3"], FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, 3), (["-C"], FLAG_CUTOFF, 1)])
 def test_cli_synthetic_matches_oracle(cli, oracle, tmp_path, extra, flags, ds):
     out = str(tmp_path / "stitched.bin")
     r = run(cli, "-f", "synth:640x480", "-m", "-t", "4", "-n", "3", "-r", "3", "-o", out, *extra)

@@ -14,7 +14,7 @@ from pointcloud_stitching_amd import synthetic as S
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI_DIR = os.path.join(ROOT, "pointcloud_stitching_amd", "cli")
 EDGE = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-camera-optimized")
-CENTRAL = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-multicamera-hip")
+CENTRAL = os.path.join(ROOT, "pointcloud_stitching_amd", "bin", "pcs-multicamera-optimized")      # the reference's program name
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -64,8 +64,19 @@ def test_central_cli_surface():
     assert r.returncode == 0 and "-d (downsample)" in r.stdout and "-t (timer)" in r.stdout
     r = subprocess.run([CENTRAL, "-v"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 2 and "PCL" in r.stderr
-    r = subprocess.run([CENTRAL, "-t"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 2
+    assert os.path.basename(CENTRAL) == "pcs-multicamera-optimized"        # shipped under the reference's program name
+    r = subprocess.run([CENTRAL, "-i", "synth:64x48", "-c", "127.0.0.1:1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 2 and "at most one" in r.stderr
+
+
+@pytest.mark.gpu
+def test_central_accepts_the_reference_invocation():
+    """src/pcs-multicamera-optimized.cpp:90 parses "hftsvd:n" with -f a BOOLEAN ("fast"): an existing `-f -t -d2`
+    command line must keep working (round 1 had re-purposed -f as the frame source)."""
+    r = subprocess.run([CENTRAL, "-f", "-t", "-d2", "-N", "2", "-i", "synth:64x48", "-q", "-r", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "no effect" in r.stderr and "Usage" not in r.stdout
 
 
 @pytest.mark.gpu
@@ -141,7 +152,7 @@ def test_full_star_topology_two_edges_one_central(oracle):
 @pytest.mark.gpu
 def test_central_all_gpu_mode(oracle):
     port = free_port()
-    p = subprocess.Popen([CENTRAL, "-f", "synth:128x96", "-N", "3", "-d", "3", "-p", str(port), "-r", "2"],
+    p = subprocess.Popen([CENTRAL, "-i", "synth:128x96", "-N", "3", "-d", "3", "-p", str(port), "-r", "2"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         sock = connect(port)
@@ -164,7 +175,7 @@ def test_central_node_mode_one_gpu(oracle):
     """-G 1: the single-process multi-GPU layer (libpcs_node) with one device — per-device context, counts,
     stitched buffer on the root. (The N>1 exchange is straight-line RCCL and needs a multi-GPU box.)"""
     port = free_port()
-    p = subprocess.Popen([CENTRAL, "-f", "synth:128x96", "-N", "4", "-G", "1", "-p", str(port), "-r", "2"],
+    p = subprocess.Popen([CENTRAL, "-i", "synth:128x96", "-N", "4", "-G", "1", "-p", str(port), "-r", "2"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         sock = connect(port)
@@ -185,6 +196,6 @@ def test_central_node_mode_one_gpu(oracle):
 
 @pytest.mark.gpu
 def test_central_node_mode_rejects_more_gpus_than_present():
-    r = subprocess.run([CENTRAL, "-f", "synth:64x48", "-N", "64", "-G", "64", "-q", "-r", "1"],
+    r = subprocess.run([CENTRAL, "-i", "synth:64x48", "-N", "64", "-G", "64", "-q", "-r", "1"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 1 and "available" in r.stderr
