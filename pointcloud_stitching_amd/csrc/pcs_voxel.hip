@@ -26,6 +26,7 @@
 // Integer sums make the result independent of the order of the partials and of any reduction order.
 // (Round 1 used rocPRIM's radix_sort_pairs + reduce_by_key for steps 2-3: 0.56 ms of library kernels per call at 50 mm,
 // plus a stream synchronisation in the middle of the call to learn m.)
+#include <cstdlib>
 #include <cstring>
 
 #include "pcs_device.h"
@@ -85,21 +86,40 @@ __device__ __forceinline__ unsigned int wave_incl_scan(unsigned int x)
     return v;
 }
 
-// Segmented inclusive scan step over the wavefront for the seven sums of a partial: lanes whose span already contains
+// Segmented inclusive scan step over the wavefront for the sums of a run of points: lanes whose span already contains
 // a run head keep their value; the others add the value `ctrl` lanes below (or the row's carry) and inherit its flag.
 // A lane without a valid source (start of a row for row_shr) receives zeros / "no head", i.e. it simply keeps going.
-struct SegAcc { int x, y, z; unsigned int r, g, b, n; int head; };
+// Within a wavefront the colour sums (<= 64 * 255) and the count (<= 64) fit 16 bits: r|g<<16 and b|n<<16 travel as
+// two words instead of four.
+struct SegAcc { int x, y, z; unsigned int rg, bn; int head; };
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void seg_step(SegAcc& a)
 {
     const int ux = dpp_from<CTRL, ROW_MASK>(a.x), uy = dpp_from<CTRL, ROW_MASK>(a.y), uz = dpp_from<CTRL, ROW_MASK>(a.z);
-    const int ur = dpp_from<CTRL, ROW_MASK>((int)a.r), ug = dpp_from<CTRL, ROW_MASK>((int)a.g), ub = dpp_from<CTRL, ROW_MASK>((int)a.b);
-    const int un = dpp_from<CTRL, ROW_MASK>((int)a.n), uh = dpp_from<CTRL, ROW_MASK>(a.head);
+    const int urg = dpp_from<CTRL, ROW_MASK>((int)a.rg), ubn = dpp_from<CTRL, ROW_MASK>((int)a.bn);
+    const int uh = dpp_from<CTRL, ROW_MASK>(a.head);
     if (!a.head) {
         a.x += ux; a.y += uy; a.z += uz;
-        a.r += (unsigned int)ur; a.g += (unsigned int)ug; a.b += (unsigned int)ub; a.n += (unsigned int)un;
+        a.rg += (unsigned int)urg; a.bn += (unsigned int)ubn;
         a.head = uh;
     }
+}
+
+// One packed record (10 bytes at byte offset 10*i) from ONE 12-byte load instead of five 2-byte loads: an even record
+// starts on a dword, an odd one two bytes after one (the window then starts two bytes early).
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ u32x3 load_record_window(const int16_t* __restrict__ payload, unsigned int i)
+{
+    return *reinterpret_cast<const u32x3*>(payload + (size_t)i * PCS_POINT_SHORTS - (i & 1u));
+}
+__device__ __forceinline__ void unpack_record(const u32x3 d, unsigned int i, int& x, int& y, int& z, unsigned int& col, unsigned int& blue)
+{
+    const bool odd = (i & 1u) != 0u;
+    const unsigned int a = odd ? __builtin_amdgcn_alignbit(d.y, d.x, 16) : d.x;     // x | y << 16
+    const unsigned int b = odd ? __builtin_amdgcn_alignbit(d.z, d.y, 16) : d.y;     // z | colour << 16
+    const unsigned int c = odd ? d.z >> 16 : d.z;                                   // blue (low 16)
+    x = (int)(short)(a & 0xFFFFu); y = (int)(short)(a >> 16);
+    z = (int)(short)(b & 0xFFFFu); col = b >> 16; blue = c & 0xFFu;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -115,6 +135,10 @@ __device__ __forceinline__ void seg_step(SegAcc& a)
 constexpr int kAggThreads = 1024, kAggPerLane = 8, kSlots = 2048, kProbe = 12;
 constexpr unsigned long long kEmptyKey = ~0ull;
 
+// WIDE: the payload is 4-byte aligned and holds >= 2 points: every lane requests its eight records with eight 12-byte
+// loads up front, branch-free (indices clamped to the last record whose window stays inside the payload; an even LAST
+// record, whose window would read two bytes past the end, is passed through as a single-point partial instead).
+template <bool WIDE>
 __global__ __launch_bounds__(kAggThreads)
 void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n, VoxelDiv dv, unsigned int bits,
                                unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
@@ -126,6 +150,16 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     __shared__ unsigned int wtot[kAggThreads / 64];
     __shared__ unsigned int base_s;
 
+    const unsigned int tile0 = blockIdx.x * (unsigned)(kAggThreads * kAggPerLane);
+    u32x3 raw[kAggPerLane];
+    const unsigned int last_safe = ((n - 1u) & 1u) ? n - 1u : n - 2u;       // WIDE: last record with an in-bounds window
+    if (WIDE) {
+#pragma unroll
+        for (int k = 0; k < kAggPerLane; k++) {
+            const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;      // lane-contiguous records
+            raw[k] = load_record_window(payload, i < last_safe ? i : last_safe);
+        }
+    }
     for (int j = threadIdx.x; j < kSlots; j += kAggThreads) {
         skey[j] = kEmptyKey;
         ssx[j] = ssy[j] = ssz[j] = 0;
@@ -133,27 +167,31 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     }
     __syncthreads();
 
-    const unsigned int tile0 = blockIdx.x * (unsigned)(kAggThreads * kAggPerLane);
     const int lane = threadIdx.x & 63;
     unsigned int failed = 0;                                  // bit k: point k of this lane found no slot
 #pragma unroll
     for (int k = 0; k < kAggPerLane; k++) {
-        const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;      // lane-contiguous records
-        const bool live = i < n;
+        const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;
+        const bool exists = i < n;
+        const bool live = exists && (!WIDE || i <= last_safe);
         int x = 0, y = 0, z = 0;
         unsigned int col = 0, blue = 0;
-        if (live) {
+        if (WIDE) {
+            unpack_record(raw[k], i, x, y, z, col, blue);
+        } else if (live) {
             const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
             x = p[0]; y = p[1]; z = p[2];
             col = (unsigned short)p[3]; blue = (unsigned short)p[4] & 0xFFu;
         }
         // dead lanes (ragged last wavefront) get a key no live point has, so they form their own runs and never act
         const unsigned long long key = live ? voxel_key(dv, x, y, z, bits) : (kEmptyKey - 1ull - (unsigned long long)lane);
-        SegAcc a{x, y, z, col & 0xFFu, col >> 8, blue, 1u, 0};
-        const unsigned long long prev = ((unsigned long long)(unsigned int)__builtin_amdgcn_update_dpp(0, (int)(key >> 32), 0x138, 0xf, 0xf, false) << 32) |
-                                        (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xf, 0xf, false);   // wave_shr:1
-        const unsigned long long next = ((unsigned long long)(unsigned int)__builtin_amdgcn_update_dpp(0, (int)(key >> 32), 0x130, 0xf, 0xf, false) << 32) |
-                                        (unsigned int)__builtin_amdgcn_update_dpp(0, (int)key, 0x130, 0xf, 0xf, false);   // wave_shl:1
+        // Neighbouring lanes hold neighbouring pixels, which mostly share a voxel: runs of equal keys across the
+        // wavefront are summed first and only the LAST lane of a run touches the table.
+        SegAcc a{x, y, z, (col & 0xFFu) | ((col >> 8) << 16), blue | (1u << 16), 0};
+        const unsigned long long prev = ((unsigned long long)(unsigned int)dpp_from<0x138, 0xf>((int)(key >> 32)) << 32) |
+                                        (unsigned int)dpp_from<0x138, 0xf>((int)key);       // wave_shr:1
+        const unsigned long long next = ((unsigned long long)(unsigned int)dpp_from<0x130, 0xf>((int)(key >> 32)) << 32) |
+                                        (unsigned int)dpp_from<0x130, 0xf>((int)key);       // wave_shl:1
         a.head = (lane == 0 || prev != key) ? 1 : 0;
         bool actor = live;
         // merging pays when the wavefront holds few runs; with many (small leaves) the scan costs more than the
@@ -161,22 +199,12 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
         const bool merge = __popcll(__ballot(a.head != 0)) <= 24;
         if (merge) {
             actor = live && (lane == 63 || next != key);         // last lane of its run
-            // a lane is finished once its span holds its run's head; runs are short, so most wavefronts are done after
-            // two or three steps (wave-uniform early exit)
             seg_step<0x111, 0xf>(a);                             // row_shr:1
-            if (__ballot(a.head == 0)) {
-                seg_step<0x112, 0xf>(a);                         // row_shr:2
-                if (__ballot(a.head == 0)) {
-                    seg_step<0x114, 0xf>(a);                     // row_shr:4
-                    if (__ballot(a.head == 0)) {
-                        seg_step<0x118, 0xf>(a);                 // row_shr:8
-                        if (__ballot(a.head == 0)) {
-                            seg_step<0x142, 0xa>(a);             // row_bcast:15 -> rows 1, 3
-                            seg_step<0x143, 0xc>(a);             // row_bcast:31 -> rows 2, 3
-                        }
-                    }
-                }
-            }
+            seg_step<0x112, 0xf>(a);                             // row_shr:2
+            seg_step<0x114, 0xf>(a);                             // row_shr:4
+            seg_step<0x118, 0xf>(a);                             // row_shr:8
+            seg_step<0x142, 0xa>(a);                             // row_bcast:15 -> rows 1, 3
+            seg_step<0x143, 0xc>(a);                             // row_bcast:31 -> rows 2, 3
         }
         unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 53);       // 11 bits
         bool placed = false;
@@ -188,8 +216,8 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
             }
             if (placed) {
                 atomicAdd(&ssx[h], a.x); atomicAdd(&ssy[h], a.y); atomicAdd(&ssz[h], a.z);
-                atomicAdd(&sr[h], a.r); atomicAdd(&sg[h], a.g); atomicAdd(&sb[h], a.b);
-                atomicAdd(&sn[h], a.n);
+                atomicAdd(&sr[h], a.rg & 0xFFFFu); atomicAdd(&sg[h], a.rg >> 16); atomicAdd(&sb[h], a.bn & 0xFFFFu);
+                atomicAdd(&sn[h], a.bn >> 16);
             }
         }
         if (merge) {
@@ -200,7 +228,7 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
             const int mine_actor = __ffsll((long long)at_or_after) - 1;            // -1 only for dead lanes
             placed = mine_actor >= 0 && ((ok >> mine_actor) & 1ull);
         }
-        if (live && !placed) failed |= 1u << k;
+        if (exists && !placed) failed |= 1u << k;
     }
     __syncthreads();
 
@@ -666,33 +694,41 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
         }
         dv.magic = cached_magic;
     }
-    hipError_t e = hipMemsetAsync(w.ctl, 0, 2 * sizeof(unsigned int), st);
+    hipError_t e = hipMemsetAsync(w.ctl, 0, 4 * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
     const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
-    hipLaunchKernelGGL(pcs_voxel_partials_kernel, dim3((n_points + per_block - 1) / per_block), dim3(kAggThreads), 0, st,
-                       d_payload, n_points, dv, bits, w.keys_a, w.idx_a, w.part, w.ctl);
+    const dim3 agg_grid((n_points + per_block - 1) / per_block);
+    static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
+    if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits,
+                           w.keys_a, w.idx_a, w.part, w.ctl);
+    else
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits,
+                           w.keys_a, w.idx_a, w.part, w.ctl);
+    unsigned long long *kin = w.keys_a, *kout = w.keys_b;
+    unsigned int *iin = w.idx_a, *iout = w.idx_b;
+    const VoxelPartial* parts = w.part;
+    const unsigned int* m_ptr = w.ctl;
 
     // grids sized for what the launch can need at most, capped: the kernels loop over chunks / blocks
     const unsigned int max_chunks = (n_points + kSortChunk - 1) / kSortChunk;
     const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
-    unsigned long long *kin = w.keys_a, *kout = w.keys_b;
-    unsigned int *iin = w.idx_a, *iout = w.idx_b;
     for (unsigned int shift = 0; shift < 3u * bits; shift += kRadixBits) {
-        hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, w.ctl, shift, w.table);
-        hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, w.ctl, w.digit_total);
-        hipLaunchKernelGGL(pcs_voxel_scatter_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, w.ctl, shift,
+        hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, m_ptr, shift, w.table);
+        hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, m_ptr, w.digit_total);
+        hipLaunchKernelGGL(pcs_voxel_scatter_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, m_ptr, shift,
                            w.table, w.digit_total);
         unsigned long long* tk = kin; kin = kout; kout = tk;
         unsigned int* ti = iin; iin = iout; iout = ti;
     }
     const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
     const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
-    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, w.ctl, w.heads);
-    hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, w.ctl, w.ctl + 1, d_out_points);
-    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, iin, w.part, w.ctl, w.heads, d_out,
+    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, m_ptr, w.heads);
+    hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, m_ptr, w.ctl + 1, d_out_points);
+    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, iin, parts, m_ptr, w.heads, d_out,
                        w.lead, w.trail);
     const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
-    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, w.ctl, w.lead, w.trail, d_out);
+    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, m_ptr, w.lead, w.trail, d_out);
     return hipGetLastError();
 }
 

@@ -186,3 +186,64 @@ def test_config5_full_size_against_oracle_digests():
             assert int(nv[0]) == want["voxels"], leaf
             got = np.empty(int(nv[0]) * 5, np.int16); ctx.memcpy_d2h(got, d_vox)
             assert hashlib.sha256(got.tobytes()).hexdigest() == want["sha256"], leaf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 4095, 4096, 4097, 8191, 8193, 70001])
+def test_gpu_voxel_grid_sizes_around_the_kernels_block_borders(oracle, n):
+    """n = 1 takes the narrow-load kernel; an even LAST record (odd n) is passed through as a single-point partial by the
+    wide-load kernel; 256 / 4096 / 8192 are the block sizes of the segmented mean, the sort chunks and the pre-aggregation."""
+    p = random_payload(n, 700 + n, 600)
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        for leaf in (1, 64, 5000):
+            got = ctx.voxel_grid(p, leaf)
+            want = oracle.voxel_grid(p, leaf)
+            assert got.shape == want.shape and (got == want).all(), (n, leaf)
+
+
+@pytest.mark.gpu
+def test_gpu_voxel_grid_long_runs_cross_many_blocks(oracle):
+    """Runs of equal keys far longer than a 256-element block of the segmented mean: every pre-aggregation workgroup
+    contributes a partial to the SAME few voxels, so after the sort a run spans dozens of blocks (lead / trail pieces
+    and the fix-up kernel), and the sums exceed 32 bits (64-bit accumulation across blocks)."""
+    rng = np.random.default_rng(17)
+    n = 120 * 8192 + 5
+    p = np.zeros((n, 5), np.int16)
+    p[:, 0] = rng.integers(30000, 32767, n)                # large coordinates: coordinate sums pass 2^31 quickly
+    p[:, 1] = rng.integers(-32768, -30000, n)
+    p[:, 2] = rng.integers(0, 3, n) * 1000                 # three voxels along z at leaf 5000
+    p[:, 3] = rng.integers(0, 65536, n).astype(np.uint16).view(np.int16)
+    p[:, 4] = rng.integers(0, 256, n)
+    # plus a sprinkle of isolated points so that short and long runs are mixed in the sorted order
+    p[::977, :3] = rng.integers(-20000, 20000, (p[::977].shape[0], 3))
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        for leaf in (1000, 5000, 32767):
+            got = ctx.voxel_grid(p, leaf)
+            want = oracle.voxel_grid(p, leaf)
+            assert got.shape == want.shape and (got == want).all(), leaf
+
+
+@pytest.mark.gpu
+def test_gpu_voxel_grid_device_unaligned_payload_and_async(oracle):
+    """Device API: a payload that starts 2 bytes off a dword (the reference's buffer + 2 shorts convention shifted once
+    more) takes the narrow-load pre-aggregation; two calls queued back to back without synchronising in between (the call
+    no longer waits for the host anywhere) must both be right."""
+    p = random_payload(50001, 23, 1500)
+    want = {leaf: oracle.voxel_grid(p, leaf) for leaf in (10, 300)}
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        d_in = ctx.device_malloc(p.nbytes + 64)
+        outs = {leaf: ctx.device_malloc(p.nbytes + 64) for leaf in want}
+        cnts = {leaf: ctx.device_malloc(4) for leaf in want}
+        for skew in (0, 2):
+            ctx.memcpy_h2d(d_in + skew, p)
+            for leaf in want:                                  # queued back to back
+                ctx.voxel_grid_device(d_in + skew, p.shape[0], leaf, outs[leaf], p.size, cnts[leaf])
+            ctx.synchronize()
+            for leaf in want:
+                nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, cnts[leaf])
+                assert int(nv[0]) == want[leaf].shape[0], (skew, leaf)
+                got = np.empty((int(nv[0]), 5), np.int16); ctx.memcpy_d2h(got, outs[leaf])
+                assert (got == want[leaf]).all(), (skew, leaf)
