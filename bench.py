@@ -236,7 +236,12 @@ def main():
     cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
     mode_flags = {"drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}.get(args.mode, 0)
     ctx = PcsContext(cfgs, device=local_rank, flags=mode_flags)
-    stream = torch.cuda.current_stream(dev)
+    # One explicit HIP stream for everything this rank enqueues: the library's kernels (pcs_set_stream) and torch's own
+    # work — the RCCL gather orders itself against torch's CURRENT stream. (torch's default stream has the handle 0, which
+    # pcs_set_stream reads as "use the context's own stream": the kernels and the gather would then be unordered.)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
 
     # Ring of frame-sets resident in HBM, carved from ONE slab at 256-byte granularity (power-of-two aligned

@@ -271,11 +271,12 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
 
 // ------------------------------------------------------------------------------------------------
 // 2. LSD radix sort of (key, index) pairs, 11 bits per pass, element count read from device memory.
-//    Chunks of 4096 elements; persistent grids (the kernels loop over chunks), so a launch costs the same whether the
+//    Chunks of 8192 elements handled by 512-lane workgroups (half as many chunks = half as many strided accesses in the
+//    column scan, same number of wavefronts in flight); persistent grids (the kernels loop over chunks), so a launch costs the same whether the
 //    pre-aggregation left 90 k or 17 M partials and needs no size from the host.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRadixBits = 11, kRadix = 1 << kRadixBits;
-constexpr unsigned int kSortChunk = 4096, kSortThreads = 256, kSortGrid = 4096, kSortBatch = 8;
+constexpr unsigned int kSortChunk = 8192, kSortThreads = 512, kSortWaves = kSortThreads / 64, kSortGrid = 4096, kSortBatch = 8;
 
 __device__ __forceinline__ unsigned int digit_of(unsigned long long key, unsigned int shift) { return (unsigned int)(key >> shift) & (kRadix - 1); }
 
@@ -341,7 +342,7 @@ void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned i
     if (lane == 0) digit_total[digit] = carry;
 }
 
-// Stable scatter. Wavefront w of the workgroup owns the w-th quarter of the chunk and walks it 64 elements at a time,
+// Stable scatter. Wavefront w of the workgroup owns the w-th eighth of the chunk and walks it 64 elements at a time,
 // so "earlier in memory" = (lower wavefront, lower round, lower lane):
 //   destination = digit base (all smaller digits) + this digit in earlier chunks (column scan)
 //               + this digit in earlier wavefronts of the chunk + in earlier rounds of this wavefront + in lower lanes.
@@ -353,14 +354,14 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
                               const unsigned int* __restrict__ m_ptr, unsigned int shift,
                               const unsigned int* __restrict__ table, const unsigned int* __restrict__ digit_total)
 {
-    __shared__ unsigned int cnt[4][kRadix];      // 32 KiB
+    __shared__ unsigned int cnt[kSortWaves][kRadix];      // 64 KiB
     __shared__ unsigned int dbase[kRadix];       //  8 KiB
-    __shared__ unsigned int wsum[4];
+    __shared__ unsigned int wsum[kSortWaves];
     const unsigned int m = *m_ptr;
     const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
     if (blockIdx.x >= chunks) return;
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    constexpr unsigned int kPer = kRadix / kSortThreads;      // 8 consecutive digits per thread
+    constexpr unsigned int kPer = kRadix / kSortThreads;      // 4 consecutive digits per thread
 
     {   // digit bases: exclusive scan of the 2048 digit totals
         unsigned int v[kPer], s = 0;
@@ -377,11 +378,11 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
     }
 
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        for (unsigned int j = threadIdx.x; j < 4 * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
+        for (unsigned int j = threadIdx.x; j < kSortWaves * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
         __syncthreads();
-        const unsigned int w0 = chunk * kSortChunk + wave * (kSortChunk / 4);
+        const unsigned int w0 = chunk * kSortChunk + wave * (kSortChunk / kSortWaves);
         // count: this wavefront's occurrences of every digit
-        constexpr unsigned int kRounds = kSortChunk / 4 / 64;
+        constexpr unsigned int kRounds = kSortChunk / kSortWaves / 64;
         for (unsigned int r0 = 0; r0 < kRounds; r0 += kSortBatch) {
             unsigned long long k[kSortBatch];
 #pragma unroll
@@ -400,7 +401,7 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
         for (unsigned int j = threadIdx.x; j < kRadix; j += kSortThreads) {
             unsigned int start = dbase[j] + table[(size_t)chunk * kRadix + j];
 #pragma unroll
-            for (unsigned int w = 0; w < 4; w++) { const unsigned int c = cnt[w][j]; cnt[w][j] = start; start += c; }
+            for (unsigned int w = 0; w < kSortWaves; w++) { const unsigned int c = cnt[w][j]; cnt[w][j] = start; start += c; }
         }
         __syncthreads();
         // place: one round of 64 elements at a time, in order (the loads of a batch of rounds go out together)
