@@ -141,7 +141,7 @@ constexpr unsigned long long kEmptyKey = ~0ull;
 template <bool WIDE>
 __global__ __launch_bounds__(kAggThreads)
 void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n, VoxelDiv dv, unsigned int bits,
-                               unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
+                               unsigned int idx_bits, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
                                VoxelPartial* __restrict__ part, unsigned int* __restrict__ n_runs)
 {
     __shared__ unsigned long long skey[kSlots];
@@ -199,6 +199,10 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
         const bool merge = __popcll(__ballot(a.head != 0)) <= 24;
         if (merge) {
             actor = live && (lane == 63 || next != key);         // last lane of its run
+            // (Measured and dropped: a wave-uniform early exit once every lane's span holds its run's head — any branch
+            // inside this unrolled loop stops the compiler from overlapping the eight iterations: 254 vs 188 us at 50 mm,
+            // taken or not; and a split into a branch-free phase for all eight records followed by the table phase —
+            // 128 VGPRs, one workgroup per CU: 312 us.)
             seg_step<0x111, 0xf>(a);                             // row_shr:1
             seg_step<0x112, 0xf>(a);                             // row_shr:2
             seg_step<0x114, 0xf>(a);                             // row_shr:4
@@ -251,7 +255,8 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     for (int q = 0; q < kSlots / kAggThreads; q++) {
         const int j = threadIdx.x * (kSlots / kAggThreads) + q;
         if (skey[j] != kEmptyKey) {
-            keys[pos] = skey[j]; idx[pos] = pos;
+            if (idx_bits) keys[pos] = (skey[j] << idx_bits) | pos;      // packed: the partial's index rides in the low bits
+            else { keys[pos] = skey[j]; idx[pos] = pos; }
             part[pos] = VoxelPartial{ssx[j], ssy[j], ssz[j], sr[j], sg[j], sb[j], sn[j], 0u};
             pos++;
         }
@@ -263,7 +268,8 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
         const int16_t* p = payload + (size_t)i * PCS_POINT_SHORTS;
         const int x = p[0], y = p[1], z = p[2];
         const unsigned int col = (unsigned short)p[3], blue = (unsigned short)p[4] & 0xFFu;
-        keys[pos] = voxel_key(dv, x, y, z, bits); idx[pos] = pos;
+        if (idx_bits) keys[pos] = (voxel_key(dv, x, y, z, bits) << idx_bits) | pos;
+        else { keys[pos] = voxel_key(dv, x, y, z, bits); idx[pos] = pos; }
         part[pos] = VoxelPartial{x, y, z, col & 0xFFu, col >> 8, blue, 1u, 0u};
         pos++;
     }
@@ -348,6 +354,10 @@ void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned i
 //               + this digit in earlier wavefronts of the chunk + in earlier rounds of this wavefront + in lower lanes.
 // The last three come from per-(wavefront, digit) LDS counters: counted first (LDS adds), turned into starting offsets,
 // then advanced round by round by the lowest lane of each group of equal digits (found with 11 ballots).
+// PACKED: the element is (key << idx_bits) | partial index in ONE 64-bit word (possible when 3*bits + idx_bits <= 64, i.e.
+// for every leaf >= 8 mm on the 30 M-point cloud): one 8-byte scattered store per element instead of 8 + 4, and no
+// index arrays at all.
+template <bool PACKED>
 __global__ __launch_bounds__(kSortThreads)
 void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ idx_in,
                               unsigned long long* __restrict__ keys_out, unsigned int* __restrict__ idx_out,
@@ -412,7 +422,7 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
                 k[q] = 0ull; id[q] = 0u;
-                if (e < m) { k[q] = keys_in[e]; id[q] = idx_in[e]; }
+                if (e < m) { k[q] = keys_in[e]; if (!PACKED) id[q] = idx_in[e]; }
             }
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
@@ -432,7 +442,7 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
                     if (below == 0) cnt[wave][d] = start + __popcll(peers);       // the group's lowest lane advances the counter
                     const unsigned int dst = start + below;
                     keys_out[dst] = k[q];
-                    idx_out[dst] = id[q];
+                    if (!PACKED) idx_out[dst] = id[q];
                 }
             }
         }
@@ -453,14 +463,14 @@ constexpr unsigned int kSegThreads = 256, kSegGrid = 4096;
 // heads[b] = runs that START in block b (block = 256 consecutive sorted elements)
 __global__ __launch_bounds__(kSegThreads)
 void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ m_ptr,
-                            unsigned int* __restrict__ heads)
+                            unsigned int idx_bits, unsigned int* __restrict__ heads)
 {
     __shared__ unsigned int wsum[4];
     const unsigned int m = *m_ptr;
     const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
     for (unsigned int b = blockIdx.x; b < blocks; b += gridDim.x) {
         const unsigned int g = b * kSegThreads + threadIdx.x;
-        const bool head = g < m && (g == 0 || keys[g] != keys[g - 1]);
+        const bool head = g < m && (g == 0 || (keys[g] >> idx_bits) != (keys[g - 1] >> idx_bits));
         const unsigned int c = __popcll(__ballot(head));
         if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = c;
         __syncthreads();
@@ -558,7 +568,7 @@ __device__ __forceinline__ void write_voxel(int16_t* __restrict__ out, unsigned 
 __global__ __launch_bounds__(kSegThreads)
 void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ idx,
                              const VoxelPartial* __restrict__ part, const unsigned int* __restrict__ m_ptr,
-                             const unsigned int* __restrict__ block_base, int16_t* __restrict__ out,
+                             unsigned int idx_bits, const unsigned int* __restrict__ block_base, int16_t* __restrict__ out,
                              BlockPiece* __restrict__ lead, BlockPiece* __restrict__ trail)
 {
     __shared__ SegSum wv[4];
@@ -572,10 +582,11 @@ void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys, const 
         unsigned long long key = 0, kprev = 0, knext = 0;
         VoxelPartial q{0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
-            key = keys[g];
-            kprev = g ? keys[g - 1] : ~key;
-            knext = g + 1 < m ? keys[g + 1] : ~key;
-            q = part[idx[g]];
+            const unsigned long long e = keys[g];
+            key = e >> idx_bits;
+            kprev = g ? keys[g - 1] >> idx_bits : ~key;
+            knext = g + 1 < m ? keys[g + 1] >> idx_bits : ~key;
+            q = part[idx_bits ? (unsigned int)(e & ((1ull << idx_bits) - 1ull)) : idx[g]];
         }
         const bool head = !live || kprev != key;          // dead lanes (past m) are heads of empty runs: they absorb nothing
         const bool tail = live && knext != key;
@@ -699,12 +710,17 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
     if (e != hipSuccess) return e;
     const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
     const dim3 agg_grid((n_points + per_block - 1) / per_block);
+    // one 64-bit word per element when the packed key and the partial's index fit together
+    unsigned int idx_bits = 1;
+    while ((1ull << idx_bits) < (unsigned long long)n_points) idx_bits++;
+    static const int pack_ok = [] { const char* v = getenv("PCS_VOXEL_PACKED"); return v ? atoi(v) : 1; }();
+    if (!pack_ok || 3u * bits + idx_bits > 64u) idx_bits = 0;
     static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
     if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits,
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits, idx_bits,
                            w.keys_a, w.idx_a, w.part, w.ctl);
     else
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits,
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits, idx_bits,
                            w.keys_a, w.idx_a, w.part, w.ctl);
     unsigned long long *kin = w.keys_a, *kout = w.keys_b;
     unsigned int *iin = w.idx_a, *iout = w.idx_b;
@@ -714,19 +730,24 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
     // grids sized for what the launch can need at most, capped: the kernels loop over chunks / blocks
     const unsigned int max_chunks = (n_points + kSortChunk - 1) / kSortChunk;
     const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
-    for (unsigned int shift = 0; shift < 3u * bits; shift += kRadixBits) {
+    for (unsigned int pass_bit = 0; pass_bit < 3u * bits; pass_bit += kRadixBits) {
+        const unsigned int shift = pass_bit + idx_bits;
         hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, m_ptr, shift, w.table);
         hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, m_ptr, w.digit_total);
-        hipLaunchKernelGGL(pcs_voxel_scatter_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, m_ptr, shift,
-                           w.table, w.digit_total);
+        if (idx_bits)
+            hipLaunchKernelGGL(pcs_voxel_scatter_kernel<true>, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, m_ptr, shift,
+                               w.table, w.digit_total);
+        else
+            hipLaunchKernelGGL(pcs_voxel_scatter_kernel<false>, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, m_ptr, shift,
+                               w.table, w.digit_total);
         unsigned long long* tk = kin; kin = kout; kout = tk;
         unsigned int* ti = iin; iin = iout; iout = ti;
     }
     const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
     const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
-    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, m_ptr, w.heads);
+    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, m_ptr, idx_bits, w.heads);
     hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, m_ptr, w.ctl + 1, d_out_points);
-    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, iin, parts, m_ptr, w.heads, d_out,
+    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, iin, parts, m_ptr, idx_bits, w.heads, d_out,
                        w.lead, w.trail);
     const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
     hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, m_ptr, w.lead, w.trail, d_out);
