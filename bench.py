@@ -57,6 +57,7 @@ def parse():
                     help="only the headline leg: skip compaction / batched / pack / cache-resident / two-stream / rotation legs")
     ap.add_argument("--no-cache-leg", action="store_true",
                     help="skip the informational legs (Infinity-Cache-resident ring, two HIP streams)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 16 x 1920x1080 compaction + voxel-grid leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: shard only, skip the gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
@@ -669,6 +670,52 @@ def main():
                                 "note": "copyPointCloudXYZRGBToBufferSIMD's twin on device-resident rs2::points arrays "
                                         "(12 B vertex + 8 B texcoord + 3 B RGB in, 10 B out): pcs_copy_pointclouds_xyzrgb_to_buffer_device "
                                         "(one launch for all cameras) vs pcs_copy_pointcloud_xyzrgb_to_buffer_device per camera"}
+        if extra and not args.no_config5:
+            # ---- BASELINE configs[4] on ONE GPU: 16 x 1920x1080 -> invalid-depth compaction -> camera-order stitch -> voxel
+            # grid of the stitched cloud, device-resident and asynchronous (the voxel grid reads the kept total from the
+            # device); 4 input sets (664 MB) so that the rasters come from HBM
+            W5, H5, S5, LEAF = 1920, 1080, 16, 50
+            cfg5 = [Syn.synth_stream_config(W5, H5, s) for s in range(S5)]
+            ctx5 = PcsContext(cfg5, device=local_rank, flags=FLAG_DROP_INVALID)
+            ctx5.set_stream(stream.cuda_stream)
+            n5 = W5 * H5
+            dep5 = [torch.from_numpy(Syn.synth_depth(W5, H5, s).reshape(-1).view(np.uint8)).to(dev) for s in range(S5)]
+            col5 = [torch.from_numpy(Syn.synth_color(W5, H5, s)).to(dev) for s in range(S5)]
+            sets5 = [(dep5, col5)] + [([d.clone() for d in dep5], [c.clone() for c in col5]) for _ in range(3)]
+            pay5 = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
+            vox5 = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
+            cnt5 = torch.zeros(S5 + 1, dtype=torch.int32, device=dev)
+            nv5 = torch.zeros(1, dtype=torch.int32, device=dev)
+            args5 = [((VP * S5)(*[t.data_ptr() for t in d]), (VP * S5)(*[t.data_ptr() for t in c])) for d, c in sets5]
+            k5 = [0]
+
+            def compact5():
+                dp, cp = args5[k5[0] % 4]; k5[0] += 1
+                check(lib.pcs_process_frames_device(ctx5._h, dp, cp, VP(pay5.data_ptr()), pay5.numel(), VP(cnt5.data_ptr())), ctx5._h)
+
+            def voxel5():
+                check(lib.pcs_voxel_grid_device_counted(ctx5._h, VP(pay5.data_ptr()), VP(cnt5.data_ptr() + 4 * S5), S5 * n5, LEAF,
+                                                        VP(vox5.data_ptr()), vox5.numel(), VP(nv5.data_ptr())), ctx5._h)
+
+            def both5():
+                compact5(); voxel5()
+            for _ in range(3):
+                both5()
+            torch.cuda.synchronize(dev)
+            ms_c5 = timed(compact5, 30, ctx5)
+            ms_v5 = timed(voxel5, 30, ctx5)
+            ms_b5 = timed(both5, 30, ctx5)
+            kept5, nvox5 = int(cnt5[S5].item()), int(nv5.item())
+            out["config5_one_gpu"] = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
+                                      "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
+                                      "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
+                                      "pipeline_ms_per_frame_set": round(ms_b5, 4),
+                                      "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
+                                      "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
+                                              "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}
+            ctx5.close()
+            del dep5, col5, sets5, pay5, vox5
         if extra and not args.no_cache_leg and R > 6:
             # Informational: the same launches on a ring of 6 frame-sets, whose input rasters (221 MB for 8 x 720p) fit the
             # 256 MiB Infinity Cache — what the kernel reads when its inputs were produced or touched on the GPU just

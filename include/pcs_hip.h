@@ -249,6 +249,12 @@ int pcs_stitch_device(pcs_ctx* ctx, const int16_t* const* d_cam_payload, const i
  * hand-written kernels that read their sizes from device memory; no host round trip in the middle).            */
 int pcs_voxel_grid_device(pcs_ctx* ctx, const int16_t* d_payload, int n_points, int leaf_mm,
                           int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
+/* Counted form for device pipelines: the number of points is READ FROM DEVICE MEMORY when the kernels run (e.g. the total
+ * pcs_process_frames_device left in d_counts[n_streams] under CUTOFF / DROP_INVALID), max_points is the capacity of the
+ * payload (it sizes the workspace; the output needs room for max_points points). BASELINE config 5 — compaction, stitch,
+ * voxel grid — then is two asynchronous calls with no host round trip between them.                                */
+int pcs_voxel_grid_device_counted(pcs_ctx* ctx, const int16_t* d_payload, const int32_t* d_n_points, int max_points,
+                                  int leaf_mm, int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
 int pcs_voxel_grid(pcs_ctx* ctx, const int16_t* payload, int n_points, int leaf_mm,
                    int16_t* out, size_t out_shorts, int* out_points);
 

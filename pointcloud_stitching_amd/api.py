@@ -269,6 +269,13 @@ class PcsContext:
         self._check(self._lib.pcs_voxel_grid_device(self._h, d_payload, n_points, int(leaf_mm), d_out, out_shorts,
                                                     d_out_points or None))
 
+    def voxel_grid_device_counted(self, d_payload: int, d_n_points: int, max_points: int, leaf_mm: int, d_out: int,
+                                  out_shorts: int, d_out_points: int = 0) -> None:
+        """The point count is read from device memory (d_n_points) when the kernels run: no host round trip after a
+        compaction launch. See pcs_voxel_grid_device_counted."""
+        self._check(self._lib.pcs_voxel_grid_device_counted(self._h, d_payload, d_n_points, int(max_points), int(leaf_mm),
+                                                            d_out, out_shorts, d_out_points or None))
+
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))

@@ -1221,8 +1221,8 @@ int pcs_stitch_device(pcs_ctx* c, const int16_t* const* d_cam_payload, const int
 }
 
 // ---- voxel-grid downsample (not in the reference; defined in pcs_voxel.hip / DESIGN.md) ----------
-int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, int leaf_mm, int16_t* d_out,
-                          size_t out_shorts, int32_t* d_out_points)
+static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_points, const int32_t* d_n_points, int leaf_mm,
+                                  int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
 {
     if (!c) return PCS_ERR_INVALID_ARG;
     if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
@@ -1236,9 +1236,23 @@ int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, in
     if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
     int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
     if (rc) return rc;
-    HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out,
+    HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, d_n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out,
                                 d_out_points, c->stream));
     return PCS_OK;
+}
+
+int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, int leaf_mm, int16_t* d_out,
+                          size_t out_shorts, int32_t* d_out_points)
+{
+    return voxel_grid_device_impl(c, d_payload, n_points, nullptr, leaf_mm, d_out, out_shorts, d_out_points);
+}
+
+int pcs_voxel_grid_device_counted(pcs_ctx* c, const int16_t* d_payload, const int32_t* d_n_points, int max_points, int leaf_mm,
+                                  int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!d_n_points) return fail(c, PCS_ERR_INVALID_ARG, "d_n_points is NULL");
+    return voxel_grid_device_impl(c, d_payload, max_points, d_n_points, leaf_mm, d_out, out_shorts, d_out_points);
 }
 
 int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,

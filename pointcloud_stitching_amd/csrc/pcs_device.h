@@ -152,8 +152,8 @@ hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n
 
 // Voxel-grid downsample (pcs_voxel.hip).
 size_t     voxel_workspace_bytes(uint32_t n_points);
-hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
-                             int16_t* d_out, int32_t* d_out_points, hipStream_t st);
+hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
+                             size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st);
 
 // a7 with stride.
 hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,

@@ -140,7 +140,8 @@ constexpr unsigned long long kEmptyKey = ~0ull;
 // record, whose window would read two bytes past the end, is passed through as a single-point partial instead).
 template <bool WIDE>
 __global__ __launch_bounds__(kAggThreads)
-void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n, VoxelDiv dv, unsigned int bits,
+void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int n_host, const int32_t* __restrict__ n_dev,
+                               VoxelDiv dv, unsigned int bits,
                                unsigned int idx_bits, unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx,
                                VoxelPartial* __restrict__ part, unsigned int* __restrict__ n_runs)
 {
@@ -150,9 +151,14 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     __shared__ unsigned int wtot[kAggThreads / 64];
     __shared__ unsigned int base_s;
 
+    // the point count comes from the host, or (counted form) from device memory — e.g. the total a compaction launch
+    // left behind; the grid then covers the buffer's capacity and the surplus workgroups leave here
+    const unsigned int n = n_dev ? (unsigned int)max(*n_dev, 0) : n_host;
     const unsigned int tile0 = blockIdx.x * (unsigned)(kAggThreads * kAggPerLane);
+    if (tile0 >= n) return;
     u32x3 raw[kAggPerLane];
-    const unsigned int last_safe = ((n - 1u) & 1u) ? n - 1u : n - 2u;       // WIDE: last record with an in-bounds window
+    // WIDE: last record with an in-bounds window (the host guarantees room for two records; a lone record is passed through)
+    const unsigned int last_safe = n < 2u ? 0u : (((n - 1u) & 1u) ? n - 1u : n - 2u);
     if (WIDE) {
 #pragma unroll
         for (int k = 0; k < kAggPerLane; k++) {
@@ -173,7 +179,7 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
     for (int k = 0; k < kAggPerLane; k++) {
         const unsigned int i = tile0 + (unsigned)k * kAggThreads + threadIdx.x;
         const bool exists = i < n;
-        const bool live = exists && (!WIDE || i <= last_safe);
+        const bool live = exists && (!WIDE || (i <= last_safe && n >= 2u));
         int x = 0, y = 0, z = 0;
         unsigned int col = 0, blue = 0;
         if (WIDE) {
@@ -676,8 +682,10 @@ inline Workspace carve(uint8_t* base, size_t n)
 // worst case: every point its own partial
 size_t voxel_workspace_bytes(uint32_t n_points) { return carve(nullptr, n_points).bytes + 256; }
 
-hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
-                             int16_t* d_out, int32_t* d_out_points, hipStream_t st)
+// d_n_points != nullptr: the number of points is read from device memory (<= n_points, which then is the capacity that
+// sizes the workspace and the grids)
+hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
+                             size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
 {
     if (n_points == 0) {
         if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
@@ -717,10 +725,10 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, int le
     if (!pack_ok || 3u * bits + idx_bits > 64u) idx_bits = 0;
     static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
     if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits, idx_bits,
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, dv, bits, idx_bits,
                            w.keys_a, w.idx_a, w.part, w.ctl);
     else
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, dv, bits, idx_bits,
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, dv, bits, idx_bits,
                            w.keys_a, w.idx_a, w.part, w.ctl);
     unsigned long long *kin = w.keys_a, *kout = w.keys_b;
     unsigned int *iin = w.idx_a, *iout = w.idx_b;

@@ -52,6 +52,9 @@ def test_bench_line_has_the_contract_keys():
     comp = d["compaction"]
     assert 0.85 < comp["kept_fraction"] < 0.95 and abs(comp["algorithmic_bytes_per_point"] - (5 + 10 * comp["kept_fraction"])) < 1e-2
     assert comp["frac"] > 0.2 and d["batched_dense"]["frac"] > 0.3 and d["pack_twin"]["batched_frac"] > 0.2
+    c5 = d["config5_one_gpu"]
+    assert c5["points_in"] == 16 * 1920 * 1080 and 0.85 < c5["points_kept"] / c5["points_in"] < 0.95 and 0 < c5["voxels"] < c5["points_kept"]
+    assert c5["pipeline_ms_per_frame_set"] > 0
 
 
 def _bench_line(*extra, launcher=()):

@@ -135,6 +135,14 @@ def test_config5_pipeline_compaction_then_voxel_grid(oracle):
         ctx.synchronize()
         nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
         got = np.empty((int(nv[0]), 5), np.int16); ctx.memcpy_d2h(got, d_vox)
+        assert got.shape == want.shape and (got == want).all()
+        # and the counted form: the point count is taken from the compaction's device-side total
+        ctx.memcpy_h2d(d_nv, np.zeros(1, np.int32))
+        ctx.process_frames_device(dd, dc, d_pay, n_max * 5, d_cnt)
+        ctx.voxel_grid_device_counted(d_pay, d_cnt + 4 * 4, n_max, 25, d_vox, n_max * 5, d_nv)
+        ctx.synchronize()
+        nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
+        got = np.empty((int(nv[0]), 5), np.int16); ctx.memcpy_d2h(got, d_vox)
     assert got.shape == want.shape and (got == want).all()
     assert want.shape[0] < stitched.shape[0]
 
@@ -177,10 +185,12 @@ def test_config5_full_size_against_oracle_digests():
         assert list(cnt[:16]) == gold["counts"] and int(cnt[16]) == gold["points"]
         stitched = np.empty(int(cnt[16]) * 5, np.int16); ctx.memcpy_d2h(stitched, d_pay)
         assert hashlib.sha256(stitched.tobytes()).hexdigest() == gold["stitched_sha256"]
-        d_vox = ctx.device_malloc(int(cnt[16]) * 10 + 64)
+        d_vox = ctx.device_malloc(n_max * 10 + 64)
         d_nv = ctx.device_malloc(4)
         for leaf, want in sorted(gold["voxel"].items()):
-            ctx.voxel_grid_device(d_pay, int(cnt[16]), int(leaf), d_vox, int(cnt[16]) * 5, d_nv)
+            # the whole of config 5 as two asynchronous calls: the voxel grid reads the kept total from the device
+            ctx.process_frames_device(dd, dc, d_pay, n_max * 5, d_cnt)
+            ctx.voxel_grid_device_counted(d_pay, d_cnt + 4 * 16, n_max, int(leaf), d_vox, n_max * 5, d_nv)
             ctx.synchronize()
             nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
             assert int(nv[0]) == want["voxels"], leaf
@@ -247,3 +257,25 @@ def test_gpu_voxel_grid_device_unaligned_payload_and_async(oracle):
                 assert int(nv[0]) == want[leaf].shape[0], (skew, leaf)
                 got = np.empty((int(nv[0]), 5), np.int16); ctx.memcpy_d2h(got, outs[leaf])
                 assert (got == want[leaf]).all(), (skew, leaf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 777, 8192])
+def test_gpu_voxel_grid_counted_reads_the_count_from_the_device(oracle, n):
+    """pcs_voxel_grid_device_counted with a capacity far above the live count (incl. 0 and 1 live points)."""
+    cap = 20000
+    p = random_payload(cap, 41, 900)
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        d_in = ctx.device_malloc(p.nbytes + 64); ctx.memcpy_h2d(d_in, p)
+        d_out = ctx.device_malloc(p.nbytes + 64)
+        d_n = ctx.device_malloc(4); ctx.memcpy_h2d(d_n, np.array([n], np.int32))
+        d_nv = ctx.device_malloc(4); ctx.memcpy_h2d(d_nv, np.array([-7], np.int32))
+        ctx.voxel_grid_device_counted(d_in, d_n, cap, 120, d_out, cap * 5, d_nv)
+        ctx.synchronize()
+        nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
+        want = oracle.voxel_grid(p[:n], 120)
+        assert int(nv[0]) == want.shape[0]
+        if want.shape[0]:
+            got = np.empty((int(nv[0]), 5), np.int16); ctx.memcpy_d2h(got, d_out)
+            assert (got == want).all()

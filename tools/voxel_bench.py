@@ -51,4 +51,12 @@ with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
         ctx.timer_end()
         t = ctx.timer_elapsed_ms() / reps
         nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
-        print(f"  voxel grid leaf {leaf:4d} mm: {t:.3f} ms ({total / t / 1e3:.0f} Mpoints/s in) -> {int(nv[0])} voxels")
+        # the whole of config 5, device-resident and asynchronous: compaction launch(es), then the counted voxel grid
+        ctx.timer_begin()
+        for _ in range(reps):
+            ctx.process_frames_device(dd, dc, d_pay, n_max * 5, d_cnt)
+            ctx.voxel_grid_device_counted(d_pay, d_cnt + 4 * n_streams, n_max, leaf, d_vox, n_max * 5, d_nv)
+        ctx.timer_end()
+        t_all = ctx.timer_elapsed_ms() / reps
+        print(f"  voxel grid leaf {leaf:4d} mm: {t:.3f} ms ({total / t / 1e3:.0f} Mpoints/s in) -> {int(nv[0])} voxels; "
+              f"compaction + stitch + voxel grid, no host sync: {t_all:.3f} ms per frame-set ({n_max / t_all / 1e3:.0f} Mpixels/s)")
