@@ -185,6 +185,27 @@ def cpu_baseline(cfgs, depth, color, budget_s):
     }
 
 
+class Leg:
+    """A leg of the line must never cost the line: an exception inside is recorded under `leg_errors` and swallowed."""
+
+    def __init__(self, out, name):
+        self.out, self.name = out, name
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and issubclass(et, Exception):
+            self.out.setdefault("leg_errors", {})[self.name] = f"{et.__name__}: {ev}"[:300]
+            try:
+                import torch
+                torch.cuda.synchronize()
+            except Exception:       # noqa: BLE001
+                pass
+            return True
+        return False
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -593,272 +614,282 @@ def main():
         extra = world == 1 and args.mode == "dense" and not args.no_extra_legs
         n_leg = max(200, min(args.steps, 600))
         if extra:
-            # ---- ordered compaction (invalid-depth drop, ~10 % of the synthetic pixels), cold ring --------------------
-            ctx_c = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
-            ctx_c.set_stream(stream.cuda_stream)
-            d_cnt = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+            with Leg(out, "compaction"):
+                # ---- ordered compaction (invalid-depth drop, ~10 % of the synthetic pixels), cold ring --------------------
+                ctx_c = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
+                ctx_c.set_stream(stream.cuda_stream)
+                d_cnt = torch.zeros(S + 1, dtype=torch.int32, device=dev)
 
-            def launch_c(cnt=None):
-                dp, cp, outp = call_args[next_slot()]
-                check(lib.pcs_process_frames_device(ctx_c._h, dp, cp, outp, payload_shorts, cnt), ctx_c._h)
-            launch_c(VP(d_cnt.data_ptr())); ctx_c.synchronize()
-            kept = int(d_cnt[S].item())
-            for _ in range(100):
-                launch_c()
-            torch.cuda.synchronize(dev)
-            ms_c = timed(launch_c, n_leg, ctx_c)
-            rho = kept / set_points
-            ach_c = set_points * (5 + 10 * rho) / (ms_c * 1e-3) / 1e9
-            out["compaction"] = {"ms_per_step": round(ms_c, 5), "value": round(set_points / ms_c / 1e3, 1), "unit": "Mpoints/s in",
-                                 "kept_fraction": round(rho, 4), "algorithmic_bytes_per_point": round(5 + 10 * rho, 3),
-                                 "achieved": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
-                                 "path": os.environ.get("PCS_COMPACT_PATH", "three (default: count + scan + emit)"),
-                                 "note": "PCS_FLAG_DROP_INVALID, order-preserving (= the reference's -c -m -t1 order), same cold ring; "
-                                         "bytes = 2 (Z16) + 3 (RGB8) + 10*rho (records)"}
-            ctx_c.close()
-            if "PCS_COMPACT_PATH" not in os.environ:
-                # the opt-in one-launch kernel (its forward progress assumes in-order workgroup dispatch; bounded waits and a
-                # three-pass re-run catch a violation — which is why it is not the default)
-                os.environ["PCS_COMPACT_PATH"] = "single"
-                try:
-                    ctx_s = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
-                finally:
-                    del os.environ["PCS_COMPACT_PATH"]
-                ctx_s.set_stream(stream.cuda_stream)
-
-                def launch_s():
+                def launch_c(cnt=None):
                     dp, cp, outp = call_args[next_slot()]
-                    check(lib.pcs_process_frames_device(ctx_s._h, dp, cp, outp, payload_shorts, None), ctx_s._h)
+                    check(lib.pcs_process_frames_device(ctx_c._h, dp, cp, outp, payload_shorts, cnt), ctx_c._h)
+                launch_c(VP(d_cnt.data_ptr())); ctx_c.synchronize()
+                kept = int(d_cnt[S].item())
                 for _ in range(100):
-                    launch_s()
+                    launch_c()
                 torch.cuda.synchronize(dev)
-                ms_s = timed(launch_s, n_leg, ctx_s)
-                ctx_s.synchronize()          # raises if a placement wait ever expired
-                ach_s = set_points * (5 + 10 * rho) / (ms_s * 1e-3) / 1e9
-                out["compaction"]["single_pass_opt_in"] = {"ms_per_step": round(ms_s, 5), "achieved": round(ach_s, 1),
-                                                           "frac": round(ach_s / HBM_PEAK_GBS, 4),
-                                                           "note": "PCS_COMPACT_PATH=single: one launch, Z16 read once"}
-                ctx_s.close()
-            # ---- K frame-sets per launch (throughput form of the dense path) --------------------------------------------
-            if KB >= 2:
-                for _ in range(30):
-                    launch_batch()
+                ms_c = timed(launch_c, n_leg, ctx_c)
+                rho = kept / set_points
+                ach_c = set_points * (5 + 10 * rho) / (ms_c * 1e-3) / 1e9
+                out["compaction"] = {"ms_per_step": round(ms_c, 5), "value": round(set_points / ms_c / 1e3, 1), "unit": "Mpoints/s in",
+                                     "kept_fraction": round(rho, 4), "algorithmic_bytes_per_point": round(5 + 10 * rho, 3),
+                                     "achieved": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
+                                     "path": os.environ.get("PCS_COMPACT_PATH", "three (default: count + scan + emit)"),
+                                     "note": "PCS_FLAG_DROP_INVALID, order-preserving (= the reference's -c -m -t1 order), same cold ring; "
+                                             "bytes = 2 (Z16) + 3 (RGB8) + 10*rho (records)"}
+                ctx_c.close()
+                if "PCS_COMPACT_PATH" not in os.environ:
+                    # the opt-in one-launch kernel (its forward progress assumes in-order workgroup dispatch; bounded waits and a
+                    # three-pass re-run catch a violation — which is why it is not the default)
+                    os.environ["PCS_COMPACT_PATH"] = "single"
+                    try:
+                        ctx_s = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
+                    finally:
+                        del os.environ["PCS_COMPACT_PATH"]
+                    ctx_s.set_stream(stream.cuda_stream)
+
+                    def launch_s():
+                        dp, cp, outp = call_args[next_slot()]
+                        check(lib.pcs_process_frames_device(ctx_s._h, dp, cp, outp, payload_shorts, None), ctx_s._h)
+                    for _ in range(100):
+                        launch_s()
+                    torch.cuda.synchronize(dev)
+                    ms_s = timed(launch_s, n_leg, ctx_s)
+                    ctx_s.synchronize()          # raises if a placement wait ever expired
+                    ach_s = set_points * (5 + 10 * rho) / (ms_s * 1e-3) / 1e9
+                    out["compaction"]["single_pass_opt_in"] = {"ms_per_step": round(ms_s, 5), "achieved": round(ach_s, 1),
+                                                               "frac": round(ach_s / HBM_PEAK_GBS, 4),
+                                                               "note": "PCS_COMPACT_PATH=single: one launch, Z16 read once"}
+                    ctx_s.close()
+            with Leg(out, "batched_dense"):
+                # ---- K frame-sets per launch (throughput form of the dense path) --------------------------------------------
+                if KB >= 2:
+                    for _ in range(30):
+                        launch_batch()
+                    torch.cuda.synchronize(dev)
+                    ms_b = timed(launch_batch, max(50, n_leg // KB), ctx0) / KB
+                    ach_b = set_points * ALGO_BYTES_PER_POINT / (ms_b * 1e-3) / 1e9
+                    out["batched_dense"] = {"frame_sets_per_launch": KB, "ms_per_frame_set": round(ms_b, 5),
+                                            "value": round(set_points / ms_b / 1e3, 1), "achieved": round(ach_b, 1),
+                                            "frac": round(ach_b / HBM_PEAK_GBS, 4),
+                                            "note": "pcs_process_frames_device_batch: the same tiles, K frame-sets share one launch's "
+                                                    "fill and drain; a throughput figure (latency of a frame-set = the whole launch), "
+                                                    "NOT the headline value"}
+            with Leg(out, "pack_twin"):
+                # ---- the a2 twin, one launch per camera vs all cameras in one launch -----------------------------------------
+                for _ in range(20):
+                    launch_pack_batch()
                 torch.cuda.synchronize(dev)
-                ms_b = timed(launch_batch, max(50, n_leg // KB), ctx0) / KB
-                ach_b = set_points * ALGO_BYTES_PER_POINT / (ms_b * 1e-3) / 1e9
-                out["batched_dense"] = {"frame_sets_per_launch": KB, "ms_per_frame_set": round(ms_b, 5),
-                                        "value": round(set_points / ms_b / 1e3, 1), "achieved": round(ach_b, 1),
-                                        "frac": round(ach_b / HBM_PEAK_GBS, 4),
-                                        "note": "pcs_process_frames_device_batch: the same tiles, K frame-sets share one launch's "
-                                                "fill and drain; a throughput figure (latency of a frame-set = the whole launch), "
-                                                "NOT the headline value"}
-            # ---- the a2 twin, one launch per camera vs all cameras in one launch -----------------------------------------
-            for _ in range(20):
-                launch_pack_batch()
-            torch.cuda.synchronize(dev)
-            ms_pb = timed(launch_pack_batch, max(50, n_leg // 2), ctx0)
-            for _ in range(10):
-                launch_pack_single()
-            torch.cuda.synchronize(dev)
-            ms_ps = timed(launch_pack_single, max(30, n_leg // 4), ctx0)
-            out["pack_twin"] = {"batched_ms_per_frame_set": round(ms_pb, 5),
-                                "batched_achieved": round(set_points * PACK_BYTES_PER_POINT / (ms_pb * 1e-3) / 1e9, 1),
-                                "batched_frac": round(set_points * PACK_BYTES_PER_POINT / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "per_stream_launches_ms_per_frame_set": round(ms_ps, 5),
-                                "per_stream_launches_frac": round(set_points * PACK_BYTES_PER_POINT / (ms_ps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "algorithmic_bytes_per_point": PACK_BYTES_PER_POINT, "ring_frame_sets": pack_ring["R"],
-                                "note": "copyPointCloudXYZRGBToBufferSIMD's twin on device-resident rs2::points arrays "
-                                        "(12 B vertex + 8 B texcoord + 3 B RGB in, 10 B out): pcs_copy_pointclouds_xyzrgb_to_buffer_device "
-                                        "(one launch for all cameras) vs pcs_copy_pointcloud_xyzrgb_to_buffer_device per camera"}
+                ms_pb = timed(launch_pack_batch, max(50, n_leg // 2), ctx0)
+                for _ in range(10):
+                    launch_pack_single()
+                torch.cuda.synchronize(dev)
+                ms_ps = timed(launch_pack_single, max(30, n_leg // 4), ctx0)
+                out["pack_twin"] = {"batched_ms_per_frame_set": round(ms_pb, 5),
+                                    "batched_achieved": round(set_points * PACK_BYTES_PER_POINT / (ms_pb * 1e-3) / 1e9, 1),
+                                    "batched_frac": round(set_points * PACK_BYTES_PER_POINT / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "per_stream_launches_ms_per_frame_set": round(ms_ps, 5),
+                                    "per_stream_launches_frac": round(set_points * PACK_BYTES_PER_POINT / (ms_ps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "algorithmic_bytes_per_point": PACK_BYTES_PER_POINT, "ring_frame_sets": pack_ring["R"],
+                                    "note": "copyPointCloudXYZRGBToBufferSIMD's twin on device-resident rs2::points arrays "
+                                            "(12 B vertex + 8 B texcoord + 3 B RGB in, 10 B out): pcs_copy_pointclouds_xyzrgb_to_buffer_device "
+                                            "(one launch for all cameras) vs pcs_copy_pointcloud_xyzrgb_to_buffer_device per camera"}
         if extra and not args.no_config5:
-            # ---- BASELINE configs[4] on ONE GPU: 16 x 1920x1080 -> invalid-depth compaction -> camera-order stitch -> voxel
-            # grid of the stitched cloud, device-resident and asynchronous (the voxel grid reads the kept total from the
-            # device); 4 input sets (664 MB) so that the rasters come from HBM
-            W5, H5, S5, LEAF = 1920, 1080, 16, 50
-            cfg5 = [Syn.synth_stream_config(W5, H5, s) for s in range(S5)]
-            ctx5 = PcsContext(cfg5, device=local_rank, flags=FLAG_DROP_INVALID)
-            ctx5.set_stream(stream.cuda_stream)
-            n5 = W5 * H5
-            dep5 = [torch.from_numpy(Syn.synth_depth(W5, H5, s).reshape(-1).view(np.uint8)).to(dev) for s in range(S5)]
-            col5 = [torch.from_numpy(Syn.synth_color(W5, H5, s)).to(dev) for s in range(S5)]
-            sets5 = [(dep5, col5)] + [([d.clone() for d in dep5], [c.clone() for c in col5]) for _ in range(3)]
-            pay5 = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
-            vox5 = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
-            cnt5 = torch.zeros(S5 + 1, dtype=torch.int32, device=dev)
-            nv5 = torch.zeros(1, dtype=torch.int32, device=dev)
-            args5 = [((VP * S5)(*[t.data_ptr() for t in d]), (VP * S5)(*[t.data_ptr() for t in c])) for d, c in sets5]
-            k5 = [0]
+            with Leg(out, "config5_one_gpu"):
+                # ---- BASELINE configs[4] on ONE GPU: 16 x 1920x1080 -> invalid-depth compaction -> camera-order stitch -> voxel
+                # grid of the stitched cloud, device-resident and asynchronous (the voxel grid reads the kept total from the
+                # device); 4 input sets (664 MB) so that the rasters come from HBM
+                W5, H5, S5, LEAF = 1920, 1080, 16, 50
+                cfg5 = [Syn.synth_stream_config(W5, H5, s) for s in range(S5)]
+                ctx5 = PcsContext(cfg5, device=local_rank, flags=FLAG_DROP_INVALID)
+                ctx5.set_stream(stream.cuda_stream)
+                n5 = W5 * H5
+                dep5 = [torch.from_numpy(Syn.synth_depth(W5, H5, s).reshape(-1).view(np.uint8)).to(dev) for s in range(S5)]
+                col5 = [torch.from_numpy(Syn.synth_color(W5, H5, s)).to(dev) for s in range(S5)]
+                sets5 = [(dep5, col5)] + [([d.clone() for d in dep5], [c.clone() for c in col5]) for _ in range(3)]
+                pay5 = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
+                vox5 = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
+                cnt5 = torch.zeros(S5 + 1, dtype=torch.int32, device=dev)
+                nv5 = torch.zeros(1, dtype=torch.int32, device=dev)
+                args5 = [((VP * S5)(*[t.data_ptr() for t in d]), (VP * S5)(*[t.data_ptr() for t in c])) for d, c in sets5]
+                k5 = [0]
 
-            def compact5():
-                dp, cp = args5[k5[0] % 4]; k5[0] += 1
-                check(lib.pcs_process_frames_device(ctx5._h, dp, cp, VP(pay5.data_ptr()), pay5.numel(), VP(cnt5.data_ptr())), ctx5._h)
+                def compact5():
+                    dp, cp = args5[k5[0] % 4]; k5[0] += 1
+                    check(lib.pcs_process_frames_device(ctx5._h, dp, cp, VP(pay5.data_ptr()), pay5.numel(), VP(cnt5.data_ptr())), ctx5._h)
 
-            def voxel5():
-                check(lib.pcs_voxel_grid_device_counted(ctx5._h, VP(pay5.data_ptr()), VP(cnt5.data_ptr() + 4 * S5), S5 * n5, LEAF,
-                                                        VP(vox5.data_ptr()), vox5.numel(), VP(nv5.data_ptr())), ctx5._h)
+                def voxel5():
+                    check(lib.pcs_voxel_grid_device_counted(ctx5._h, VP(pay5.data_ptr()), VP(cnt5.data_ptr() + 4 * S5), S5 * n5, LEAF,
+                                                            VP(vox5.data_ptr()), vox5.numel(), VP(nv5.data_ptr())), ctx5._h)
 
-            def both5():
-                compact5(); voxel5()
-            for _ in range(3):
-                both5()
-            torch.cuda.synchronize(dev)
-            ms_c5 = timed(compact5, 30, ctx5)
-            ms_v5 = timed(voxel5, 30, ctx5)
-            ms_b5 = timed(both5, 30, ctx5)
-            kept5, nvox5 = int(cnt5[S5].item()), int(nv5.item())
-            out["config5_one_gpu"] = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
-                                      "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
-                                      "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
-                                      "pipeline_ms_per_frame_set": round(ms_b5, 4),
-                                      "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
-                                      "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                      "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
-                                              "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}
-            ctx5.close()
-            del dep5, col5, sets5, pay5, vox5
+                def both5():
+                    compact5(); voxel5()
+                for _ in range(3):
+                    both5()
+                torch.cuda.synchronize(dev)
+                ms_c5 = timed(compact5, 30, ctx5)
+                ms_v5 = timed(voxel5, 30, ctx5)
+                ms_b5 = timed(both5, 30, ctx5)
+                kept5, nvox5 = int(cnt5[S5].item()), int(nv5.item())
+                out["config5_one_gpu"] = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
+                                          "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
+                                          "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
+                                          "pipeline_ms_per_frame_set": round(ms_b5, 4),
+                                          "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
+                                          "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
+                                                  "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}
+                ctx5.close()
+                del dep5, col5, sets5, pay5, vox5
         if extra and not args.no_cache_leg and R > 6:
-            # Informational: the same launches on a ring of 6 frame-sets, whose input rasters (221 MB for 8 x 720p) fit the
-            # 256 MiB Infinity Cache — what the kernel reads when its inputs were produced or touched on the GPU just
-            # before (and what an under-sized ring silently measures). NOT an HBM figure, NOT `value`.
-            def launch6():
-                dp, cp, outp = call_args[next_slot(6)]
-                check(lib.pcs_process_frames_device(h, dp, cp, outp, payload_shorts, None))
-            for _ in range(600):
-                launch6()
-            torch.cuda.synchronize(dev)
-            ms_c6 = timed(launch6, max(400, args.steps))
-            out["infinity_cache_resident_inputs"] = {
-                "ms_per_step": round(ms_c6, 5), "value": round(set_points / ms_c6 / 1e3, 1),
-                "algorithmic_GBps": round(set_points * ALGO_BYTES_PER_POINT / (ms_c6 * 1e-3) / 1e9, 1),
-                "ring_frame_sets": 6, "input_mbytes": round(6 * in_bytes_per_set / 1e6, 1),
-                "note": "inputs served by the 256 MiB Infinity Cache, payload written to HBM; informational, not a roofline fraction"}
+            with Leg(out, "infinity_cache_resident_inputs"):
+                # Informational: the same launches on a ring of 6 frame-sets, whose input rasters (221 MB for 8 x 720p) fit the
+                # 256 MiB Infinity Cache — what the kernel reads when its inputs were produced or touched on the GPU just
+                # before (and what an under-sized ring silently measures). NOT an HBM figure, NOT `value`.
+                def launch6():
+                    dp, cp, outp = call_args[next_slot(6)]
+                    check(lib.pcs_process_frames_device(h, dp, cp, outp, payload_shorts, None))
+                for _ in range(600):
+                    launch6()
+                torch.cuda.synchronize(dev)
+                ms_c6 = timed(launch6, max(400, args.steps))
+                out["infinity_cache_resident_inputs"] = {
+                    "ms_per_step": round(ms_c6, 5), "value": round(set_points / ms_c6 / 1e3, 1),
+                    "algorithmic_GBps": round(set_points * ALGO_BYTES_PER_POINT / (ms_c6 * 1e-3) / 1e9, 1),
+                    "ring_frame_sets": 6, "input_mbytes": round(6 * in_bytes_per_set / 1e6, 1),
+                    "note": "inputs served by the 256 MiB Infinity Cache, payload written to HBM; informational, not a roofline fraction"}
         if extra and not args.no_cache_leg:
-            # Informational: the same cold launches alternated over two HIP streams (two contexts), so the drain of
-            # launch k overlaps the fill of launch k+1 — what a throughput-oriented frame loop can sustain. It is NOT
-            # `value` and not what `roofline` prices (each individual kernel gets longer when two overlap).
-            ctx2 = PcsContext(cfgs, device=local_rank)           # its own non-blocking stream
-            flip = [0]
+            with Leg(out, "two_stream_overlap"):
+                # Informational: the same cold launches alternated over two HIP streams (two contexts), so the drain of
+                # launch k overlaps the fill of launch k+1 — what a throughput-oriented frame loop can sustain. It is NOT
+                # `value` and not what `roofline` prices (each individual kernel gets longer when two overlap).
+                ctx2 = PcsContext(cfgs, device=local_rank)           # its own non-blocking stream
+                flip = [0]
 
-            def launch2():
-                flip[0] ^= 1
-                launch_dense(ctx2._h if flip[0] else None)
-            for _ in range(400):
-                launch2()
-            torch.cuda.synchronize(dev); ctx2.synchronize()
-            k2 = max(800, args.steps)
-            t0o = time.perf_counter()
-            for _ in range(k2):
-                launch2()
-            torch.cuda.synchronize(dev); ctx2.synchronize()
-            ms_o = (time.perf_counter() - t0o) * 1e3 / k2
-            ctx2.close()
-            out["two_stream_overlap"] = {"ms_per_step": round(ms_o, 5), "value": round(set_points / ms_o / 1e3, 1),
-                                         "aggregate_GBps": round(set_points * ALGO_BYTES_PER_POINT / (ms_o * 1e-3) / 1e9, 1),
-                                         "aggregate_frac_of_peak": round(set_points * ALGO_BYTES_PER_POINT / (ms_o * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                         "note": "host clock; consecutive cold launches alternate over two HIP streams and overlap; "
-                                                 "informational (not the contract's value, not a per-kernel figure)"}
+                def launch2():
+                    flip[0] ^= 1
+                    launch_dense(ctx2._h if flip[0] else None)
+                for _ in range(400):
+                    launch2()
+                torch.cuda.synchronize(dev); ctx2.synchronize()
+                k2 = max(800, args.steps)
+                t0o = time.perf_counter()
+                for _ in range(k2):
+                    launch2()
+                torch.cuda.synchronize(dev); ctx2.synchronize()
+                ms_o = (time.perf_counter() - t0o) * 1e3 / k2
+                ctx2.close()
+                out["two_stream_overlap"] = {"ms_per_step": round(ms_o, 5), "value": round(set_points / ms_o / 1e3, 1),
+                                             "aggregate_GBps": round(set_points * ALGO_BYTES_PER_POINT / (ms_o * 1e-3) / 1e9, 1),
+                                             "aggregate_frac_of_peak": round(set_points * ALGO_BYTES_PER_POINT / (ms_o * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "note": "host clock; consecutive cold launches alternate over two HIP streams and overlap; "
+                                                     "informational (not the contract's value, not a per-kernel figure)"}
         if extra and not args.no_general_rotation:
-            # The synthetic configuration of SURVEY.md 8(d) has depth->colour R = I, which lets the kernel skip 15
-            # individually-rounded flops per pixel; real D400 units report a small rotation. Same rasters, same
-            # launch, R = 1 degree about a skewed axis:
-            import math
-            ang = math.radians(1.0)
-            ax = np.array([0.3, 0.9, 0.3]); ax /= np.linalg.norm(ax)
-            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
-            Rm = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
-            cfgs_r = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
-            for cfg_r in cfgs_r:
-                for k, v in enumerate(Rm.T.reshape(-1)):
-                    cfg_r.depth_to_color.rotation[k] = float(v)
-            ctx_r = PcsContext(cfgs_r, device=local_rank)
-            ctx_r.set_stream(stream.cuda_stream)
+            with Leg(out, "general_rotation"):
+                # The synthetic configuration of SURVEY.md 8(d) has depth->colour R = I, which lets the kernel skip 15
+                # individually-rounded flops per pixel; real D400 units report a small rotation. Same rasters, same
+                # launch, R = 1 degree about a skewed axis:
+                import math
+                ang = math.radians(1.0)
+                ax = np.array([0.3, 0.9, 0.3]); ax /= np.linalg.norm(ax)
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                Rm = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+                cfgs_r = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
+                for cfg_r in cfgs_r:
+                    for k, v in enumerate(Rm.T.reshape(-1)):
+                        cfg_r.depth_to_color.rotation[k] = float(v)
+                ctx_r = PcsContext(cfgs_r, device=local_rank)
+                ctx_r.set_stream(stream.cuda_stream)
 
-            def launch_r():
-                launch_dense(ctx_r._h)
-            preheat(launch_r, args.preheat_ms / 2)       # same clock settling as the headline leg
-            ms_r = timed(launch_r, max(400, args.steps), ctx_r)
-            ach_r = set_points * ALGO_BYTES_PER_POINT / (ms_r * 1e-3) / 1e9
-            out["general_rotation"] = {"ms_per_step": round(ms_r, 5), "value": round(set_points / ms_r / 1e3, 1),
-                                       "achieved": round(ach_r, 1), "frac": round(ach_r / HBM_PEAK_GBS, 4),
-                                       "arithmetic": POLICY[min(ctx_r.stream_math(s) for s in range(S))],
-                                       "note": "same rasters and launch with a 1-degree depth->colour rotation (what real cameras "
-                                               "report); the headline configuration has R = I per SURVEY.md 8(d)"}
-            ctx_r.close()
+                def launch_r():
+                    launch_dense(ctx_r._h)
+                preheat(launch_r, args.preheat_ms / 2)       # same clock settling as the headline leg
+                ms_r = timed(launch_r, max(400, args.steps), ctx_r)
+                ach_r = set_points * ALGO_BYTES_PER_POINT / (ms_r * 1e-3) / 1e9
+                out["general_rotation"] = {"ms_per_step": round(ms_r, 5), "value": round(set_points / ms_r / 1e3, 1),
+                                           "achieved": round(ach_r, 1), "frac": round(ach_r / HBM_PEAK_GBS, 4),
+                                           "arithmetic": POLICY[min(ctx_r.stream_math(s) for s in range(S))],
+                                           "note": "same rasters and launch with a 1-degree depth->colour rotation (what real cameras "
+                                                   "report); the headline configuration has R = I per SURVEY.md 8(d)"}
+                ctx_r.close()
         if world == 1 and args.mode in ("dense", "drop_invalid", "cutoff"):
-            # per-launch distribution (SURVEY.md 8d asks for median + min): a separate leg with a hipEvent pair
-            # around every launch, so the event records stay out of the timed region above
-            ctx.kernel_timing(True)
-            for _ in range(300):
-                launch()
-            per = np.sort(ctx.kernel_times_ms())       # synchronises the stream
-            ctx.kernel_timing(False)
-            if per.size:
-                out["roofline"]["per_launch_ms"] = {"n": int(per.size), "median": round(float(np.median(per)), 5),
-                                                    "min": round(float(per[0]), 5), "p95": round(float(per[int(per.size * 0.95)]), 5),
-                                                    "note": "one hipEvent pair per launch (includes event overhead); "
-                                                            "avg_launch_ms above is the contract figure"}
+            with Leg(out, "per_launch_ms"):
+                # per-launch distribution (SURVEY.md 8d asks for median + min): a separate leg with a hipEvent pair
+                # around every launch, so the event records stay out of the timed region above
+                ctx.kernel_timing(True)
+                for _ in range(300):
+                    launch()
+                per = np.sort(ctx.kernel_times_ms())       # synchronises the stream
+                ctx.kernel_timing(False)
+                if per.size:
+                    out["roofline"]["per_launch_ms"] = {"n": int(per.size), "median": round(float(np.median(per)), 5),
+                                                        "min": round(float(per[0]), 5), "p95": round(float(per[int(per.size * 0.95)]), 5),
+                                                        "note": "one hipEvent pair per launch (includes event overhead); "
+                                                                "avg_launch_ms above is the contract figure"}
         if world == 1 and args.mode == "dense" and not args.no_host_api:
-            # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
-            # pageable numpy memory like a caller of the reference's function would have. Never `value`.
-            def time_host(dep, col, outbuf, reps=5):
-                ctx.process_frames(dep, col, out=outbuf)
-                t0h = time.perf_counter()
-                for _ in range(reps):
+            with Leg(out, "host_api"):
+                # PCIe-inclusive: host pointers in, host buffer out (36.9 MB up + 73.7 MB down per frame-set),
+                # pageable numpy memory like a caller of the reference's function would have. Never `value`.
+                def time_host(dep, col, outbuf, reps=5):
                     ctx.process_frames(dep, col, out=outbuf)
-                return (time.perf_counter() - t0h) / reps
-            pg_out = np.zeros(2 + payload_shorts, np.int16)      # allocated and touched once, like the reference's buffer (:157)
-            th = time_host(host0[0], host0[1], pg_out)
-            pd = [ctx.host_array(d.shape, np.uint16) for d in host0[0]]
-            pc = [ctx.host_array(c.shape, np.uint8) for c in host0[1]]
-            for a, b in zip(pd + pc, host0[0] + host0[1]):
-                a[...] = b
-            po = ctx.host_array((2 + payload_shorts,), np.int16)
-            tp = time_host(pd, pc, po)
-            # software-pipelined loop (pcs_submit_frames / pcs_collect_frames): upload of k+1 overlaps download of k
-            po2 = ctx.host_array((2 + payload_shorts,), np.int16)
+                    t0h = time.perf_counter()
+                    for _ in range(reps):
+                        ctx.process_frames(dep, col, out=outbuf)
+                    return (time.perf_counter() - t0h) / reps
+                pg_out = np.zeros(2 + payload_shorts, np.int16)      # allocated and touched once, like the reference's buffer (:157)
+                th = time_host(host0[0], host0[1], pg_out)
+                pd = [ctx.host_array(d.shape, np.uint16) for d in host0[0]]
+                pc = [ctx.host_array(c.shape, np.uint8) for c in host0[1]]
+                for a, b in zip(pd + pc, host0[0] + host0[1]):
+                    a[...] = b
+                po = ctx.host_array((2 + payload_shorts,), np.int16)
+                tp = time_host(pd, pc, po)
+                # software-pipelined loop (pcs_submit_frames / pcs_collect_frames): upload of k+1 overlaps download of k
+                po2 = ctx.host_array((2 + payload_shorts,), np.int16)
 
-            def time_pipe(reps=8):
-                ta, tb = ctx.submit_frames(pd, pc), ctx.submit_frames(pd, pc)     # warm both slots
-                ctx.collect_frames(ta, po); ctx.collect_frames(tb, po2)
-                t0p = time.perf_counter()
-                t_prev = ctx.submit_frames(pd, pc)
-                for k in range(1, reps + 1):
-                    t_next = ctx.submit_frames(pd, pc) if k < reps else None
-                    ctx.collect_frames(t_prev, po if k & 1 else po2)
-                    t_prev = t_next
-                return (time.perf_counter() - t0p) / reps
-            tpipe = time_pipe()
-            # the two directions on their own (page-locked buffers), SURVEY.md 8d: "H2D/D2H reported separately"
-            d_tmp = ctx.device_malloc(payload_shorts * 2)
+                def time_pipe(reps=8):
+                    ta, tb = ctx.submit_frames(pd, pc), ctx.submit_frames(pd, pc)     # warm both slots
+                    ctx.collect_frames(ta, po); ctx.collect_frames(tb, po2)
+                    t0p = time.perf_counter()
+                    t_prev = ctx.submit_frames(pd, pc)
+                    for k in range(1, reps + 1):
+                        t_next = ctx.submit_frames(pd, pc) if k < reps else None
+                        ctx.collect_frames(t_prev, po if k & 1 else po2)
+                        t_prev = t_next
+                    return (time.perf_counter() - t0p) / reps
+                tpipe = time_pipe()
+                # the two directions on their own (page-locked buffers), SURVEY.md 8d: "H2D/D2H reported separately"
+                d_tmp = ctx.device_malloc(payload_shorts * 2)
 
-            def time_copy(fn, reps=5):
-                fn()
-                t0c = time.perf_counter()
-                for _ in range(reps):
+                def time_copy(fn, reps=5):
                     fn()
-                return (time.perf_counter() - t0c) / reps
-            up_bytes = sum(a.nbytes for a in pd + pc)
+                    t0c = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    return (time.perf_counter() - t0c) / reps
+                up_bytes = sum(a.nbytes for a in pd + pc)
 
-            def all_up():
-                o = 0
-                for a in pd + pc:
-                    ctx.memcpy_h2d(d_tmp + o, a); o += (a.nbytes + 255) & ~255
-            t_up = time_copy(all_up)
-            pay = po[2:]
-            t_dn = time_copy(lambda: ctx.memcpy_d2h(pay, d_tmp))
-            ctx.device_free(d_tmp)
-            out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
-                               "pinned_ms_per_step": round(tp * 1e3, 3), "pinned_value": round(set_points / tp / 1e6, 1),
-                               "pipelined_ms_per_step": round(tpipe * 1e3, 3), "pipelined_value": round(set_points / tpipe / 1e6, 1),
-                               "h2d_ms": round(t_up * 1e3, 3), "h2d_GBps": round(up_bytes / t_up / 1e9, 1),
-                               "d2h_ms": round(t_dn * 1e3, 3), "d2h_GBps": round(pay.nbytes / t_dn / 1e9, 1),
-                               "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous: H2D (36.9 MB) + kernel + D2H (73.7 MB) per "
-                               "frame-set, with long-lived pageable (numpy) buffers and with buffers from pcs_host_malloc; bounded by the host link, "
-                               "not by the kernel"}
+                def all_up():
+                    o = 0
+                    for a in pd + pc:
+                        ctx.memcpy_h2d(d_tmp + o, a); o += (a.nbytes + 255) & ~255
+                t_up = time_copy(all_up)
+                pay = po[2:]
+                t_dn = time_copy(lambda: ctx.memcpy_d2h(pay, d_tmp))
+                ctx.device_free(d_tmp)
+                out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
+                                   "pinned_ms_per_step": round(tp * 1e3, 3), "pinned_value": round(set_points / tp / 1e6, 1),
+                                   "pipelined_ms_per_step": round(tpipe * 1e3, 3), "pipelined_value": round(set_points / tpipe / 1e6, 1),
+                                   "h2d_ms": round(t_up * 1e3, 3), "h2d_GBps": round(up_bytes / t_up / 1e9, 1),
+                                   "d2h_ms": round(t_dn * 1e3, 3), "d2h_GBps": round(pay.nbytes / t_dn / 1e9, 1),
+                                   "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous: H2D (36.9 MB) + kernel + D2H (73.7 MB) per "
+                                   "frame-set, with long-lived pageable (numpy) buffers and with buffers from pcs_host_malloc; bounded by the host link, "
+                                   "not by the kernel"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
-            if args.mode == "dense":
-                out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            with Leg(out, "cpu_baseline"):
+                out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
+                if args.mode == "dense":
+                    out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 
     if ctx0 is not ctx:
