@@ -198,16 +198,17 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
                                         (unsigned int)dpp_from<0x138, 0xf>((int)key);       // wave_shr:1
         const unsigned long long next = ((unsigned long long)(unsigned int)dpp_from<0x130, 0xf>((int)(key >> 32)) << 32) |
                                         (unsigned int)dpp_from<0x130, 0xf>((int)key);       // wave_shl:1
-        // runs are merged inside a DPP row of 16 lanes only: a run that crosses a row border simply becomes two actors
-        // (one more table access) and the two row_bcast steps of a wavefront-wide segmented scan are not needed — a
-        // third of the merge, which is half of this VALU-bound kernel
-        a.head = ((lane & 15) == 0 || prev != key) ? 1 : 0;
+        // runs are merged inside aligned groups of 8 lanes only: a run that crosses a group border simply becomes several
+        // actors (a few more table accesses, to the same slot) and three row_shr steps replace the six of a wavefront-wide
+        // segmented scan — the merge was half of this VALU-bound kernel (50 mm: 188 us wavefront-wide, 158 us per row of
+        // 16, 149 us per group of 8; 200 mm: 137 / 118 / 111 us)
+        a.head = ((lane & 7) == 0 || prev != key) ? 1 : 0;
         bool actor = live;
         // merging pays when the wavefront holds few runs; with many (small leaves) the scan costs more than the
         // conflicts it avoids
-        const bool merge = __popcll(__ballot(a.head != 0)) <= 28;
+        const bool merge = __popcll(__ballot(a.head != 0)) <= 32;
         if (merge) {
-            actor = live && ((lane & 15) == 15 || next != key);  // last lane of its run within the row
+            actor = live && ((lane & 7) == 7 || next != key);  // last lane of its run within the group of 8
             // (Measured and dropped: a wave-uniform early exit once every lane's span holds its run's head — any branch
             // inside this unrolled loop stops the compiler from overlapping the eight iterations: 254 vs 188 us at 50 mm,
             // taken or not; and a split into a branch-free phase for all eight records followed by the table phase —
@@ -215,7 +216,6 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
             seg_step<0x111, 0xf>(a);                             // row_shr:1
             seg_step<0x112, 0xf>(a);                             // row_shr:2
             seg_step<0x114, 0xf>(a);                             // row_shr:4
-            seg_step<0x118, 0xf>(a);                             // row_shr:8
         }
         unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 53);       // 11 bits
         bool placed = false;
