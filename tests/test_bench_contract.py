@@ -90,3 +90,31 @@ def test_two_ranks_shard_the_eight_streams():
     assert d["config"]["parallelism"] == "streams sharded 4/GPU x 2" and d["config"]["streams_total"] == 8
     assert d["config"]["gather_to_rank0"] is True and "gather" in d
     assert abs(d["value"] - 8 * 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+def _load_bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_leg_guard_records_and_swallows_exceptions():
+    """A failing leg must not cost the line: the exception is recorded under leg_errors and the run goes on."""
+    b = _load_bench_module()
+    out = {}
+    with b.Leg(out, "broken"):
+        raise RuntimeError("boom")
+    with b.Leg(out, "fine"):
+        out["fine"] = 1
+    assert out["fine"] == 1 and "RuntimeError: boom" in out["leg_errors"]["broken"] and "fine" not in out["leg_errors"]
+    with pytest.raises(KeyboardInterrupt):          # not an Exception: must propagate
+        with b.Leg(out, "interrupted"):
+            raise KeyboardInterrupt
+
+
+def test_bench_reports_physical_cores():
+    b = _load_bench_module()
+    n = b._physical_cores()
+    assert n is None or (1 <= n <= (os.cpu_count() or 1))
