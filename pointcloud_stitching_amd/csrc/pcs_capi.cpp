@@ -312,6 +312,27 @@ bool row_magic(uint32_t W, uint32_t H, uint32_t& magic, uint32_t& shift)
     return true;
 }
 
+// -c (src/pcs-camera-optimized.cpp:398-401, 504-511) keeps 0 < z <= 1.5 && -2 < x <= 2 on the camera-frame vertex. The
+// count pass may evaluate it on the raw Z16 word if (a) z = fl(depth_scale * d) is positive exactly for d >= 1 and
+// monotone in d — then z <= 1.5f <=> d <= dmax, dmax found by bisection with the device's own float product — and
+// (b) the x test cannot fail while the z test holds: x = fl(z * mx[c]) with no depth distortion, so
+// |x| <= 1.5 * max|mx| * (1 + 2^-23) < 2 whenever 1.5 * max|mx| < 2 - 2^-10. Returns 0 if either cannot be shown.
+uint32_t cutoff_dmax(const pcs_stream_config& s, const StreamParams& p, const std::vector<float>& mx)
+{
+    if (!p.z_zero_iff_d_zero || p.ddist || !(s.depth_scale > 0.0f)) return 0;
+    double mxmax = 0;
+    for (float v : mx) { if (!std::isfinite(v)) return 0; mxmax = std::max(mxmax, std::fabs((double)v)); }
+    if (!(1.5 * mxmax < 2.0 - 1.0 / 1024.0)) return 0;
+    const volatile float scale = s.depth_scale;
+    auto z_of = [&](uint32_t d) { volatile float z = scale * (float)d; return (float)z; };      // one rounded product, as on the device
+    if (!(z_of(1) > 0.0f)) return 0;
+    for (uint32_t d = 1; d < 65535; d += 257) if (!(z_of(d) <= z_of(d + 1))) return 0;            // monotone (spot check; exact product of positives is)
+    uint32_t lo = 0, hi = 65535;                                                                     // largest d with z(d) <= 1.5
+    if (z_of(65535) <= 1.5f) return 65535;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (z_of(mid) <= 1.5f) lo = mid; else hi = mid; }
+    return lo;       // 0 if even d = 1 is beyond 1.5 m: nothing is in range; the general path handles it
+}
+
 inline uint32_t tiles_of(uint32_t n) { return (n + kTilePoints - 1) / kTilePoints; }
 inline bool has_pred(uint32_t flags) { return (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0; }
 
@@ -617,6 +638,7 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         p.no_overflow = certify_no_overflow(c->cfg[s], cert, c->cfg[s].cam_to_world) ? 1 : 0;
         c->cert.push_back(cert);
         row_magic((uint32_t)p.W, (uint32_t)p.H, p.w_magic, p.w_shift);
+        p.cut_dmax = cutoff_dmax(c->cfg[s], p, mx);
         float *dmx = nullptr, *dmy = nullptr;
         CREATE_CHK(hipMalloc((void**)&dmx, sizeof(float) * ((size_t)p.W + 8)));
         c->d_lut[2 * s] = dmx;

@@ -46,6 +46,7 @@ struct alignas(16) StreamParams {
     int32_t  ident_r;        // depth->colour rotation is exactly I, translation has no -0
     int32_t  no_overflow;    // certified: no converted value (world mm, colour column/row) can reach 2^31
     int32_t  z_zero_iff_d_zero; // depth_scale finite and depth_scale*1 != 0: (z == 0) == (d == 0)
+    uint32_t cut_dmax;       // -c from the Z16 word alone: in range <=> 1 <= d <= cut_dmax (0 = not certified, deproject)
     int32_t  tex_half;       // PCS_FLAG_TEXCOORD_HALF_PIXEL: u = (px + 0.5)/W (handled on the CDIST code path)
     const float* mx;         // [W]  (c - ppx) / fx   — IEEE division done once on the host
     const float* my;         // [H]  (r - ppy) / fy

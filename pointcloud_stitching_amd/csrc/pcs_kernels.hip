@@ -362,15 +362,12 @@ __device__ __forceinline__ bool in_range(float X, float Z)
 }
 
 // Keep mask for a lane's 8 consecutive points (point index i0 + k, i0 % 8 == 0).
-__device__ __forceinline__ uint32_t keep_mask8(const PointIn (&p)[8], uint32_t i0, uint32_t n, uint32_t flags)
+// Keep mask from the per-point predicate bits: rng = -c range test, nz = depth valid (bit k = point i0 + k).
+__device__ __forceinline__ uint32_t keep_from_bits(uint32_t rng, uint32_t nz, uint32_t i0, uint32_t n, uint32_t flags)
 {
-    uint32_t rng = 0, nz = 0, live = 0;
+    uint32_t live = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        rng  |= (uint32_t)in_range(p[k].X, p[k].Z) << k;
-        nz   |= (uint32_t)(p[k].Z != 0.0f) << k;
-        live |= (uint32_t)(i0 + k < n) << k;
-    }
+    for (int k = 0; k < 8; k++) live |= (uint32_t)(i0 + k < n) << k;
     uint32_t keep = live;
     if (flags & PCS_FLAG_CUTOFF) {
         uint32_t gate = rng;
@@ -389,6 +386,18 @@ __device__ __forceinline__ uint32_t keep_mask8(const PointIn (&p)[8], uint32_t i
     }
     if (flags & PCS_FLAG_DROP_INVALID) keep &= nz;
     return keep;
+}
+
+// Keep mask for a lane's 8 consecutive points (point index i0 + k, i0 % 8 == 0).
+__device__ __forceinline__ uint32_t keep_mask8(const PointIn (&p)[8], uint32_t i0, uint32_t n, uint32_t flags)
+{
+    uint32_t rng = 0, nz = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        rng |= (uint32_t)in_range(p[k].X, p[k].Z) << k;
+        nz  |= (uint32_t)(p[k].Z != 0.0f) << k;
+    }
+    return keep_from_bits(rng, nz, i0, n, flags);
 }
 
 // Wavefront-wide inclusive prefix sum (64 lanes, all active) by DPP: four row_shr steps scan each row of 16 lanes,
@@ -926,9 +935,15 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
     if (tile_first * kTilePoints >= n) return;
     uint32_t c[kCountTiles];
     const uint16_t* __restrict__ dp = fp.depth[s];
-    if ((flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) == PCS_FLAG_DROP_INVALID && P.z_zero_iff_d_zero) {
-        // z = depth_scale * d is zero exactly when d is (the host checked the scale: finite, and scale*1 != 0):
-        // count the non-zero Z16 values, no deprojection needed
+    const bool cut = (flags & PCS_FLAG_CUTOFF) != 0;
+    if (P.z_zero_iff_d_zero && (!cut || P.cut_dmax != 0u)) {
+        // The predicate from the Z16 words alone, no deprojection:
+        //  * z = depth_scale * d is zero exactly when d is (the host checked the scale: finite, and scale*1 != 0);
+        //  * -c (:504-511) keeps 0 < z <= 1.5 and -2 < x <= 2. z is monotone in d, so the z test is 1 <= d <= cut_dmax
+        //    (the host found the largest d with fl(depth_scale * d) <= 1.5f), and cut_dmax is only non-zero when the host
+        //    has also shown that |x| = |fl(z * mx)| < 2 for every column whenever z <= 1.5 (no depth distortion,
+        //    1.5 * max|mx| < 2 with slack) — true for any lens narrower than 106 degrees.
+        const uint32_t dmax = cut ? P.cut_dmax : 0xFFFFu;
         uint4 dv[kCountTiles];
         const bool aligned = ((uintptr_t)dp & 15) == 0;
 #pragma unroll
@@ -940,12 +955,19 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
 #pragma unroll
         for (int q = 0; q < kCountTiles; q++) {
             const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
-            const uint32_t dw[4] = {dv[q].x, dv[q].y, dv[q].z, dv[q].w};
-            c[q] = 0;
+            uint32_t dw[4] = {dv[q].x, dv[q].y, dv[q].z, dv[q].w};
+            if (!(aligned && i0 + 8 <= n)) {            // ragged end / unaligned raster: gather the halfwords one by one
+                dw[0] = dw[1] = dw[2] = dw[3] = 0u;
+                for (uint32_t k = 0; k < 8 && i0 + k < n; k++) dw[k >> 1] |= (uint32_t)dp[i0 + k] << ((k & 1u) * 16u);
+            }
+            uint32_t rng = 0, nz = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) c[q] += ((dw[k] & 0xFFFFu) != 0u) + ((dw[k] >> 16) != 0u);
-            if (!(aligned && i0 + 8 <= n))
-                for (uint32_t k = 0; k < 8 && i0 + k < n; k++) c[q] += dp[i0 + k] != 0;
+            for (int k = 0; k < 8; k++) {
+                const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+                nz  |= (uint32_t)(d != 0u) << k;
+                rng |= (uint32_t)(d != 0u && d <= dmax) << k;
+            }
+            c[q] = __popc(keep_from_bits(rng, nz, i0, n, flags));
         }
     } else {
         DepthSource<DDIST, CDIST> src{dp};

@@ -816,3 +816,25 @@ def test_batched_pack_with_cutoff_runs_cloud_by_cloud(oracle):
             if want.size:
                 ctx.memcpy_d2h(got, outs[i])
             assert_same(got.reshape(-1, 5), want)
+
+
+@pytest.mark.parametrize("flags", [FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT | FLAG_DROP_INVALID])
+@pytest.mark.parametrize("fx", [100.0, 448.0])
+def test_cutoff_count_from_depth_words_and_its_refusal(oracle, flags, fx, compaction_path):
+    """-c on the count pass: with a narrow lens (fx 448: 1.5 * max|mx| < 2) the host certifies that the x test cannot
+    fail inside the z range and the count pass tests the raw Z16 word against a precomputed d_max; with a 145-degree lens
+    (fx 100) the x test rejects points at the image border and the count pass must deproject. Depths straddle 1.5 m
+    (d = 1499..1502 at scale 0.001) so the d_max boundary itself is exercised."""
+    w, h = 640, 480
+    it = make_intrinsics(w, h, fx, fx, w / 2 - 0.5, h / 2 - 0.5)
+    cfgs = [make_stream_config(it, it, cam_to_world=TRANSFORMS[s]) for s in range(2)]
+    rng = np.random.default_rng(int(fx))
+    depth = [rng.integers(0, 3000, (h, w)).astype(np.uint16) for _ in range(2)]
+    for d in depth:
+        d[::7, ::3] = rng.integers(1497, 1504, d[::7, ::3].shape)
+        d[5:40, :] = 0
+    color = [S.synth_color(w, h, s) for s in range(2)]
+    got, counts = run_fused(cfgs, depth, color, flags)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags)
+    assert counts == wcounts and 0 < sum(counts) < 2 * w * h
+    assert_same(got, want)
