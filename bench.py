@@ -637,6 +637,20 @@ def main():
                                      "path": os.environ.get("PCS_COMPACT_PATH", "three (default: count + scan + emit)"),
                                      "note": "PCS_FLAG_DROP_INVALID, order-preserving (= the reference's -c -m -t1 order), same cold ring; "
                                              "bytes = 2 (Z16) + 3 (RGB8) + 10*rho (records)"}
+                if KB >= 2:
+                    # K frame-sets per call: three launches (count, scan, emit) for all K sets, nothing order-dependent
+                    def launch_cb():
+                        dp, cp, pp = batch_args[next_slot(len(batch_args))]
+                        check(lib.pcs_process_frames_device_batch(ctx_c._h, KB, dp, cp, pp, payload_shorts, None), ctx_c._h)
+                    for _ in range(30):
+                        launch_cb()
+                    torch.cuda.synchronize(dev)
+                    ms_cb = timed(launch_cb, max(50, n_leg // KB), ctx_c) / KB
+                    ach_cb = set_points * (5 + 10 * rho) / (ms_cb * 1e-3) / 1e9
+                    out["compaction"]["batched"] = {"frame_sets_per_call": KB, "ms_per_frame_set": round(ms_cb, 5),
+                                                    "achieved": round(ach_cb, 1), "frac": round(ach_cb / HBM_PEAK_GBS, 4),
+                                                    "note": "pcs_process_frames_device_batch with the predicate: count, scan and emit "
+                                                            "launches shared by K frame-sets (throughput form)"}
                 ctx_c.close()
                 if "PCS_COMPACT_PATH" not in os.environ:
                     # the opt-in one-launch kernel (its forward progress assumes in-order workgroup dispatch; bounded waits and a

@@ -43,6 +43,9 @@ struct pcs_ctx {
     uint32_t*                       d_arrive = nullptr;        // scan arrival counter (self-resetting)
     int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
     int32_t*                        d_static_counts = nullptr; // n_streams + 1: ceil(n/downsample) per stream, total
+    // batched compaction scratch (pcs_process_frames_device_batch with a predicate): one slab, rows per frame-set
+    uint32_t*                       d_batch_scratch = nullptr;
+    int                             batch_scratch_sets = 0;
     // single-pass compaction state (pcs_fused_compact_kernel)
     unsigned long long*             d_ticket = nullptr;        // never reset
     unsigned long long              tickets_issued = 0;
@@ -754,7 +757,7 @@ void pcs_destroy(pcs_ctx* c)
     }
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->d_batch_scratch, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1003,6 +1006,55 @@ try {
     DeviceGuard guard(c->device);
     const int per_launch = std::min(kBatchSets, kBatchEntries / S);
     const bool dense = !has_pred(c->flags) && c->downsample == 1 && c->dense_ok && aligned && per_launch >= 2;
+    if (has_pred(c->flags) && c->downsample == 1 && per_launch >= 2 && S <= kLaunchStreams) {
+        // Ordered compaction of K frame-sets with THREE launches for all of them: count (grid.z = set), scan
+        // (one workgroup per stream and set), emit (grid.z = set). Same kernels' tile code as the one-set path,
+        // the same bytes; no in-launch handoff between tiles, so nothing depends on dispatch order.
+        if (payload_shorts < c->max_payload_points * PCS_POINT_SHORTS)
+            return fail(c, PCS_ERR_CAPACITY, "payload buffers hold %zu shorts; with compaction the worst case %zu is required",
+                        payload_shorts, c->max_payload_points * PCS_POINT_SHORTS);
+        const size_t tt = std::max<uint32_t>(c->total_tiles, 1);
+        const size_t row = 2 * tt + (size_t)S + (size_t)(S + 1);      // counts, prefixes, kept per stream, counts out
+        if (c->batch_scratch_sets < per_launch) {
+            if (c->d_batch_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_batch_scratch); c->d_batch_scratch = nullptr; }
+            c->batch_scratch_sets = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_batch_scratch, sizeof(uint32_t) * row * per_launch));
+            c->batch_scratch_sets = per_launch;
+        }
+        uint32_t* tcounts = c->d_batch_scratch;
+        uint32_t* tprefix = tcounts + tt * per_launch;
+        uint32_t* kept    = tprefix + tt * per_launch;
+        int32_t*  icounts = reinterpret_cast<int32_t*>(kept + (size_t)S * per_launch);
+        bool fast = true, ident = true;
+        for (int s = 0; s < S; s++) { fast &= c->h_params[s].cert_fast != 0; ident &= c->h_params[s].ident_r != 0; }
+        const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
+        std::pair<hipEvent_t, hipEvent_t> ev{};
+        if (c->kernel_timing) {
+            int rc = acquire_event_pair(c, ev);
+            if (rc) return rc;
+            HIPCHK(c, hipEventRecord(ev.first, c->stream));
+        }
+        for (int k0 = 0; k0 < n_sets; k0 += per_launch) {
+            const int nk = std::min(per_launch, n_sets - k0);
+            BatchPtrs bp{};
+            BatchCounts bc{};
+            for (int k = 0; k < nk; k++) {
+                bp.payload[k] = reinterpret_cast<uint8_t*>(d_payload[k0 + k]);
+                bc.counts[k] = (d_counts && d_counts[k0 + k]) ? d_counts[k0 + k] : icounts + (size_t)k * (S + 1);
+                for (int s = 0; s < S; s++) {
+                    bp.depth[k * S + s] = d_depth[(size_t)(k0 + k) * S + s];
+                    bp.color[k * S + s] = d_color[(size_t)(k0 + k) * S + s];
+                }
+            }
+            HIPCHK(c, launch_compact_batch(c->d_params, S, nk, c->max_points, c->total_tiles, c->flags, sel, bp, bc,
+                                           tcounts, tprefix, kept, c->stream));
+        }
+        if (c->kernel_timing) {
+            HIPCHK(c, hipEventRecord(ev.second, c->stream));
+            c->ev_pool.push_back(ev);
+        }
+        return PCS_OK;
+    }
     if (!dense) {
         for (int k = 0; k < n_sets; k++) {
             int rc = run_fused_device(c, d_depth + (size_t)k * S, d_color + (size_t)k * S, d_payload[k], payload_shorts,

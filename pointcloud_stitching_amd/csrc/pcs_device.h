@@ -75,6 +75,10 @@ struct BatchPtrs {
     const uint8_t*  color[kBatchEntries];
     uint8_t*        payload[kBatchSets];                               // payload base of frame-set z
 };
+// Where the per-stream counts [S] and the total [S] of frame-set z go (batched compaction).
+struct BatchCounts {
+    int32_t* counts[kBatchSets];
+};
 
 // Batched a2 twin: several cameras' rs2::points arrays in ONE launch (blockIdx.y = cloud).
 constexpr int kPackBatch = 16;
@@ -131,6 +135,12 @@ hipError_t launch_fused_compact(const StreamParams* d_params, int stream0, int n
 // K frame-sets per launch (dense path only).
 hipError_t launch_fused_dense_batch(const StreamParams* d_params, int n_streams, int n_sets, uint32_t max_points,
                                     bool any_ddist, bool any_cdist, MathSel math, const BatchPtrs& bp, hipStream_t st);
+// K frame-sets per launch, ordered compaction (stride 1): count, scan and emit each cover all K sets.
+// d_tile_counts / d_tile_prefix hold n_sets * total_tiles words, d_stream_kept n_sets * n_streams.
+hipError_t launch_compact_batch(const StreamParams* d_params, int n_streams, int n_sets, uint32_t max_points,
+                                uint32_t total_tiles, uint32_t flags, MathSel math, const BatchPtrs& bp,
+                                const BatchCounts& bc, uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
+                                uint32_t* d_stream_kept, hipStream_t st);
 hipError_t launch_verify_div_const(float c, float rc, int32_t dim, unsigned long long* d_bad, hipStream_t st);
 
 // a2 twin.

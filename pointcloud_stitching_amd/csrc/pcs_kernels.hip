@@ -923,18 +923,13 @@ void pcs_fused_dense_batch_kernel(const StreamParams* __restrict__ params, Batch
 // 5.1 us for the 14.7 MB of 8 x 720p: latency, not bandwidth).
 constexpr int kCountTiles = 4;
 template <bool DDIST, bool CDIST>
-__global__ __launch_bounds__(kBlockThreads)
-void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
-                            uint32_t* __restrict__ tile_counts)
+__device__ __forceinline__ void count_tiles(const StreamParams& P, const uint16_t* __restrict__ dp, uint32_t flags,
+                                            uint32_t* __restrict__ tile_counts, uint32_t (*wsum)[4])
 {
-    __shared__ uint32_t wsum[kCountTiles][4];
-    const int s = blockIdx.y;
-    const StreamParams& P = params[stream0 + s];
     const uint32_t n = P.n_points;
     const uint32_t tile_first = blockIdx.x * kCountTiles;
     if (tile_first * kTilePoints >= n) return;
     uint32_t c[kCountTiles];
-    const uint16_t* __restrict__ dp = fp.depth[s];
     const bool cut = (flags & PCS_FLAG_CUTOFF) != 0;
     if (P.z_zero_iff_d_zero && (!cut || P.cut_dmax != 0u)) {
         // The predicate from the Z16 words alone, no deprojection:
@@ -945,12 +940,18 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
         //    1.5 * max|mx| < 2 with slack) — true for any lens narrower than 106 degrees.
         const uint32_t dmax = cut ? P.cut_dmax : 0xFFFFu;
         uint4 dv[kCountTiles];
-        const bool aligned = ((uintptr_t)dp & 15) == 0;
+        const bool aligned = ((uintptr_t)dp & 15) == 0 && n >= 8;      // uniform over the launch
+        if (aligned) {
+            // branch-free: a lane past the end re-reads the stream's first 16 bytes (and gathers below), so the four
+            // loads are issued back to back with no wait between them
 #pragma unroll
-        for (int q = 0; q < kCountTiles; q++) {
-            const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
-            dv[q] = make_uint4(0, 0, 0, 0);
-            if (aligned && i0 + 8 <= n) dv[q] = *reinterpret_cast<const uint4*>(dp + i0);
+            for (int q = 0; q < kCountTiles; q++) {
+                const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
+                dv[q] = *reinterpret_cast<const uint4*>(dp + ((i0 + 8 <= n) ? i0 : 0u));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kCountTiles; q++) dv[q] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < kCountTiles; q++) {
@@ -990,6 +991,28 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
             wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
 }
 
+template <bool DDIST, bool CDIST>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
+                            uint32_t* __restrict__ tile_counts)
+{
+    __shared__ uint32_t wsum[kCountTiles][4];
+    const int s = blockIdx.y;
+    count_tiles<DDIST, CDIST>(params[stream0 + s], fp.depth[s], flags, tile_counts, wsum);
+}
+
+// K frame-sets: blockIdx.z = frame-set, its tile counts at tile_counts + z * total_tiles.
+template <bool DDIST, bool CDIST>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_fused_count_batch_kernel(const StreamParams* __restrict__ params, BatchPtrs bp, uint32_t flags,
+                                  uint32_t* __restrict__ tile_counts, uint32_t total_tiles)
+{
+    __shared__ uint32_t wsum[kCountTiles][4];
+    const int s = blockIdx.y;
+    count_tiles<DDIST, CDIST>(params[s], bp.depth[blockIdx.z * gridDim.y + s], flags,
+                              tile_counts + (size_t)blockIdx.z * total_tiles, wsum);
+}
+
 // (Placing the emit tiles straight from per-chunk totals of the count pass — no scan launch, four extra L2-resident loads
 // per lane riding on the tile's existing barrier — was built and measured: 32.4 vs 32.5 us on 8 x 720p and 127 vs 107 us
 // on 16 x 1080p. Whatever the scan launch costs, extra memory instructions in the emit tile cost at least as much.)
@@ -1023,6 +1046,35 @@ void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0,
     }
     generic_tile<DepthSource<true, true, Mth>, PRED, DS1>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
                                                   payload_bytes, stage, wsum, nullptr);
+}
+
+// K frame-sets of ordered compaction (stride 1): blockIdx.z = frame-set. Prefixes at tile_prefix + z * total_tiles, the
+// per-stream kept totals at stream_kept + z * S; frame-set z's total is written by its first workgroup.
+template <class Mth>
+__global__ __launch_bounds__(kBlockThreads, 6)
+void pcs_fused_emit_batch_kernel(const StreamParams* __restrict__ params, BatchPtrs bp, uint32_t flags,
+                                 const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ stream_kept,
+                                 uint32_t total_tiles, BatchCounts bc)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
+    __shared__ uint32_t wsum[4];
+    const int s = blockIdx.y, S = gridDim.y, z = blockIdx.z;
+    const uint32_t* __restrict__ kept = stream_kept + z * S;
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int e = 0; e < S; e++) tot += kept[e];
+        bc.counts[z][S] = (int32_t)tot;
+    }
+    const StreamParams& P = params[s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n) return;
+    DepthSource<true, true, Mth> src{bp.depth[z * S + s]};
+    const uint32_t g0 = tile_prefix[(size_t)z * total_tiles + P.tile_base + blockIdx.x];
+    uint32_t out_first = 0;
+    for (int e = 0; e < s; e++) out_first += kept[e];
+    generic_tile<DepthSource<true, true, Mth>, true, true>(P, src, bp.color[z * S + s], tile0, n, flags, 1u, g0, out_first,
+                                                           bp.payload[z], stage, wsum, nullptr);
 }
 
 // Exclusive scan of the tile counts, one workgroup of 1024 lanes PER STREAM (streams scan concurrently).
@@ -1077,6 +1129,41 @@ void pcs_scan_kernel(const StreamParams* __restrict__ params, int stream0, int n
                 __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             }
         }
+    }
+}
+
+// The scan of K frame-sets: blockIdx.x = stream, blockIdx.y = frame-set (stride 1, no grand-total atomic: the emit
+// launch that follows adds the totals).
+__global__ __launch_bounds__(1024)
+void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32_t* __restrict__ tile_counts,
+                           uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ stream_kept, uint32_t total_tiles,
+                           BatchCounts bc)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    const int s = blockIdx.x, z = blockIdx.y;
+    const uint32_t n = params[s].n_points;
+    const uint32_t tiles = (n + kTilePoints - 1) / kTilePoints;
+    const size_t tb = (size_t)z * total_tiles + params[s].tile_base;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t c = (t < tiles) ? tile_counts[tb + t] : 0u;
+        uint32_t wave_total;
+        const uint32_t ex = wave_exclusive_scan(c, wave_total);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = wave_total;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wtot[w];
+        if (t < tiles) tile_prefix[tb + t] = before + ex;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + ex + c;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stream_kept[z * gridDim.x + s] = carry_s;
+        bc.counts[z][s] = (int32_t)carry_s;
     }
 }
 
@@ -1340,6 +1427,28 @@ hipError_t launch_fused_dense_batch(const StreamParams* d_params, int n_streams,
         if (any_ddist) { if (any_cdist) L(true, true, IeeeMath); else L(true, false, IeeeMath); }
         else           { if (any_cdist) L(false, true, IeeeMath); else L(false, false, IeeeMath); }
     }
+#undef L
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_batch(const StreamParams* d_params, int n_streams, int n_sets, uint32_t max_points,
+                                uint32_t total_tiles, uint32_t flags, MathSel math, const BatchPtrs& bp,
+                                const BatchCounts& bc, uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
+                                uint32_t* d_stream_kept, hipStream_t st)
+{
+    if (n_streams <= 0 || n_sets <= 0 || max_points == 0) return hipSuccess;
+    if (n_streams * n_sets > kBatchEntries || n_sets > kBatchSets) return hipErrorInvalidValue;
+    const uint32_t tiles = (max_points + kTilePoints - 1) / kTilePoints;
+    hipLaunchKernelGGL((pcs_fused_count_batch_kernel<true, false>),
+                       dim3((tiles + kCountTiles - 1) / kCountTiles, (unsigned)n_streams, (unsigned)n_sets),
+                       dim3(kBlockThreads), 0, st, d_params, bp, flags, d_tile_counts, total_tiles);
+    hipLaunchKernelGGL(pcs_scan_batch_kernel, dim3((unsigned)n_streams, (unsigned)n_sets), dim3(1024), 0, st, d_params,
+                       d_tile_counts, d_tile_prefix, d_stream_kept, total_tiles, bc);
+    const dim3 grid(tiles, (unsigned)n_streams, (unsigned)n_sets);
+#define L(M) hipLaunchKernelGGL((pcs_fused_emit_batch_kernel<M>), grid, dim3(kBlockThreads), 0, st, d_params, bp, flags, \
+                                d_tile_prefix, d_stream_kept, total_tiles, bc)
+    const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
+    if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
 #undef L
     return hipGetLastError();
 }

@@ -764,6 +764,60 @@ def test_batch_of_frame_sets_non_dense_configurations(oracle, flags, skew):
             assert_same(got.reshape(-1, 5), want)
 
 
+@pytest.mark.parametrize("flags", [FLAG_DROP_INVALID, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT,
+                                   FLAG_CUTOFF | FLAG_DROP_INVALID])
+@pytest.mark.parametrize("shapes,n_sets,skew", [([(640, 480)] * 3, 5, 0), ([(1280, 720), (321, 243), (64, 48), (640, 480)], 18, 2),
+                                                ([(160, 120)] * 16, 5, 0)])
+def test_batched_compaction_equals_the_oracle(oracle, flags, shapes, n_sets, skew):
+    """pcs_process_frames_device_batch with a predicate: count, scan and emit each cover every frame-set of the launch
+    (grid.z = set). Every set's payload and counts equal the oracle's; 4 streams x 18 sets = two launches of <= 16 sets;
+    16 streams x 5 sets = launches of 4 sets; ragged rasters, payloads 2-byte aligned only, some sets without a counts
+    pointer."""
+    n = len(shapes)
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 31 * k) for s, (w, h) in enumerate(shapes)],
+             [S.synth_color(w, h, s, seed=S.SEED + 31 * k) for s, (w, h) in enumerate(shapes)]) for k in range(n_sets)]
+    sets[1][0][0][:] = 0                                     # a stream with nothing kept
+    if n_sets > 2:
+        for d in sets[2][0]:
+            d[:] = 0                                         # a whole frame-set with nothing kept
+    n_sh = sum(c.n_points for c in cfgs) * POINT_SHORTS
+    with PcsContext(cfgs, flags=flags) as ctx:
+        dd = [_upload(ctx, d) for d, _ in sets]
+        dc = [_upload(ctx, c) for _, c in sets]
+        outs = [ctx.device_malloc(n_sh * 2 + 64) + skew for _ in range(n_sets)]
+        d_counts = [ctx.device_malloc(4 * (n + 1)) if k % 3 != 1 else None for k in range(n_sets)]
+        for rep in range(2):                                 # the scratch rows are reused by the second call
+            ctx.process_frames_device_batch(dd, dc, outs, n_sh, d_counts)
+        ctx.synchronize()
+        for k in range(n_sets):
+            want, wcounts = oracle.process_frames(cfgs, sets[k][0], sets[k][1], flags)
+            if d_counts[k] is not None:
+                cnt = np.empty(n + 1, np.int32)
+                ctx.memcpy_d2h(cnt, d_counts[k])
+                assert list(cnt[:n]) == wcounts and cnt[n] == sum(wcounts), f"set {k}"
+            got = np.empty(max(want.size, 1), np.int16)
+            ctx.memcpy_d2h(got, outs[k])
+            assert_same(got[:want.size].reshape(-1, 5), want)
+
+
+def test_batched_compaction_with_a_stride_runs_set_by_set(oracle):
+    cfgs, _, _ = S.synth_frame_set(2, 320, 240)
+    sets = [S.synth_frame_set(2, 320, 240, seed=S.SEED + 3 * k)[1:] for k in range(3)]
+    n_sh = sum(c.n_points for c in cfgs) * POINT_SHORTS
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID, downsample=3) as ctx:
+        dd = [_upload(ctx, d) for d, _ in sets]
+        dc = [_upload(ctx, c) for _, c in sets]
+        outs = [ctx.device_malloc(n_sh * 2 + 64) for _ in range(3)]
+        ctx.process_frames_device_batch(dd, dc, outs, n_sh, None)
+        ctx.synchronize()
+        for k in range(3):
+            want, _ = oracle.process_frames(cfgs, sets[k][0], sets[k][1], FLAG_DROP_INVALID, downsample=3)
+            got = np.empty(want.size, np.int16)
+            ctx.memcpy_d2h(got, outs[k])
+            assert_same(got.reshape(-1, 5), want)
+
+
 @pytest.mark.parametrize("skew", [0, 4])
 def test_batched_pack_equals_single_clouds(oracle, skew):
     """pcs_copy_pointclouds_xyzrgb_to_buffer_device: 19 cameras (two launches), ragged point counts incl. 0, each
