@@ -276,6 +276,16 @@ class PcsContext:
         self._check(self._lib.pcs_voxel_grid_device_counted(self._h, d_payload, d_n_points, int(max_points), int(leaf_mm),
                                                             d_out, out_shorts, d_out_points or None))
 
+    def process_frames_voxel_device(self, d_depth: Sequence[int], d_color: Sequence[int], leaf_mm: int, d_out: int,
+                                    out_shorts: int, d_out_points: int = 0) -> None:
+        """Rasters -> voxel grid without the stitched cloud (pcs_process_frames_voxel_device)."""
+        if len(d_depth) != self.n_streams or len(d_color) != self.n_streams:
+            raise ValueError("need one depth and one colour pointer per stream")
+        dp = (C.c_void_p * self.n_streams)(*d_depth)
+        cp = (C.c_void_p * self.n_streams)(*d_color)
+        self._check(self._lib.pcs_process_frames_voxel_device(self._h, dp, cp, int(leaf_mm), d_out, out_shorts,
+                                                              d_out_points or None))
+
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))

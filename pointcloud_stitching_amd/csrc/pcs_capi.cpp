@@ -1329,6 +1329,70 @@ int pcs_voxel_grid_device_counted(pcs_ctx* c, const int16_t* d_payload, const in
     return voxel_grid_device_impl(c, d_payload, max_points, d_n_points, leaf_mm, d_out, out_shorts, d_out_points);
 }
 
+int pcs_process_frames_voxel_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
+                                    int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!d_depth || !d_color || !d_out) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
+    const int S = c->n_streams;
+    for (int s = 0; s < S; s++) {
+        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
+    }
+    const size_t cap = c->max_payload_points;          // every pixel kept, no stride
+    if (out_shorts < cap * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every pixel its own voxel) needs %zu",
+                    out_shorts, cap * PCS_POINT_SHORTS);
+    DeviceGuard guard(c->device);
+    // Below ~36 mm (on the synthetic scene) a 4096-pixel round holds more voxels than a workgroup's LDS table takes
+    // gracefully; the payload reader, fed by the ordered compaction, then is the faster route (16 x 1080p at 25 mm:
+    // 0.93 ms vs 1.11 ms). Same result either way. PCS_VOXEL_FUSED=0/1 forces one or the other.
+    static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
+    const bool fused = fused_env >= 0 ? fused_env != 0 : leaf_mm >= 36;
+    if (c->downsample != 1 || !fused) {
+        // (the stride is defined on the ORDER of the kept points: build the stitched cloud, then its voxel grid)
+        int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
+        if (rc) return rc;
+        rc = run_fused_device(c, d_depth, d_color, c->s_payload, cap * PCS_POINT_SHORTS, c->d_counts, true);
+        if (rc) return rc;
+        return voxel_grid_device_impl(c, c->s_payload, (int)cap, c->d_counts + S, leaf_mm, d_out, out_shorts, d_out_points);
+    }
+    const size_t need = voxel_workspace_bytes((uint32_t)cap);
+    if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
+    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    if (rc) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev{};
+    if (c->kernel_timing) {
+        rc = acquire_event_pair(c, ev);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(ev.first, c->stream));
+    }
+    VoxelStage vs{};
+    HIPCHK(c, voxel_begin((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &vs, c->stream));
+    for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
+        const int nl = std::min(kLaunchStreams, S - s0);
+        FramePtrs fp{};
+        uint32_t mp = 0;
+        bool fast = true, ident = true;
+        for (int k = 0; k < nl; k++) {
+            fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
+            mp = std::max(mp, c->h_params[s0 + k].n_points);
+            fast &= c->h_params[s0 + k].cert_fast != 0; ident &= c->h_params[s0 + k].ident_r != 0;
+        }
+        const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
+        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, c->flags, sel, fp, vs, c->stream));
+    }
+    HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out, d_out_points, c->stream));
+    if (c->kernel_timing) {
+        HIPCHK(c, hipEventRecord(ev.second, c->stream));
+        c->ev_pool.push_back(ev);
+    }
+    return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_device: host allocation failed (%s)", ex.what());
+}
+
 int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,
                    int* out_points)
 {

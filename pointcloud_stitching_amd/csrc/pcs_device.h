@@ -166,6 +166,22 @@ size_t     voxel_workspace_bytes(uint32_t n_points);
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
                              size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st);
 
+// The same pipeline fed from the rasters (pcs_process_frames_voxel_device): voxel_begin carves the workspace and clears
+// the counters, launch_fused_voxel_partials (pcs_kernels.hip) appends the partials, voxel_finish sorts and reduces.
+struct VoxelStage {
+    unsigned long long* keys;
+    unsigned int*       idx;
+    void*               part;          // VoxelPartial[capacity]
+    unsigned int*       n_runs;        // partials appended so far
+    uint32_t            leaf, bias_leaf, magic, bits, idx_bits;
+};
+hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
+hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
+                        int32_t* d_out_points, hipStream_t st);
+hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                                       uint32_t flags, MathSel math, const FramePtrs& fp, const VoxelStage& vs,
+                                       hipStream_t st);
+
 // a7 with stride.
 hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,
                          int16_t* d_dst, hipStream_t st);

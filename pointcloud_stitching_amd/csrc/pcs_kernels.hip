@@ -918,10 +918,10 @@ void pcs_fused_dense_batch_kernel(const StreamParams* __restrict__ params, Batch
 // Count pass: kept points per tile. (Folding the per-stream scan into this launch through a last-arriver
 // counter was measured and is slower — 450 returning atomics per counter line cost more than the separate
 // 5 us scan launch)
-// A workgroup counts kCountTiles consecutive tiles: the (independent) Z16 loads of all of them are in flight together,
-// so the launch is one HBM round trip deep with a quarter of the workgroups (3 600 one-tile workgroups measured
-// 5.1 us for the 14.7 MB of 8 x 720p: latency, not bandwidth).
-constexpr int kCountTiles = 4;
+// A workgroup counts kCountTiles consecutive tiles, their (independent) Z16 loads issued back to back with no branch
+// between them. Measured on 8 x 720p (14.7 MB of Z16, rocprofv3 average): 1 tile 5.4 us, 2 tiles 5.4 us, 4 tiles
+// 5.9 us, 8 tiles 6.9 us — latency, not bandwidth; 2 halves the workgroups at no cost.
+constexpr int kCountTiles = 2;
 template <bool DDIST, bool CDIST>
 __device__ __forceinline__ void count_tiles(const StreamParams& P, const uint16_t* __restrict__ dp, uint32_t flags,
                                             uint32_t* __restrict__ tile_counts, uint32_t (*wsum)[4])
@@ -1164,6 +1164,175 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
     if (threadIdx.x == 0) {
         stream_kept[z * gridDim.x + s] = carry_s;
         bc.counts[z][s] = (int32_t)carry_s;
+    }
+}
+
+// ---- rasters -> voxel partials (config 5 without the stitched payload) ---------------------------------------------
+// pcs_process_frames_voxel_device: the voxel grid of the cloud pcs_process_frames_device would stitch, without writing
+// that cloud (10 B per kept point out, 10 B back in for the pre-aggregation) and without its ordered placement (count
+// and scan passes): the voxel sums are integers, so the order of the points is irrelevant. A workgroup of 1024 lanes
+// takes 8192 consecutive pixels of one camera; a lane deprojects, transforms and packs its 8 consecutive pixels exactly
+// as the stitch kernels do (same records, bit for bit), sums runs of equal voxel keys among them in registers (8
+// neighbouring pixels mostly share a voxel) and adds each run to the workgroup's LDS hash table (pcs_voxel.hip, step 1);
+// one partial per occupied slot is appended to the same arrays the payload reader fills, and pcs_voxel.hip's sort and
+// segmented mean run unchanged.
+#include "pcs_voxel_agg.h"
+
+constexpr int kVoxThreads = 512;
+constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 pixels per round; `rounds` of them share one table
+
+// 512 lanes x 2 rounds rather than 1024 x 1: the kernel needs ~100 VGPRs (the stitch kernels' 8 points in flight plus
+// the table phase), which leaves room for one 1024-lane workgroup per CU — its load phase and its LDS phase then have
+// nothing to overlap with. Two 512-lane workgroups fit, and there is no barrier between the rounds.
+template <class Mth>
+__global__ __launch_bounds__(kVoxThreads)
+void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
+                                     VoxelStage vs, int rounds)
+{
+    __shared__ unsigned long long skey[kSlots];
+    __shared__ int          ssx[kSlots], ssy[kSlots], ssz[kSlots];
+    __shared__ unsigned int sr[kSlots], sg[kSlots], sb[kSlots], sn[kSlots];
+    __shared__ unsigned int wtot[kVoxThreads / 64];
+    __shared__ unsigned int base_s;
+
+    const int s = blockIdx.y;
+    const StreamParams& P = params[stream0 + s];
+    const uint32_t n = P.n_points;
+    const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
+    if (tile0 >= n) return;
+    const uint8_t* __restrict__ color = fp.color[s];
+    DepthSource<true, true, Mth> src{fp.depth[s]};
+    const VoxelDiv dv{vs.leaf, vs.bias_leaf, vs.magic};
+    const unsigned int bits = vs.bits, idx_bits = vs.idx_bits;
+    VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    for (int j = threadIdx.x; j < kSlots; j += kVoxThreads) {
+        skey[j] = kEmptyKey;
+        ssx[j] = ssy[j] = ssz[j] = 0;
+        sr[j] = sg[j] = sb[j] = sn[j] = 0u;
+    }
+    __syncthreads();
+
+    for (int round = 0; round < rounds; round++) {
+        const uint32_t i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
+        PointIn p[8];
+        src.load8(P, i0, n, p, nullptr);
+        const uint32_t keep = keep_mask8(p, i0, n, flags);
+
+        Record rec[8];
+        auto fill = [&](auto& cv) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) rec[k] = make_record(P, color, p[k], cv);
+        };
+        if (Mth::kCvtMode == 2) {
+            FastCvt<false> fast;
+            fill(fast);
+            if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+        } else if (Mth::kCvtMode == 1) {
+            FastCvt<true> fast;
+            fill(fast);
+            if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+        } else {
+            ExactCvt exact;
+            fill(exact);
+        }
+
+        auto key_of = [&](const Record& r) {
+            return voxel_key(dv, (int)(short)(r.xy & 0xFFFFu), (int)(short)(r.xy >> 16), (int)(short)(r.zc & 0xFFFFu), bits);
+        };
+        // runs of equal keys among the lane's 8 pixels: summed in registers, the run's LAST point adds them to the table
+        int ax = 0, ay = 0, az = 0;
+        unsigned int ar = 0, ag = 0, ab = 0, an = 0, failed = 0;
+        bool cont = false;                                       // point k continues the run of point k-1
+        unsigned long long kcur = key_of(rec[0]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool live = (keep >> k) & 1u;
+            const bool live_next = k < 7 && ((keep >> (k + 1)) & 1u);
+            const unsigned long long knext = k < 7 ? key_of(rec[k + 1]) : 0ull;
+            const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
+            const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
+            if (!cont) { ax = ay = az = 0; ar = ag = ab = an = 0u; }
+            ax += x; ay += y; az += z;
+            ar += col & 0xFFu; ag += col >> 8; ab += blue; an += 1u;
+            const bool same_next = live_next && knext == kcur;
+            const bool actor = live && !same_next;
+            if (actor) {
+                const VoxelProbe pr(kcur);
+                unsigned int h = pr.first;
+                bool placed = false;
+                for (int t = 0; t < kProbe; t++) {
+                    const unsigned long long old = atomicCAS(&skey[h], kEmptyKey, kcur);
+                    if (old == kEmptyKey || old == kcur) { placed = true; break; }
+                    h = pr.next(h);
+                }
+                if (placed) {
+                    atomicAdd(&ssx[h], ax); atomicAdd(&ssy[h], ay); atomicAdd(&ssz[h], az);
+                    atomicAdd(&sr[h], ar); atomicAdd(&sg[h], ag); atomicAdd(&sb[h], ab); atomicAdd(&sn[h], an);
+                } else {
+                    failed |= 1u << k;                           // the run ending at k goes out as a partial of its own
+                }
+            }
+            cont = live && same_next;
+            kcur = knext;
+        }
+        // Runs that found no slot (more voxels under this table than it can take: leaves of a few pixels) are appended
+        // as partials of their own; one global atomic per wavefront, only when it happens. The sums are rebuilt from
+        // the records: a failed run is the maximal stretch of kept points with the same key that ends at its bit.
+        if (__ballot(failed != 0u)) {
+            const unsigned int c = __popc(failed);
+            const unsigned int inc = wave_inclusive_scan(c);
+            unsigned int base = 0;
+            if (lane == 63) base = atomicAdd(vs.n_runs, inc);
+            unsigned int pos = (unsigned int)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+            int sx = 0, sy = 0, sz = 0;
+            unsigned int r = 0, g = 0, b = 0, cnt = 0;
+            unsigned long long kprev = 0ull;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool live = (keep >> k) & 1u;
+                const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
+                const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
+                const unsigned long long key = voxel_key(dv, x, y, z, bits);
+                const bool joins = k > 0 && live && ((keep >> (k - 1)) & 1u) && key == kprev;
+                if (!joins) { sx = sy = sz = 0; r = g = b = cnt = 0u; }
+                sx += x; sy += y; sz += z; r += col & 0xFFu; g += col >> 8; b += blue; cnt += 1u;
+                kprev = key;
+                if ((failed >> k) & 1u) {
+                    if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
+                    else { vs.keys[pos] = key; vs.idx[pos] = pos; }
+                    part[pos] = VoxelPartial{sx, sy, sz, r, g, b, cnt, 0u};
+                    pos++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // every lane owns four slots; one partial per occupied slot
+    unsigned int c = 0;
+#pragma unroll
+    for (int q = 0; q < kSlots / kVoxThreads; q++) c += skey[threadIdx.x * (kSlots / kVoxThreads) + q] != kEmptyKey;
+    const unsigned int inc = wave_inclusive_scan(c);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int w = 0; w < kVoxThreads / 64; w++) { const unsigned int t = wtot[w]; wtot[w] = tot; tot += t; }
+        base_s = tot ? atomicAdd(vs.n_runs, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int pos = base_s + wtot[wave] + inc - c;
+#pragma unroll
+    for (int q = 0; q < kSlots / kVoxThreads; q++) {
+        const int j = threadIdx.x * (kSlots / kVoxThreads) + q;
+        if (skey[j] != kEmptyKey) {
+            if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
+            else { vs.keys[pos] = skey[j]; vs.idx[pos] = pos; }
+            part[pos] = VoxelPartial{ssx[j], ssy[j], ssz[j], sr[j], sg[j], sb[j], sn[j], 0u};
+            pos++;
+        }
     }
 }
 
@@ -1447,6 +1616,31 @@ hipError_t launch_compact_batch(const StreamParams* d_params, int n_streams, int
     const dim3 grid(tiles, (unsigned)n_streams, (unsigned)n_sets);
 #define L(M) hipLaunchKernelGGL((pcs_fused_emit_batch_kernel<M>), grid, dim3(kBlockThreads), 0, st, d_params, bp, flags, \
                                 d_tile_prefix, d_stream_kept, total_tiles, bc)
+    const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
+    if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
+#undef L
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
+                                       uint32_t flags, MathSel math, const FramePtrs& fp, const VoxelStage& vs, hipStream_t st)
+{
+    if (n_launch <= 0 || max_points == 0) return hipSuccess;
+    static const int env_rounds = [] { const char* v = getenv("PCS_VOXEL_ROUNDS"); return v ? atoi(v) : 0; }();
+    // Rounds (4096 pixels each) that share one 2048-slot table. More rounds = fewer partials for the sort, as long as
+    // the voxels under one table stay below its slots: a leaf spans leaf / (depth / focal) pixels, so the voxels per
+    // round fall roughly with the square of the leaf. Tuned on the synthetic scene (0.5 - 4.5 m, fx = 0.7 W: 1 400 /
+    // 740 / 370 voxels per round at 25 / 50 / 100 mm; 16 x 1080p, ms per frame-set at 2 / 3 / 4 / 8 rounds: 35 mm
+    // 0.57 / 0.50 / 0.51 / -, 50 mm 0.42 / 0.39 / 0.34 / 0.43, 200 mm 0.25 / - / 0.22 / 0.22). A wrong guess costs
+    // speed, never correctness (runs that find no slot go out as partials of their own). Capped so that the launch
+    // still fills the chip twice over.
+    const uint64_t launch_tiles = (uint64_t)((max_points + kVoxRoundPoints - 1) / kVoxRoundPoints) * (uint64_t)n_launch;
+    const uint64_t by_leaf = std::min<uint64_t>(8, std::max<uint64_t>(3, ((uint64_t)vs.leaf * vs.leaf) / 625u));
+    int rounds = (int)std::min<uint64_t>(by_leaf, std::max<uint64_t>(1, launch_tiles / 1024));
+    if (env_rounds > 0) rounds = env_rounds;
+    const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
+    const dim3 grid((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
+#define L(M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
     if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
 #undef L

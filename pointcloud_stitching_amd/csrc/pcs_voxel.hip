@@ -35,40 +35,7 @@ namespace pcs {
 
 namespace {
 
-// What one workgroup of the pre-aggregation kernel knows about one voxel: the sums over its (<= 8192) points
-// that fall into it (|sum| <= 8192 * 32768 = 2^28 fits an int).
-struct alignas(32) VoxelPartial {      // 32 B: one sector per gathered partial in the segmented mean
-    int          sx, sy, sz;
-    unsigned int r, g, b, n, pad;
-};
-
-// Bits one axis needs: voxel indices run over 0 .. floor(32767/leaf) + ceil(32768/leaf) <= 65536/leaf + 1.
-// Packing the three axes into 3*bits (instead of a fixed 51) saves whole radix passes for realistic leaves.
-inline unsigned int axis_bits(int leaf)
-{
-    const unsigned int max_index = 32767u / (unsigned)leaf + (32768u + (unsigned)leaf - 1u) / (unsigned)leaf;
-    unsigned int b = 1;
-    while ((1u << b) <= max_index) b++;
-    return b;
-}
-
-// floor(v / leaf) + bias, bias = ceil(32768 / leaf): the biased numerator u = v + bias*leaf is in [0, 2^17), and
-// floor(u / leaf) == (u * magic) >> 32 with magic = ceil(2^32 / leaf) — checked by the host over every u before the
-// launch (magic = 0: use '/'). Three variable-divisor integer divisions per point otherwise cost ~75 instructions.
-struct VoxelDiv {
-    unsigned int leaf, bias_leaf, magic;
-    __device__ __forceinline__ unsigned int operator()(int v) const
-    {
-        const unsigned int u = (unsigned int)(v + (int)bias_leaf);
-        return magic ? __umulhi(u, magic) : u / leaf;
-    }
-};
-
-__device__ __forceinline__ unsigned long long voxel_key(const VoxelDiv& dv, int x, int y, int z, unsigned int bits)
-{
-    const unsigned long long kx = dv(x), ky = dv(y), kz = dv(z);
-    return (kz << (2 * bits)) | (ky << bits) | kx;      // z major, x fastest: (z,y,x) voxel order
-}
+#include "pcs_voxel_agg.h"
 
 // ---- wavefront helpers (64 lanes, all active) ---------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
@@ -132,8 +99,7 @@ __device__ __forceinline__ void unpack_record(const u32x3 d, unsigned int i, int
 // as single-point partials. One returning global atomic per workgroup reserves its slice of the partial arrays; the
 // order of the partials does not matter (they are sorted next, and the sums are integers).
 // ------------------------------------------------------------------------------------------------
-constexpr int kAggThreads = 1024, kAggPerLane = 8, kSlots = 2048, kProbe = 12;
-constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kAggThreads = 1024, kAggPerLane = 8;      // kSlots, kProbe, kEmptyKey: pcs_voxel_agg.h
 
 // WIDE: the payload is 4-byte aligned and holds >= 2 points: every lane requests its eight records with eight 12-byte
 // loads up front, branch-free (indices clamped to the last record whose window stays inside the payload; an even LAST
@@ -217,13 +183,14 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
             seg_step<0x112, 0xf>(a);                             // row_shr:2
             seg_step<0x114, 0xf>(a);                             // row_shr:4
         }
-        unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 53);       // 11 bits
+        const VoxelProbe pr(key);
+        unsigned int h = pr.first;
         bool placed = false;
         if (actor) {
             for (int t = 0; t < kProbe; t++) {
                 const unsigned long long old = atomicCAS(&skey[h], kEmptyKey, key);
                 if (old == kEmptyKey || old == key) { placed = true; break; }
-                h = (h + 1u) & (unsigned)(kSlots - 1);
+                h = pr.next(h);
             }
             if (placed) {
                 atomicAdd(&ssx[h], a.x); atomicAdd(&ssy[h], a.y); atomicAdd(&ssz[h], a.z);
@@ -683,23 +650,24 @@ inline Workspace carve(uint8_t* base, size_t n)
 // worst case: every point its own partial
 size_t voxel_workspace_bytes(uint32_t n_points) { return carve(nullptr, n_points).bytes + 256; }
 
-// d_n_points != nullptr: the number of points is read from device memory (<= n_points, which then is the capacity that
-// sizes the workspace and the grids)
-hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
-                             size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
+namespace {
+
+struct Plan {
+    Workspace w;
+    VoxelDiv dv;
+    unsigned int bits, idx_bits;
+};
+
+// Carves the workspace and derives the key layout for a cloud of at most n_points points.
+hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes, Plan& pl)
 {
-    if (n_points == 0) {
-        if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
-        return hipSuccess;
-    }
     if (ws_bytes < voxel_workspace_bytes(n_points)) return hipErrorInvalidValue;
     uint8_t* base = static_cast<uint8_t*>(d_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
-    const Workspace w = carve(base, n_points);
-
-    const unsigned int bits = axis_bits(leaf_mm);
+    pl.w = carve(base, n_points);
+    pl.bits = axis_bits(leaf_mm);
     const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
-    VoxelDiv dv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
+    pl.dv = VoxelDiv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
     {   // floor(u / leaf) == umulhi(u, magic) for every biased coordinate u = v + bias*leaf, v in [-32768, 32767]:
         // verified here over all 65 536 of them (once per leaf per host thread), magic = 0 -> the kernel divides
         thread_local int cached_leaf = 0;
@@ -707,30 +675,27 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
         if (cached_leaf != leaf_mm) {
             const unsigned long long magic = ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
             bool ok = magic < (1ull << 32);
-            const unsigned int lo = dv.bias_leaf - 32768u, hi = dv.bias_leaf + 32767u;
+            const unsigned int lo = pl.dv.bias_leaf - 32768u, hi = pl.dv.bias_leaf + 32767u;
             for (unsigned int u = lo; ok && u <= hi; u++)
                 ok = (unsigned int)(((unsigned long long)u * magic) >> 32) == u / (unsigned)leaf_mm;
             cached_leaf = leaf_mm;
             cached_magic = ok ? (unsigned int)magic : 0u;
         }
-        dv.magic = cached_magic;
+        pl.dv.magic = cached_magic;
     }
-    hipError_t e = hipMemsetAsync(w.ctl, 0, 4 * sizeof(unsigned int), st);
-    if (e != hipSuccess) return e;
-    const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
-    const dim3 agg_grid((n_points + per_block - 1) / per_block);
     // one 64-bit word per element when the packed key and the partial's index fit together
-    unsigned int idx_bits = 1;
-    while ((1ull << idx_bits) < (unsigned long long)n_points) idx_bits++;
+    pl.idx_bits = 1;
+    while ((1ull << pl.idx_bits) < (unsigned long long)n_points) pl.idx_bits++;
     static const int pack_ok = [] { const char* v = getenv("PCS_VOXEL_PACKED"); return v ? atoi(v) : 1; }();
-    if (!pack_ok || 3u * bits + idx_bits > 64u) idx_bits = 0;
-    static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
-    if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, dv, bits, idx_bits,
-                           w.keys_a, w.idx_a, w.part, w.ctl);
-    else
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, dv, bits, idx_bits,
-                           w.keys_a, w.idx_a, w.part, w.ctl);
+    if (!pack_ok || 3u * pl.bits + pl.idx_bits > 64u) pl.idx_bits = 0;
+    return hipSuccess;
+}
+
+// Steps 2 and 3 on the partials a pre-aggregation left in the workspace.
+hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
+{
+    const Workspace& w = pl.w;
+    const unsigned int bits = pl.bits, idx_bits = pl.idx_bits;
     unsigned long long *kin = w.keys_a, *kout = w.keys_b;
     unsigned int *iin = w.idx_a, *iout = w.idx_b;
     const VoxelPartial* parts = w.part;
@@ -761,6 +726,58 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
     const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
     hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, m_ptr, w.lead, w.trail, d_out);
     return hipGetLastError();
+}
+
+}  // namespace
+
+// d_n_points != nullptr: the number of points is read from device memory (<= n_points, which then is the capacity that
+// sizes the workspace and the grids)
+hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
+                             size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
+{
+    if (n_points == 0) {
+        if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
+        return hipSuccess;
+    }
+    Plan pl;
+    hipError_t e = plan_for(n_points, leaf_mm, d_ws, ws_bytes, pl);
+    if (e != hipSuccess) return e;
+    const Workspace& w = pl.w;
+    e = hipMemsetAsync(w.ctl, 0, 4 * sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+    const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
+    const dim3 agg_grid((n_points + per_block - 1) / per_block);
+    static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
+    if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv, pl.bits,
+                           pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
+    else
+        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv, pl.bits,
+                           pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
+    return sort_and_reduce(pl, n_points, d_out, d_out_points, st);
+}
+
+// Raster source (pcs_kernels.hip: launch_fused_voxel_partials fills the stage between these two calls).
+hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st)
+{
+    Plan pl;
+    hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, pl);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(pl.w.ctl, 0, 4 * sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+    stage->keys = pl.w.keys_a; stage->idx = pl.w.idx_a; stage->part = pl.w.part; stage->n_runs = pl.w.ctl;
+    stage->leaf = pl.dv.leaf; stage->bias_leaf = pl.dv.bias_leaf; stage->magic = pl.dv.magic;
+    stage->bits = pl.bits; stage->idx_bits = pl.idx_bits;
+    return hipSuccess;
+}
+
+hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out, int32_t* d_out_points,
+                        hipStream_t st)
+{
+    Plan pl;
+    hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, pl);
+    if (e != hipSuccess) return e;
+    return sort_and_reduce(pl, capacity_points, d_out, d_out_points, st);
 }
 
 }  // namespace pcs

@@ -6,7 +6,7 @@ import pytest
 
 from pointcloud_stitching_amd import synthetic as S
 from pointcloud_stitching_amd.api import PcsContext, PcsError
-from pointcloud_stitching_amd.types import FLAG_DROP_INVALID
+from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID, FLAG_FORCE_IEEE
 
 
 def numpy_voxel_grid(p, leaf):
@@ -195,6 +195,104 @@ def test_config5_full_size_against_oracle_digests():
             nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
             assert int(nv[0]) == want["voxels"], leaf
             got = np.empty(int(nv[0]) * 5, np.int16); ctx.memcpy_d2h(got, d_vox)
+            assert hashlib.sha256(got.tobytes()).hexdigest() == want["sha256"], leaf
+
+
+def _upload_rasters(ctx, depth, color):
+    dd = [ctx.device_malloc(max(d.nbytes, 16)) for d in depth]
+    dc = [ctx.device_malloc(max(c.nbytes, 16)) for c in color]
+    for ptr, a in zip(dd + dc, list(depth) + list(color)):
+        ctx.memcpy_h2d(ptr, a)
+    return dd, dc
+
+
+def _rasters_to_voxels(ctx, dd, dc, leaf, n_max):
+    d_vox = ctx.device_malloc(n_max * 10 + 64)
+    d_nv = ctx.device_malloc(4)
+    ctx.process_frames_voxel_device(dd, dc, leaf, d_vox, n_max * 5, d_nv)
+    ctx.synchronize()
+    nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
+    got = np.empty(max(int(nv[0]), 1) * 5, np.int16); ctx.memcpy_d2h(got, d_vox)
+    ctx.device_free(d_vox); ctx.device_free(d_nv)
+    return got[:int(nv[0]) * 5].reshape(-1, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT | FLAG_DROP_INVALID,
+                                   FLAG_DROP_INVALID | FLAG_FORCE_IEEE])
+@pytest.mark.parametrize("shapes", [[(640, 480)] * 2, [(1280, 720), (321, 243), (64, 48)], [(8, 1)], [(1920, 1080)]])
+def test_rasters_to_voxel_grid_equals_stitch_then_voxel_grid(oracle, flags, shapes):
+    """pcs_process_frames_voxel_device never writes the stitched cloud; its voxels must be exactly those of the oracle's
+    voxel grid over the oracle's stitched cloud (same flags), for leaves from 'every point its own voxel' to 'one voxel'.
+    Ragged rasters (321 x 243: rows not a multiple of 8, last workgroup partly empty), a raster smaller than one lane's
+    8 pixels, a raster larger than a workgroup's 8192 pixels."""
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
+    color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+    n_max = sum(c.n_points for c in cfgs)
+    stitched, _ = oracle.process_frames(cfgs, depth, color, flags)
+    with PcsContext(cfgs, flags=flags) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        for leaf in (1, 7, 36, 50, 200, 32767):
+            got = _rasters_to_voxels(ctx, dd, dc, leaf, n_max)
+            want = oracle.voxel_grid(stitched, leaf)
+            assert got.shape == want.shape and (got == want).all(), (leaf, got.shape, want.shape)
+
+
+@pytest.mark.gpu
+def test_rasters_to_voxel_grid_nothing_kept_and_stride(oracle):
+    cfgs, depth, color = S.synth_frame_set(3, 320, 240)
+    n_max = sum(c.n_points for c in cfgs)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        dd, dc = _upload_rasters(ctx, [np.zeros_like(d) for d in depth], color)
+        assert _rasters_to_voxels(ctx, dd, dc, 50, n_max).shape[0] == 0
+        with pytest.raises(PcsError):
+            ctx.process_frames_voxel_device(dd, dc, 0, dd[0], n_max * 5)
+        with pytest.raises(PcsError):
+            ctx.process_frames_voxel_device(dd, dc, 50, dd[0], n_max * 5 - 1)
+    # with a stride the stitched cloud is built internally (the stride is defined on the order of the kept points)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID, downsample=3) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID, downsample=3)
+        got = _rasters_to_voxels(ctx, dd, dc, 100, n_max)
+        want = oracle.voxel_grid(stitched, 100)
+        assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.gpu
+def test_rasters_to_voxel_grid_full_table_passes_points_through(oracle):
+    """Uniformly random depth (0 .. 65 m): neighbouring pixels are metres apart, so practically every pixel is its own
+    voxel even at 40 / 64 mm — the leaves at which the one-call form reads the rasters directly — and the 2048-slot LDS
+    table of a workgroup overflows: most runs take the pass-through route. (Below 36 mm the call goes through the
+    internal stitched cloud; leaves 1 and 3 cover that route on the same input.)"""
+    cfgs = [S.synth_stream_config(640, 480, 0)]
+    rng = np.random.default_rng(5)
+    depth = [rng.integers(0, 65536, 640 * 480, dtype=np.uint16)]
+    color = [S.synth_color(640, 480, 0)]
+    stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        for leaf in (1, 3, 40, 64):
+            got = _rasters_to_voxels(ctx, dd, dc, leaf, cfgs[0].n_points)
+            want = oracle.voxel_grid(stitched, leaf)
+            assert got.shape == want.shape and (got == want).all(), leaf
+
+
+@pytest.mark.gpu
+def test_config5_full_size_rasters_to_voxels_digests():
+    """BASELINE configs[4] at full size through the one-call form: 16 x 1920x1080 rasters -> voxel grid, no stitched
+    cloud in between; same pinned oracle digests as the two-call form above."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5_digests.json")))
+    cfgs, depth, color = S.synth_frame_set(16, 1920, 1080)
+    n_max = sum(c.n_points for c in cfgs)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        for leaf, want in sorted(gold["voxel"].items()):
+            got = _rasters_to_voxels(ctx, dd, dc, int(leaf), n_max)
+            assert got.shape[0] == want["voxels"], leaf
             assert hashlib.sha256(got.tobytes()).hexdigest() == want["sha256"], leaf
 
 

@@ -12,5 +12,5 @@ for f in glob.glob("/tmp/vp/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"].replace("pcs::(anonymous namespace)::", "")
         if "voxel" in n:
-            print(n[:40].ljust(40), r["Calls"].rjust(6), "%9.2f us" % (float(r["AverageNs"]) / 1e3))
+            print(n[:52].ljust(52), r["Calls"].rjust(6), "%9.2f us" % (float(r["AverageNs"]) / 1e3))
 PY
