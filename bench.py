@@ -745,11 +745,24 @@ def main():
                 ms_v5 = timed(voxel5, 30, ctx5)
                 ms_b5 = timed(both5, 30, ctx5)
                 kept5, nvox5 = int(cnt5[S5].item()), int(nv5.item())
+
+                def onecall5():       # rasters -> voxels, the stitched cloud never written
+                    dp, cp = args5[k5[0] % 4]; k5[0] += 1
+                    check(lib.pcs_process_frames_voxel_device(ctx5._h, dp, cp, LEAF, VP(vox5.data_ptr()), vox5.numel(), VP(nv5.data_ptr())), ctx5._h)
+                for _ in range(3):
+                    onecall5()
+                torch.cuda.synchronize(dev)
+                ms_o5 = timed(onecall5, 30, ctx5)
+                nvox5_one = int(nv5.item())
                 out["config5_one_gpu"] = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
                                           "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
                                           "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
                                           "pipeline_ms_per_frame_set": round(ms_b5, 4),
                                           "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
+                                          "one_call": {"ms_per_frame_set": round(ms_o5, 4), "value": round(S5 * n5 / ms_o5 / 1e3, 1),
+                                                       "voxels": nvox5_one,
+                                                       "note": "pcs_process_frames_voxel_device: the same voxel cloud straight from the "
+                                                               "rasters; the stitched cloud is never written to HBM"},
                                           "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                           "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
                                                   "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}

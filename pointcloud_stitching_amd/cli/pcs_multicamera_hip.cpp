@@ -16,6 +16,9 @@
 //     and -n belong to the PCL viewer, which this build does not have: refused with a reason.
 //   additions: -i <src>  -c <list>  -N <streams>  -g <gpu>  -p <serve port>  -r <frame-sets>  -o <file>  -q (no server)
 //              -G <n>  shard the cameras of -i over n GPUs: libpcs_node (ncclCommInitAll + one grouped send/recv to GPU 0)
+//              -V <mm> serve the voxel-grid downsample (leaf in mm, BASELINE config 5) of the stitched cloud instead of the
+//                      cloud itself: with -i one device call from the rasters (pcs_process_frames_voxel_device), with -c the
+//                      voxel grid of the concatenated payloads;  -Z  drop invalid-depth pixels (PCS_FLAG_DROP_INVALID, -i only)
 //     with neither -i nor -c the cameras are 8 synthetic 1280x720 streams on this node (there are no live cameras here).
 #include <chrono>
 #include <cstdio>
@@ -37,7 +40,8 @@ typedef std::chrono::high_resolution_clock clockTime;
 typedef std::chrono::duration<double, std::milli> timeMilli;
 
 static bool timer = false, serve = true;
-static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30, n_gpus = 0;
+static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30, n_gpus = 0, voxel_leaf = 0;
+static bool drop_invalid = false;
 static const char* source = nullptr;
 static const char* cameras = nullptr;
 static const char* dump_path = nullptr;
@@ -53,6 +57,7 @@ static void usage()
               << " -c <list>        edge servers host:port,... (pull 'Z' protocol)\n"
               << " -N <n> streams   -g <gpu>   -p <port> (default 9000)   -r <frame-sets>   -o <file>   -q no server\n"
               << " -G <n>           shard the -i cameras over n GPUs of this node (one process, RCCL gather to GPU 0)\n"
+              << " -V <mm>          serve the voxel-grid downsample (leaf in millimetres) of the stitched cloud;  -Z drop invalid depth\n"
               << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
 }
 
@@ -60,7 +65,7 @@ int main(int argc, char** argv)
 {
     signal(SIGPIPE, SIG_IGN);
     int c;
-    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:")) != -1) {
+    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:Z")) != -1) {
         switch (c) {
             case 't': timer = true; break;
             case 'd': downsample = atoi(optarg); break;
@@ -76,6 +81,8 @@ int main(int argc, char** argv)
             case 'o': dump_path = optarg; break;
             case 'q': serve = false; break;
             case 'G': n_gpus = atoi(optarg); break;
+            case 'V': voxel_leaf = atoi(optarg); break;
+            case 'Z': drop_invalid = true; break;
             case 's': case 'v': case 'n':
                 std::cerr << "-" << (char)c << " drives the reference's PCL viewer / PLY writer, which this build does not include" << std::endl;
                 return 2;
@@ -85,6 +92,9 @@ int main(int argc, char** argv)
     if (downsample < 1) { std::cerr << "downsample must be >= 1" << std::endl; return 2; }
     if (source && cameras) { std::cerr << "give at most one of -i <src> or -c <edge list>" << std::endl; usage(); return 2; }
     if (!source && !cameras) source = "synth:1280x720";      // no live cameras on this node: the synthetic generator
+    if (voxel_leaf < 0 || voxel_leaf > 32767) { std::cerr << "-V leaf must be 1..32767 mm" << std::endl; return 2; }
+    if (voxel_leaf && n_gpus > 0) { std::cerr << "-V runs on one GPU (omit -G)" << std::endl; return 2; }
+    if (drop_invalid && !source) { std::cerr << "-Z applies to cameras on this node (-i); edge servers drop with their own -c" << std::endl; return 2; }
 
     // ---- frame source / edge connections -------------------------------------------------------
     std::vector<pcs_stream_config> cfgs;
@@ -125,6 +135,7 @@ int main(int argc, char** argv)
     memset(&cfg, 0, sizeof cfg);
     cfg.device = device; cfg.n_streams = (int)cfgs.size(); cfg.streams = cfgs.data();
     cfg.downsample = source ? downsample : 1;
+    cfg.flags = (source && drop_invalid) ? PCS_FLAG_DROP_INVALID : 0u;
     pcs_ctx* ctx = nullptr;
     int rc = pcs_create(&ctx, &cfg);
     if (rc != PCS_OK) { std::cerr << "pcs_create: " << pcs_strerror(rc) << ": " << pcs_last_error(nullptr) << std::endl; return 1; }
@@ -141,6 +152,7 @@ int main(int argc, char** argv)
     }
 
     // ---- buffers -------------------------------------------------------------------------------
+    int size_bytes = 0;
     const size_t cam_cap_bytes = (size_t)10 * 4u * 1000 * 1000;           // per-camera receive buffer (reference: 10 MB, :554)
     size_t stitched_shorts = source ? PCS_HEADER_SHORTS + pcs_max_payload_shorts(ctx)
                                     : PCS_HEADER_SHORTS + (size_t)n_streams * cam_cap_bytes / 2;
@@ -154,6 +166,41 @@ int main(int argc, char** argv)
         for (int i = 0; i < n_streams; i++) if (pcs_device_malloc(ctx, &d_cam[i], cam_cap_bytes) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
         if (pcs_device_malloc(ctx, &d_stitched, (size_t)n_streams * cam_cap_bytes + 64) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
     }
+
+    // -V: device-resident rasters (with -i) and the voxel cloud
+    std::vector<void*> d_depth, d_color;
+    void *d_vox = nullptr, *d_nvox = nullptr;
+    size_t vox_cap_points = 0;
+    if (voxel_leaf) {
+        vox_cap_points = source ? pcs_max_payload_shorts(ctx) / PCS_POINT_SHORTS : (size_t)n_streams * cam_cap_bytes / PCS_POINT_BYTES;
+        if (source && cfg.downsample != 1) {
+            vox_cap_points = 0;
+            for (auto& sc : cfgs) vox_cap_points += (size_t)sc.depth.width * sc.depth.height;
+        }
+        if (pcs_device_malloc(ctx, &d_vox, vox_cap_points * PCS_POINT_BYTES + 64) != PCS_OK ||
+            pcs_device_malloc(ctx, &d_nvox, 64) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+        if (source) {
+            d_depth.resize(n_streams, nullptr); d_color.resize(n_streams, nullptr);
+            for (int s = 0; s < n_streams; s++) {
+                const size_t db = (size_t)cfgs[s].depth.width * cfgs[s].depth.height * 2;
+                const size_t cb = (size_t)cfgs[s].color_stride * cfgs[s].color.height;
+                if (pcs_device_malloc(ctx, &d_depth[s], db + 64) != PCS_OK || pcs_device_malloc(ctx, &d_color[s], cb + 64) != PCS_OK) {
+                    std::cerr << pcs_last_error(ctx) << std::endl; return 1;
+                }
+            }
+        }
+        if (stitched.size() < PCS_HEADER_SHORTS + vox_cap_points * PCS_POINT_SHORTS) stitched.resize(PCS_HEADER_SHORTS + vox_cap_points * PCS_POINT_SHORTS);
+    }
+    // the voxel cloud of whatever d_vox / d_nvox hold -> stitched (header + records)
+    auto fetch_voxels = [&]() -> bool {
+        int32_t nv = 0;
+        if (pcs_memcpy_d2h(ctx, &nv, d_nvox, sizeof nv) != PCS_OK || pcs_synchronize(ctx) != PCS_OK) return false;
+        size_bytes = nv * PCS_POINT_BYTES;
+        if (size_bytes && pcs_memcpy_d2h(ctx, stitched.data() + PCS_HEADER_SHORTS, d_vox, (size_t)size_bytes) != PCS_OK) return false;
+        if (pcs_synchronize(ctx) != PCS_OK) return false;
+        memcpy(stitched.data(), &size_bytes, sizeof(int));
+        return true;
+    };
 
     int listen_fd = -1, client_fd = -1;
     if (serve) {
@@ -169,7 +216,7 @@ int main(int argc, char** argv)
     for (int fd : cam_fd) pcs_wire::send_pull(fd);
 
     double total = 0;
-    int loop_count = 1, size_bytes = 0;
+    int loop_count = 1;
     for (int set = 0; set < max_sets; set++) {
         auto stitch_start = clockTime::now();
         if (source) {
@@ -190,7 +237,16 @@ int main(int argc, char** argv)
             }
             std::vector<const uint16_t*> dp(n_streams); std::vector<const uint8_t*> cp(n_streams);
             for (int s = 0; s < n_streams; s++) { dp[s] = depth[s].data(); cp[s] = color[s].data(); }
-            if (node) {
+            if (voxel_leaf) {
+                for (int s = 0; s < n_streams; s++) {
+                    if (pcs_memcpy_h2d(ctx, d_depth[s], depth[s].data(), depth[s].size() * 2) != PCS_OK ||
+                        pcs_memcpy_h2d(ctx, d_color[s], color[s].data(), color[s].size()) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+                }
+                rc = pcs_process_frames_voxel_device(ctx, reinterpret_cast<const uint16_t* const*>(d_depth.data()),
+                                                     reinterpret_cast<const uint8_t* const*>(d_color.data()), voxel_leaf,
+                                                     static_cast<int16_t*>(d_vox), vox_cap_points * PCS_POINT_SHORTS, static_cast<int32_t*>(d_nvox));
+                if (rc != PCS_OK || !fetch_voxels()) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+            } else if (node) {
                 rc = pcs_node_process(node, dp.data(), cp.data(), stitched.data(), stitched.size(), 1, nullptr, &size_bytes);
                 if (rc != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
             } else {
@@ -221,10 +277,16 @@ int main(int argc, char** argv)
             rc = pcs_stitch_device(ctx, dptr.data(), pts.data(), n_streams, downsample, static_cast<int16_t*>(d_stitched),
                                    (size_t)n_streams * cam_cap_bytes / 2, &total_pts);
             if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
-            size_bytes = total_pts * PCS_POINT_BYTES;
-            if (size_bytes && pcs_memcpy_d2h(ctx, stitched.data() + PCS_HEADER_SHORTS, d_stitched, (size_t)size_bytes) != PCS_OK) return 1;
-            pcs_synchronize(ctx);
-            memcpy(stitched.data(), &size_bytes, sizeof(int));                                             // :394-395
+            if (voxel_leaf) {
+                rc = pcs_voxel_grid_device(ctx, static_cast<const int16_t*>(d_stitched), total_pts, voxel_leaf, static_cast<int16_t*>(d_vox),
+                                           vox_cap_points * PCS_POINT_SHORTS, static_cast<int32_t*>(d_nvox));
+                if (rc != PCS_OK || !fetch_voxels()) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+            } else {
+                size_bytes = total_pts * PCS_POINT_BYTES;
+                if (size_bytes && pcs_memcpy_d2h(ctx, stitched.data() + PCS_HEADER_SHORTS, d_stitched, (size_t)size_bytes) != PCS_OK) return 1;
+                pcs_synchronize(ctx);
+                memcpy(stitched.data(), &size_bytes, sizeof(int));                                         // :394-395
+            }
         }
         if (serve) {
             int req = pcs_wire::recv_pull(client_fd);                                                      // :398
@@ -246,6 +308,10 @@ int main(int argc, char** argv)
     if (client_fd >= 0) ::close(client_fd);
     if (listen_fd >= 0) ::close(listen_fd);
     for (void* p : d_cam) if (p) pcs_device_free(ctx, p);
+    for (void* p : d_depth) if (p) pcs_device_free(ctx, p);
+    for (void* p : d_color) if (p) pcs_device_free(ctx, p);
+    if (d_vox) pcs_device_free(ctx, d_vox);
+    if (d_nvox) pcs_device_free(ctx, d_nvox);
     if (d_stitched) pcs_device_free(ctx, d_stitched);
     if (node) pcs_node_destroy(node);
     pcs_destroy(ctx);

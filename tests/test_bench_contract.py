@@ -55,6 +55,8 @@ def test_bench_line_has_the_contract_keys():
     c5 = d["config5_one_gpu"]
     assert c5["points_in"] == 16 * 1920 * 1080 and 0.85 < c5["points_kept"] / c5["points_in"] < 0.95 and 0 < c5["voxels"] < c5["points_kept"]
     assert c5["pipeline_ms_per_frame_set"] > 0
+    assert c5["one_call"]["voxels"] == c5["voxels"] and c5["one_call"]["ms_per_frame_set"] > 0
+    assert comp["batched"]["frac"] > comp["frac"]
 
 
 def _bench_line(*extra, launcher=()):

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from pointcloud_stitching_amd import synthetic as S
+from pointcloud_stitching_amd.types import FLAG_DROP_INVALID
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI_DIR = os.path.join(ROOT, "pointcloud_stitching_amd", "cli")
@@ -168,6 +169,58 @@ def test_central_all_gpu_mode(oracle):
     finally:
         if p.poll() is None:
             p.kill()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaf,drop,stride", [(50, True, 1), (20, False, 1), (200, True, 3)])
+def test_central_serves_the_voxel_grid(oracle, leaf, drop, stride):
+    """-V <mm>: the consumer receives the voxel-grid downsample of the stitched cloud (BASELINE config 5), produced from
+    the rasters in one device call (>= 36 mm: no stitched cloud in HBM; below, or with a stride: through it)."""
+    port = free_port()
+    args = [CENTRAL, "-i", "synth:160x120", "-N", "3", "-V", str(leaf), "-d", str(stride), "-p", str(port), "-r", "2"] + (["-Z"] if drop else [])
+    p = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        sock = connect(port)
+        for frame in range(2):
+            sock.sendall(b"Z")
+            got = read_frame(sock)
+            cfgs, depth, color = frame_inputs(3, 160, 120, frame, single=False)
+            stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID if drop else 0, stride)
+            want = oracle.voxel_grid(stitched, leaf)
+            assert got.shape == want.shape and (got == want).all()
+        sock.close()
+        _, err = p.communicate(timeout=60)
+        assert p.returncode == 0, err
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.gpu
+def test_central_voxel_grid_of_edge_payloads(oracle):
+    """-c + -V: two edge servers' payloads are concatenated on the GPU and their voxel grid is served."""
+    p1, p2, p3 = free_port(), free_port(), free_port()
+    edges = [subprocess.Popen([EDGE, "-f", "synth:128x96", "-m", "-r", "3", "-p", str(p), "-P"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for p in (p1, p2)]
+    central = None
+    try:
+        time.sleep(0.5)
+        central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-V", "100", "-p", str(p3), "-r", "1"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        consumer = connect(p3)
+        consumer.sendall(b"Z")
+        got = read_frame(consumer)
+        consumer.close()
+        cfgs, depth, color = frame_inputs(1, 128, 96, 0, single=True)
+        cam, _ = oracle.process_frames(cfgs, depth, color)
+        want = oracle.voxel_grid(oracle.stitch([cam, cam], 1), 100)      # both edges run the same single-camera config
+        assert got.shape == want.shape and (got == want).all()
+        _, err = central.communicate(timeout=60)
+        assert central.returncode == 0, err
+    finally:
+        for p in edges + ([central] if central else []):
+            if p.poll() is None:
+                p.kill()
 
 
 @pytest.mark.gpu
