@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--payload-skew", type=int, default=0,
                     help="diagnostic: offset the payload pointer by this many bytes (4 = the reference's buffer+2 shorts) "
                          "to force the generic (unaligned) store path")
-    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff", "pack", "pack_batch", "batch"], default="dense",
+    ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff", "pack", "pack_batch", "batch", "batch_drop_invalid"], default="dense",
                     help="diagnostic: make another kernel the headline of the line (for profiling one kernel at a time): "
                          "the compaction path, the a2 twin per stream / batched, or K frame-sets per launch")
     ap.add_argument("--batch-sets", type=int, default=4, help="frame-sets per launch of the batched-dense leg")
@@ -256,7 +256,7 @@ def main():
     set_points = S * npts
     # global camera index = rank*S + s  -> extrinsic transform[(rank*S+s) % 8], distinct seeds per camera
     cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
-    mode_flags = {"drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}.get(args.mode, 0)
+    mode_flags = {"drop_invalid": FLAG_DROP_INVALID, "batch_drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}.get(args.mode, 0)
     ctx = PcsContext(cfgs, device=local_rank, flags=mode_flags)
     # One explicit HIP stream for everything this rank enqueues: the library's kernels (pcs_set_stream) and torch's own
     # work — the RCCL gather orders itself against torch's CURRENT stream. (torch's default stream has the handle 0, which
@@ -395,13 +395,14 @@ def main():
         pp = (VP * KB)(*[d_out[sl].data_ptr() for sl in slots])
         batch_args.append((dp, cp, pp))
 
-    def launch_batch():
+    def launch_batch(c=None):
+        c = c or (ctx if args.mode == "batch_drop_invalid" else ctx0)
         dp, cp, pp = batch_args[next_slot(len(batch_args))]
-        check(lib.pcs_process_frames_device_batch(ctx0._h, KB, dp, cp, pp, payload_shorts, None), ctx0._h)
+        check(lib.pcs_process_frames_device_batch(c._h, KB, dp, cp, pp, payload_shorts, None), c._h)
 
     launch = {"dense": launch_dense, "drop_invalid": launch_dense, "cutoff": launch_dense, "pack": launch_pack_single,
-              "pack_batch": launch_pack_batch, "batch": launch_batch}[args.mode]
-    sets_per_launch = KB if args.mode == "batch" else 1
+              "pack_batch": launch_pack_batch, "batch": launch_batch, "batch_drop_invalid": launch_batch}[args.mode]
+    sets_per_launch = KB if args.mode in ("batch", "batch_drop_invalid") else 1
 
     pending = [None, None]
     red_dev = torch.device("cpu") if debug_gloo else dev      # where the tiny control reductions live
@@ -550,7 +551,7 @@ def main():
             roofline_timing = ("hipEvent pair on the launch stream around the same K launches WITHOUT the gather (rank 0); "
                                "the timed region's bracket includes waits for the exchange")
         bytes_pp = {"pack": PACK_BYTES_PER_POINT, "pack_batch": PACK_BYTES_PER_POINT,
-                    "drop_invalid": 5 + 10 * kept_frac}.get(args.mode, ALGO_BYTES_PER_POINT)
+                    "drop_invalid": 5 + 10 * kept_frac, "batch_drop_invalid": 5 + 10 * kept_frac}.get(args.mode, ALGO_BYTES_PER_POINT)
         algo_bytes = set_points * sets_per_launch * bytes_pp
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         where = ("one GPU" if world == 1 else f"{world} GPUs, {S} per GPU") if strong else f"per GPU x {world} GPUs"
@@ -582,6 +583,7 @@ def main():
                          "kernel": {"dense": "pcs_fused_dense_kernel", "batch": "pcs_fused_dense_batch_kernel",
                                     "pack": "pcs_pack_dense_kernel", "pack_batch": "pcs_pack_batch_kernel",
                                     "drop_invalid": "pcs_fused_count_kernel + pcs_scan_kernel + pcs_fused_emit_kernel (PCS_COMPACT_PATH=single: pcs_fused_compact_kernel)",
+                                    "batch_drop_invalid": "pcs_fused_count_batch_kernel + pcs_scan_batch_kernel + pcs_fused_emit_batch_kernel",
                                     "cutoff": "pcs_fused_count_kernel + pcs_scan_kernel + pcs_fused_emit_kernel (PCS_COMPACT_PATH=single: pcs_fused_compact_kernel)"}[args.mode],
                          "arithmetic": policy, "avg_launch_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": round(algo_bytes),
@@ -607,6 +609,8 @@ def main():
                 "pack_batch": "diagnostic: a2 twin from resident vertices/texcoords, all streams in one launch, 33 B/point",
                 "batch": f"diagnostic: {KB} frame-sets per launch (pcs_process_frames_device_batch)",
                 "drop_invalid": f"diagnostic: ordered invalid-depth compaction, kept fraction {kept_frac:.4f}, (5 + 10 rho) B/point",
+                "batch_drop_invalid": f"diagnostic: ordered invalid-depth compaction of {KB} frame-sets per call (three launches for all of them), "
+                                      f"kept fraction {kept_frac:.4f}, (5 + 10 rho) B/point",
                 "cutoff": "diagnostic: ordered -c cutoff compaction (bytes priced as the dense kernel's 15 B/point: upper bound)",
             }[args.mode]
             out["roofline"]["traffic"] = None

@@ -22,15 +22,16 @@ RUNS[cutoff]="$BENCH --mode cutoff"
 RUNS[pack]="$BENCH --mode pack"
 RUNS[pack_batch]="$BENCH --mode pack_batch"
 RUNS[batch]="$BENCH --mode batch"
+RUNS[batch_drop_invalid]="$BENCH --mode batch_drop_invalid"
 RUNS[voxel]="python $PWD/tools/voxel_bench.py 16 1920 1080 50,200"
-ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch voxel"
+ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch batch_drop_invalid voxel"
 cd /tmp
 for R in $ORDER; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -- ${RUNS[$R]} > $OUT/stats_$R.log 2>&1
   echo "stats $R rc=$?"
 done
 # PMC passes (their own runs, --pmc + --kernel-trace only): HBM traffic for every family, the instruction mix for the headline
-for R in dense drop_invalid pack_batch batch voxel; do
+for R in dense drop_invalid pack_batch batch batch_drop_invalid voxel; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${R}_$C -- ${RUNS[$R]} > $OUT/pmc_${R}_$C.log 2>&1
     echo "pmc $R $C rc=$?"
@@ -94,6 +95,10 @@ for k, cs in summ.get("dense", {}).items():
                    "write_size_kib": cs["WRITE_SIZE"]["mean"], "fetch_correction": 2.0,
                    "traffic_bytes_per_launch": cs["traffic_bytes_per_launch"],
                    "algorithmic_bytes_per_launch": 8 * 1280 * 720 * 15}, open(out + "/traffic.json", "w"), indent=1)
+import shutil
+for d in glob.glob(out + "/stats_*") + glob.glob(out + "/pmc_*"):     # raw rocprofv3 output: hundreds of MB; the summaries above are what is kept
+    if os.path.isdir(d):
+        shutil.rmtree(d, ignore_errors=True)
 for r in rows:
     print(f"{r['run']:22s} {r['kernel'][:90]:90s} calls {r['calls']:>6s} avg {float(r['avg_ns'])/1e3:9.2f} us")
 PY
