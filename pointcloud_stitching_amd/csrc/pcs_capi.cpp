@@ -1345,11 +1345,15 @@ try {
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every pixel its own voxel) needs %zu",
                     out_shorts, cap * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
-    // Below ~36 mm (on the synthetic scene) a 4096-pixel round holds more voxels than a workgroup's LDS table takes
-    // gracefully; the payload reader, fed by the ordered compaction, then is the faster route (16 x 1080p at 25 mm:
-    // 0.93 ms vs 1.11 ms). Same result either way. PCS_VOXEL_FUSED=0/1 forces one or the other.
+    // Rasters whose width is a multiple of 8 are read in square patches and the direct route wins at every leaf
+    // (16 x 1080p: 0.26 vs 0.46 ms at 50 mm, 0.52 vs 0.91 ms at 25 mm, 1.64 vs 2.57 ms at 10 mm). Other rasters are read
+    // in runs of 4096 consecutive pixels; below ~36 mm (on the synthetic scene) such a run holds more voxels than a
+    // workgroup's LDS table takes gracefully and the payload reader, fed by the ordered compaction, is the faster route
+    // (25 mm: 0.93 vs 1.11 ms). Same result either way. PCS_VOXEL_FUSED=0/1 forces one or the other.
     static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
-    const bool fused = fused_env >= 0 ? fused_env != 0 : leaf_mm >= 36;
+    bool all_patch = true;
+    for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
+    const bool fused = fused_env >= 0 ? fused_env != 0 : (all_patch || leaf_mm >= 36);
     if (c->downsample != 1 || !fused) {
         // (the stride is defined on the ORDER of the kept points: build the stitched cloud, then its voxel grid)
         int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
@@ -1373,15 +1377,18 @@ try {
     for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
         const int nl = std::min(kLaunchStreams, S - s0);
         FramePtrs fp{};
-        uint32_t mp = 0;
-        bool fast = true, ident = true;
+        uint32_t mp = 0, mw = 0, mh = 0;
+        bool fast = true, ident = true, patch_ok = true;
         for (int k = 0; k < nl; k++) {
+            const StreamParams& q = c->h_params[s0 + k];
             fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
-            mp = std::max(mp, c->h_params[s0 + k].n_points);
-            fast &= c->h_params[s0 + k].cert_fast != 0; ident &= c->h_params[s0 + k].ident_r != 0;
+            mp = std::max(mp, q.n_points);
+            mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
+            patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
+            fast &= q.cert_fast != 0; ident &= q.ident_r != 0;
         }
         const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
-        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, c->flags, sel, fp, vs, c->stream));
+        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->flags, sel, fp, vs, c->stream));
     }
     HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out, d_out_points, c->stream));
     if (c->kernel_timing) {

@@ -178,9 +178,10 @@ struct VoxelStage {
 hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
 hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
                         int32_t* d_out_points, hipStream_t st);
+// max_w / max_h: the largest raster of the launch; patch_ok: every raster's width is a multiple of 8 (square patches)
 hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                                       uint32_t flags, MathSel math, const FramePtrs& fp, const VoxelStage& vs,
-                                       hipStream_t st);
+                                       uint32_t max_w, uint32_t max_h, bool patch_ok, uint32_t flags, MathSel math,
+                                       const FramePtrs& fp, const VoxelStage& vs, hipStream_t st);
 
 // a7 with stride.
 hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,

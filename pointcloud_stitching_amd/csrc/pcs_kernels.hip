@@ -1187,19 +1187,31 @@ constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 
 template <class Mth>
 __global__ __launch_bounds__(kVoxThreads)
 void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
-                                     VoxelStage vs, int rounds)
+                                     VoxelStage vs, int rounds, int rx)
 {
+    // slot = key + the seven sums in three 64-bit words and one 32-bit word: (x, y), (z, count), (R, G), B — four LDS
+    // adds per run instead of seven. Coordinates are summed BIASED (+32768, so every term is non-negative and a
+    // 64-bit add never carries between its halves: <= 32 768 points x 65 535 < 2^31); the bias leaves at the output.
     __shared__ unsigned long long skey[kSlots];
-    __shared__ int          ssx[kSlots], ssy[kSlots], ssz[kSlots];
-    __shared__ unsigned int sr[kSlots], sg[kSlots], sb[kSlots], sn[kSlots];
+    __shared__ unsigned long long sxy[kSlots], szn[kSlots], srg[kSlots];
+    __shared__ unsigned int sbl[kSlots];
     __shared__ unsigned int wtot[kVoxThreads / 64];
     __shared__ unsigned int base_s;
 
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
     const uint32_t n = P.n_points;
+    // Which pixels a round takes. rx == 0: 4096 consecutive pixels (any raster). rx > 0 (rasters whose width is a
+    // multiple of 8): a 64 x 64-pixel SQUARE — 8 lanes x 8 pixels per row, 64 rows; a wavefront's loads still cover
+    // 8 full 128-byte lines of Z16 — and the workgroup's rounds tile an (rx x rounds/rx) block of such squares. A
+    // voxel of a few dozen pixels across lies inside ONE square patch but in three or four 8-row strips, so the same
+    // pixels leave 2.2x (50 mm) to 4x (200 mm) fewer partials behind for the sort.
+    const uint32_t W = (uint32_t)P.W, Hh = n / W;
+    const uint32_t patches_x = rx ? (W + 64u * (uint32_t)rx - 1u) / (64u * (uint32_t)rx) : 1u;
+    const uint32_t ry = rx ? (uint32_t)rounds / (uint32_t)rx : 1u;
+    const uint32_t px = rx ? blockIdx.x % patches_x : 0u, py = rx ? blockIdx.x / patches_x : 0u;
     const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
-    if (tile0 >= n) return;
+    if (rx ? (py * 64u * ry >= Hh) : (tile0 >= n)) return;
     const uint8_t* __restrict__ color = fp.color[s];
     DepthSource<true, true, Mth> src{fp.depth[s]};
     const VoxelDiv dv{vs.leaf, vs.bias_leaf, vs.magic};
@@ -1209,13 +1221,20 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
 
     for (int j = threadIdx.x; j < kSlots; j += kVoxThreads) {
         skey[j] = kEmptyKey;
-        ssx[j] = ssy[j] = ssz[j] = 0;
-        sr[j] = sg[j] = sb[j] = sn[j] = 0u;
+        sxy[j] = szn[j] = srg[j] = 0ull;
+        sbl[j] = 0u;
     }
     __syncthreads();
 
     for (int round = 0; round < rounds; round++) {
-        const uint32_t i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
+        uint32_t i0;
+        if (rx) {
+            const uint32_t row = (py * ry + (uint32_t)round / (uint32_t)rx) * 64u + (threadIdx.x >> 3);
+            const uint32_t col = (px * (uint32_t)rx + (uint32_t)round % (uint32_t)rx) * 64u + (threadIdx.x & 7u) * 8u;
+            i0 = (row < Hh && col < W) ? row * W + col : n;        // W % 8 == 0: a lane is inside the row or outside it
+        } else {
+            i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
+        }
         PointIn p[8];
         src.load8(P, i0, n, p, nullptr);
         const uint32_t keep = keep_mask8(p, i0, n, flags);
@@ -1242,7 +1261,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             return voxel_key(dv, (int)(short)(r.xy & 0xFFFFu), (int)(short)(r.xy >> 16), (int)(short)(r.zc & 0xFFFFu), bits);
         };
         // runs of equal keys among the lane's 8 pixels: summed in registers, the run's LAST point adds them to the table
-        int ax = 0, ay = 0, az = 0;
+        unsigned int ax = 0, ay = 0, az = 0;                     // biased: sums of (coordinate + 32768)
         unsigned int ar = 0, ag = 0, ab = 0, an = 0, failed = 0;
         bool cont = false;                                       // point k continues the run of point k-1
         unsigned long long kcur = key_of(rec[0]);
@@ -1253,8 +1272,8 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             const unsigned long long knext = k < 7 ? key_of(rec[k + 1]) : 0ull;
             const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
             const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
-            if (!cont) { ax = ay = az = 0; ar = ag = ab = an = 0u; }
-            ax += x; ay += y; az += z;
+            if (!cont) { ax = ay = az = 0u; ar = ag = ab = an = 0u; }
+            ax += (unsigned int)(x + 32768); ay += (unsigned int)(y + 32768); az += (unsigned int)(z + 32768);
             ar += col & 0xFFu; ag += col >> 8; ab += blue; an += 1u;
             const bool same_next = live_next && knext == kcur;
             const bool actor = live && !same_next;
@@ -1268,8 +1287,10 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
                     h = pr.next(h);
                 }
                 if (placed) {
-                    atomicAdd(&ssx[h], ax); atomicAdd(&ssy[h], ay); atomicAdd(&ssz[h], az);
-                    atomicAdd(&sr[h], ar); atomicAdd(&sg[h], ag); atomicAdd(&sb[h], ab); atomicAdd(&sn[h], an);
+                    atomicAdd(&sxy[h], (unsigned long long)ax | ((unsigned long long)ay << 32));
+                    atomicAdd(&szn[h], (unsigned long long)az | ((unsigned long long)an << 32));
+                    atomicAdd(&srg[h], (unsigned long long)ar | ((unsigned long long)ag << 32));
+                    atomicAdd(&sbl[h], ab);
                 } else {
                     failed |= 1u << k;                           // the run ending at k goes out as a partial of its own
                 }
@@ -1330,7 +1351,11 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
         if (skey[j] != kEmptyKey) {
             if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
             else { vs.keys[pos] = skey[j]; vs.idx[pos] = pos; }
-            part[pos] = VoxelPartial{ssx[j], ssy[j], ssz[j], sr[j], sg[j], sb[j], sn[j], 0u};
+            const unsigned long long xy = sxy[j], zn = szn[j], rg = srg[j];
+            const unsigned int cnt = (unsigned int)(zn >> 32);
+            const int bias = (int)(cnt << 15);                   // count x 32768 (count <= 32 768)
+            part[pos] = VoxelPartial{(int)(unsigned int)xy - bias, (int)(unsigned int)(xy >> 32) - bias, (int)(unsigned int)zn - bias,
+                                     (unsigned int)rg, (unsigned int)(rg >> 32), sbl[j], cnt, 0u};
             pos++;
         }
     }
@@ -1623,24 +1648,45 @@ hipError_t launch_compact_batch(const StreamParams* d_params, int n_streams, int
 }
 
 hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                                       uint32_t flags, MathSel math, const FramePtrs& fp, const VoxelStage& vs, hipStream_t st)
+                                       uint32_t max_w, uint32_t max_h, bool patch_ok, uint32_t flags, MathSel math,
+                                       const FramePtrs& fp, const VoxelStage& vs, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     static const int env_rounds = [] { const char* v = getenv("PCS_VOXEL_ROUNDS"); return v ? atoi(v) : 0; }();
+    static const int env_patch = [] { const char* v = getenv("PCS_VOXEL_PATCH"); return v ? atoi(v) : 1; }();
     // Rounds (4096 pixels each) that share one 2048-slot table. More rounds = fewer partials for the sort, as long as
     // the voxels under one table stay below its slots: a leaf spans leaf / (depth / focal) pixels, so the voxels per
-    // round fall roughly with the square of the leaf. Tuned on the synthetic scene (0.5 - 4.5 m, fx = 0.7 W: 1 400 /
-    // 740 / 370 voxels per round at 25 / 50 / 100 mm; 16 x 1080p, ms per frame-set at 2 / 3 / 4 / 8 rounds: 35 mm
-    // 0.57 / 0.50 / 0.51 / -, 50 mm 0.42 / 0.39 / 0.34 / 0.43, 200 mm 0.25 / - / 0.22 / 0.22). A wrong guess costs
-    // speed, never correctness (runs that find no slot go out as partials of their own). Capped so that the launch
-    // still fills the chip twice over.
+    // round fall roughly with the square of the leaf. A wrong guess costs speed, never correctness (runs that find no
+    // slot go out as partials of their own). Capped so that the launch still fills the chip twice over. The packed sums
+    // of the table hold at most 8 rounds.
     const uint64_t launch_tiles = (uint64_t)((max_points + kVoxRoundPoints - 1) / kVoxRoundPoints) * (uint64_t)n_launch;
-    const uint64_t by_leaf = std::min<uint64_t>(8, std::max<uint64_t>(3, ((uint64_t)vs.leaf * vs.leaf) / 625u));
-    int rounds = (int)std::min<uint64_t>(by_leaf, std::max<uint64_t>(1, launch_tiles / 1024));
-    if (env_rounds > 0) rounds = env_rounds;
-    const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
-    const dim3 grid((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
-#define L(M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds)
+    const uint64_t fill_cap = std::max<uint64_t>(1, launch_tiles / 1024);
+    int rounds, rx = 0;
+    if (patch_ok && env_patch) {
+        // square patches: 64 x 64 per round, (rx x ry) rounds per workgroup. 16 x 1080p, ms per frame-set with 1 / 2 / 4 /
+        // 8 rounds: 10 mm 1.64 / 1.84 / - / -, 25 mm 0.52 / 0.53 / - / -, 36 mm 0.33 / 0.32 / 0.34 / 0.46, 50 mm 0.30 / 0.26 /
+        // 0.28 / 0.33, 100 mm 0.26 / 0.23 / 0.23 / 0.25, 200 mm 0.26 / 0.23 / 0.23 / 0.24: two squares (128 x 64) per table
+        // from 30 mm up, one below. (Voxels per 128 x 64 patch on the synthetic scene: 780 / 240 / 80 / 30 at 25 / 50 /
+        // 100 / 200 mm.)
+        const uint64_t by_leaf = vs.leaf >= 30 ? 2 : 1;
+        rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);
+        rounds = rounds >= 8 ? 8 : rounds >= 4 ? 4 : rounds >= 2 ? 2 : 1;
+        if (env_rounds > 0) rounds = env_rounds >= 8 ? 8 : env_rounds >= 4 ? 4 : env_rounds >= 2 ? 2 : 1;
+        rx = rounds == 8 ? 4 : rounds >= 2 ? 2 : 1;
+    } else {
+        const uint64_t by_leaf = std::min<uint64_t>(8, std::max<uint64_t>(3, ((uint64_t)vs.leaf * vs.leaf) / 625u));
+        rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);
+        if (env_rounds > 0) rounds = std::min(env_rounds, 8);
+    }
+    dim3 grid;
+    if (rx) {
+        const uint32_t ry = (uint32_t)rounds / (uint32_t)rx;
+        grid = dim3(((max_w + 64u * rx - 1) / (64u * rx)) * ((max_h + 64u * ry - 1) / (64u * ry)), (unsigned)n_launch, 1);
+    } else {
+        const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
+        grid = dim3((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
+    }
+#define L(M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
     if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
 #undef L

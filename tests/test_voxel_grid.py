@@ -224,8 +224,9 @@ def _rasters_to_voxels(ctx, dd, dc, leaf, n_max):
 def test_rasters_to_voxel_grid_equals_stitch_then_voxel_grid(oracle, flags, shapes):
     """pcs_process_frames_voxel_device never writes the stitched cloud; its voxels must be exactly those of the oracle's
     voxel grid over the oracle's stitched cloud (same flags), for leaves from 'every point its own voxel' to 'one voxel'.
-    Ragged rasters (321 x 243: rows not a multiple of 8, last workgroup partly empty), a raster smaller than one lane's
-    8 pixels, a raster larger than a workgroup's 8192 pixels."""
+    Widths that are multiples of 8 are read in 64 x 64 squares (640 x 480: ragged last patch row; 1920 x 1080: many
+    patches; 8 x 1: smaller than one lane's 8 pixels); the mixed set holds a 321-wide raster, so the whole frame-set is
+    read in runs of consecutive pixels and, below 36 mm, through the internal stitched cloud."""
     cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
     depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
     color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
@@ -262,9 +263,8 @@ def test_rasters_to_voxel_grid_nothing_kept_and_stride(oracle):
 @pytest.mark.gpu
 def test_rasters_to_voxel_grid_full_table_passes_points_through(oracle):
     """Uniformly random depth (0 .. 65 m): neighbouring pixels are metres apart, so practically every pixel is its own
-    voxel even at 40 / 64 mm — the leaves at which the one-call form reads the rasters directly — and the 2048-slot LDS
-    table of a workgroup overflows: most runs take the pass-through route. (Below 36 mm the call goes through the
-    internal stitched cloud; leaves 1 and 3 cover that route on the same input.)"""
+    voxel and the 2048-slot LDS table of a workgroup overflows: most runs take the pass-through route (square-patch
+    reader: the raster's width is a multiple of 8)."""
     cfgs = [S.synth_stream_config(640, 480, 0)]
     rng = np.random.default_rng(5)
     depth = [rng.integers(0, 65536, 640 * 480, dtype=np.uint16)]
@@ -276,6 +276,42 @@ def test_rasters_to_voxel_grid_full_table_passes_points_through(oracle):
             got = _rasters_to_voxels(ctx, dd, dc, leaf, cfgs[0].n_points)
             want = oracle.voxel_grid(stitched, leaf)
             assert got.shape == want.shape and (got == want).all(), leaf
+
+
+@pytest.mark.gpu
+def test_rasters_to_voxel_grid_random_configurations(oracle):
+    """Random raster sizes (multiples of 8 or not, down to a single row / column), leaves, flags and scenes."""
+    rng = np.random.default_rng(20260928)
+    for trial in range(40):
+        n = int(rng.integers(1, 4))
+        shapes = []
+        for s in range(n):
+            w = int(rng.choice([8, 16, 64, 72, 200, 320, 333, 640, 1]) if rng.random() < 0.7 else rng.integers(1, 700))
+            h = int(rng.choice([1, 2, 63, 64, 65, 129, 240]) if rng.random() < 0.7 else rng.integers(1, 300))
+            shapes.append((max(w, 2) if h == 1 else w, h))                       # pcs_create refuses a colour raster of < 4 bytes
+        if rng.random() < 0.5:
+            shapes = [(w - w % 8 if w >= 8 else 8, h) for w, h in shapes]        # all multiples of 8: the square-patch reader
+        flags = int(rng.choice([0, FLAG_DROP_INVALID, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, FLAG_CUTOFF | FLAG_DROP_INVALID]))
+        leaf = int(rng.choice([1, 2, 5, 13, 29, 30, 36, 50, 77, 200, 1000, 32767]))
+        cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+        depth = []
+        for s, (w, h) in enumerate(shapes):
+            kind = rng.random()
+            if kind < 0.6:
+                d = S.synth_depth(w, h, s, seed=int(rng.integers(1, 1 << 30)))
+            elif kind < 0.8:
+                d = rng.integers(0, 65536, w * h, dtype=np.uint16)
+            else:
+                d = np.full(w * h, int(rng.integers(0, 3000)), np.uint16)              # a wall (or nothing at all)
+            depth.append(np.ascontiguousarray(d, np.uint16).reshape(-1))
+        color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+        n_max = sum(c.n_points for c in cfgs)
+        stitched, _ = oracle.process_frames(cfgs, depth, color, flags)
+        want = oracle.voxel_grid(stitched, leaf)
+        with PcsContext(cfgs, flags=flags) as ctx:
+            dd, dc = _upload_rasters(ctx, depth, color)
+            got = _rasters_to_voxels(ctx, dd, dc, leaf, n_max)
+        assert got.shape == want.shape and (got == want).all(), (trial, shapes, flags, leaf, got.shape, want.shape)
 
 
 @pytest.mark.gpu
