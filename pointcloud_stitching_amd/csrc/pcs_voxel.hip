@@ -26,6 +26,7 @@
 // Integer sums make the result independent of the order of the partials and of any reduction order.
 // (Round 1 used rocPRIM's radix_sort_pairs + reduce_by_key for steps 2-3: 0.56 ms of library kernels per call at 50 mm,
 // plus a stream synchronisation in the middle of the call to learn m.)
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -257,6 +258,16 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
 // ------------------------------------------------------------------------------------------------
 constexpr int kRadixBits = 11, kRadix = 1 << kRadixBits;
 constexpr unsigned int kSortChunk = 8192, kSortThreads = 512, kSortWaves = kSortThreads / 64, kSortGrid = 4096, kSortBatch = 8;
+constexpr unsigned int kSortMinChunk = 1024, kSortMinRows = 256;
+
+// Elements per chunk (= per workgroup pass), chosen ON THE DEVICE from the number of partials so that a small sort still
+// spreads over 128 - 256 workgroups: 8192 from 1 M elements up, halving down to 1024 below 256 k (the 125 k partials
+// of a 200 mm grid were 15 chunks of 8192: three 27 us passes on 15 CUs). More, smaller chunks cost the column scan more
+// than they save the scatter (0.9 M elements as 440 chunks of 2048: scatter 16.5 -> 12.9 us, column scan 5.8 -> 14.2 us).
+__device__ __forceinline__ unsigned int sort_chunk_of(unsigned int m)
+{
+    return m >= (1u << 20) ? 8192u : m >= (512u << 10) ? 4096u : m >= (256u << 10) ? 2048u : 1024u;
+}
 
 __device__ __forceinline__ unsigned int digit_of(unsigned long long key, unsigned int shift) { return (unsigned int)(key >> shift) & (kRadix - 1); }
 
@@ -267,22 +278,23 @@ void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys, const un
 {
     __shared__ unsigned int hist[kRadix];
     const unsigned int m = *m_ptr;
-    const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
+    const unsigned int csize = sort_chunk_of(m), per_thread = csize / kSortThreads;
+    const unsigned int chunks = (m + csize - 1) / csize;
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         for (unsigned int j = threadIdx.x; j < kRadix; j += kSortThreads) hist[j] = 0u;
         __syncthreads();
-        const unsigned int c0 = chunk * kSortChunk;
-        for (unsigned int it0 = 0; it0 < kSortChunk / kSortThreads; it0 += kSortBatch) {
+        const unsigned int c0 = chunk * csize, c1 = min(c0 + csize, m);
+        for (unsigned int it0 = 0; it0 < per_thread; it0 += kSortBatch) {
             unsigned long long k[kSortBatch];       // the batch's loads are in flight together
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = c0 + (it0 + q) * kSortThreads + threadIdx.x;
-                k[q] = e < m ? keys[e] : 0ull;
+                k[q] = e < c1 ? keys[e] : 0ull;
             }
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = c0 + (it0 + q) * kSortThreads + threadIdx.x;
-                if (e < m) atomicAdd(&hist[digit_of(k[q], shift)], 1u);
+                if (e < c1) atomicAdd(&hist[digit_of(k[q], shift)], 1u);
             }
         }
         __syncthreads();
@@ -298,8 +310,40 @@ void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned i
                               unsigned int* __restrict__ digit_total)
 {
     constexpr unsigned int kCols = 16;
+    __shared__ unsigned int tot[16][16];
     const unsigned int m = *m_ptr;
-    const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
+    const unsigned int csize = sort_chunk_of(m);
+    const unsigned int chunks = (m + csize - 1) / csize;
+    if (chunks <= 256u) {
+        // Few rows (every sort below 2 M elements): 16 digits per workgroup, 16 row slots (4 per wavefront, 16 lanes = 64
+        // contiguous bytes each) of <= 16 consecutive rows. A lane requests all its rows at once, keeps them in registers,
+        // the slots' totals cross through LDS, and the prefixes are written from the registers: one round trip to memory
+        // instead of one per 64 rows of a strided column (220 rows: 9.5 -> ~4 us per pass).
+        if (blockIdx.x >= kRadix / 16) return;
+        const unsigned int d = blockIdx.x * 16u + (threadIdx.x & 15u), slot = threadIdx.x >> 4;
+        const unsigned int rps = (chunks + 15u) / 16u, r0 = slot * rps;
+        unsigned int v[16], sum = 0;
+#pragma unroll
+        for (unsigned int j = 0; j < 16; j++) {
+            const unsigned int r = r0 + j;
+            v[j] = (j < rps && r < chunks) ? table[(size_t)r * kRadix + d] : 0u;
+        }
+#pragma unroll
+        for (unsigned int j = 0; j < 16; j++) sum += v[j];
+        tot[slot][threadIdx.x & 15u] = sum;
+        __syncthreads();
+        unsigned int run = 0, all = 0;
+#pragma unroll
+        for (unsigned int q = 0; q < 16; q++) { const unsigned int t = tot[q][threadIdx.x & 15u]; run += q < slot ? t : 0u; all += t; }
+#pragma unroll
+        for (unsigned int j = 0; j < 16; j++) {
+            const unsigned int r = r0 + j;
+            if (j < rps && r < chunks) table[(size_t)r * kRadix + d] = run;
+            run += v[j];
+        }
+        if (slot == 0) digit_total[d] = all;
+        return;
+    }
     const unsigned int digit = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     unsigned int carry = 0;
     for (unsigned int c0 = 0; c0 < chunks; c0 += 64 * kCols) {
@@ -342,7 +386,8 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
     __shared__ unsigned int dbase[kRadix];       //  8 KiB
     __shared__ unsigned int wsum[kSortWaves];
     const unsigned int m = *m_ptr;
-    const unsigned int chunks = (m + kSortChunk - 1) / kSortChunk;
+    const unsigned int csize = sort_chunk_of(m);
+    const unsigned int chunks = (m + csize - 1) / csize;
     if (blockIdx.x >= chunks) return;
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     constexpr unsigned int kPer = kRadix / kSortThreads;      // 4 consecutive digits per thread
@@ -364,20 +409,21 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         for (unsigned int j = threadIdx.x; j < kSortWaves * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
         __syncthreads();
-        const unsigned int w0 = chunk * kSortChunk + wave * (kSortChunk / kSortWaves);
+        const unsigned int w0 = chunk * csize + wave * (csize / kSortWaves);
+        const unsigned int w1 = min(w0 + csize / kSortWaves, m);               // this wavefront's elements: [w0, w1)
         // count: this wavefront's occurrences of every digit
-        constexpr unsigned int kRounds = kSortChunk / kSortWaves / 64;
+        const unsigned int kRounds = csize / kSortWaves / 64;                  // 2 .. 16
         for (unsigned int r0 = 0; r0 < kRounds; r0 += kSortBatch) {
             unsigned long long k[kSortBatch];
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                k[q] = e < m ? keys_in[e] : 0ull;
+                k[q] = e < w1 ? keys_in[e] : 0ull;
             }
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                if (e < m) atomicAdd(&cnt[wave][digit_of(k[q], shift)], 1u);
+                if (e < w1) atomicAdd(&cnt[wave][digit_of(k[q], shift)], 1u);
             }
         }
         __syncthreads();
@@ -396,12 +442,12 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
                 k[q] = 0ull; id[q] = 0u;
-                if (e < m) { k[q] = keys_in[e]; if (!PACKED) id[q] = idx_in[e]; }
+                if (e < w1) { k[q] = keys_in[e]; if (!PACKED) id[q] = idx_in[e]; }
             }
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                const bool live = e < m;
+                const bool live = e < w1;
                 const unsigned int d = digit_of(k[q], shift);
                 unsigned long long peers = __ballot(live);
 #pragma unroll
@@ -635,7 +681,10 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.idx_a = (unsigned int*)take(n * 4);
     w.idx_b = (unsigned int*)take(n * 4);
     w.part = (VoxelPartial*)take(n * sizeof(VoxelPartial));
-    w.table = (unsigned int*)take(((n + kSortChunk - 1) / kSortChunk) * (size_t)kRadix * 4);
+    {   // rows of the histogram table: m / sort_chunk_of(m) is at most kSortMinRows below 4 M partials, m / 8192 above
+        const size_t rows = std::max<size_t>((n + kSortChunk - 1) / kSortChunk, std::min<size_t>(kSortMinRows, (n + kSortMinChunk - 1) / kSortMinChunk));
+        w.table = (unsigned int*)take(rows * (size_t)kRadix * 4);
+    }
     w.digit_total = (unsigned int*)take((size_t)kRadix * 4);
     w.heads = (unsigned int*)take(((n + kSegThreads - 1) / kSegThreads) * 4);
     w.lead = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
@@ -702,7 +751,8 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     const unsigned int* m_ptr = w.ctl;
 
     // grids sized for what the launch can need at most, capped: the kernels loop over chunks / blocks
-    const unsigned int max_chunks = (n_points + kSortChunk - 1) / kSortChunk;
+    const unsigned int max_chunks = std::max((n_points + kSortChunk - 1) / kSortChunk,
+                                             std::min(kSortMinRows, (n_points + kSortMinChunk - 1) / kSortMinChunk));
     const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
     for (unsigned int pass_bit = 0; pass_bit < 3u * bits; pass_bit += kRadixBits) {
         const unsigned int shift = pass_bit + idx_bits;
