@@ -1280,11 +1280,15 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             if (actor) {
                 const VoxelProbe pr(kcur);
                 unsigned int h = pr.first;
-                bool placed = false;
-                for (int t = 0; t < kProbe; t++) {
-                    const unsigned long long old = atomicCAS(&skey[h], kEmptyKey, kcur);
-                    if (old == kEmptyKey || old == kcur) { placed = true; break; }
-                    h = pr.next(h);
+                // first probe straight-line (it succeeds for all but a few per cent of the runs), the rest in a loop
+                unsigned long long old = atomicCAS(&skey[h], kEmptyKey, kcur);
+                bool placed = old == kEmptyKey || old == kcur;
+                if (__builtin_expect(!placed, 0)) {
+                    for (int t = 1; t < kProbe; t++) {
+                        h = pr.next(h);
+                        old = atomicCAS(&skey[h], kEmptyKey, kcur);
+                        if (old == kEmptyKey || old == kcur) { placed = true; break; }
+                    }
                 }
                 if (placed) {
                     atomicAdd(&sxy[h], (unsigned long long)ax | ((unsigned long long)ay << 32));

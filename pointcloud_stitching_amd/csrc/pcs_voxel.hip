@@ -188,6 +188,8 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
         unsigned int h = pr.first;
         bool placed = false;
         if (actor) {
+            // (Peeling the first probe out of the loop, which helps the raster reader, costs this kernel a third: 143 -> 195 us.
+            // The extra branch ends the overlap of the eight iterations — the same effect as every other branch tried here.)
             for (int t = 0; t < kProbe; t++) {
                 const unsigned long long old = atomicCAS(&skey[h], kEmptyKey, key);
                 if (old == kEmptyKey || old == key) { placed = true; break; }
@@ -718,18 +720,22 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
     pl.dv = VoxelDiv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
     {   // floor(u / leaf) == umulhi(u, magic) for every biased coordinate u = v + bias*leaf, v in [-32768, 32767]:
-        // verified here over all 65 536 of them (once per leaf per host thread), magic = 0 -> the kernel divides
+        // verified here over all 65 536 of them (once per leaf per host thread). leaf 1 has no 32-bit magic: magic = 0 makes
+        // the kernels pass u through. A failed check (impossible by the bound in pcs_voxel_agg.h) refuses the call.
         thread_local int cached_leaf = 0;
         thread_local unsigned int cached_magic = 0;
+        thread_local bool cached_ok = false;
         if (cached_leaf != leaf_mm) {
-            const unsigned long long magic = ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
+            const unsigned long long magic = leaf_mm == 1 ? 0ull : ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
             bool ok = magic < (1ull << 32);
             const unsigned int lo = pl.dv.bias_leaf - 32768u, hi = pl.dv.bias_leaf + 32767u;
             for (unsigned int u = lo; ok && u <= hi; u++)
-                ok = (unsigned int)(((unsigned long long)u * magic) >> 32) == u / (unsigned)leaf_mm;
+                ok = (unsigned int)(((unsigned long long)u * magic) >> 32) + (magic ? 0u : u) == u / (unsigned)leaf_mm;
             cached_leaf = leaf_mm;
-            cached_magic = ok ? (unsigned int)magic : 0u;
+            cached_magic = (unsigned int)magic;
+            cached_ok = ok;
         }
+        if (!cached_ok) return hipErrorInvalidValue;
         pl.dv.magic = cached_magic;
     }
     // one 64-bit word per element when the packed key and the partial's index fit together

@@ -20,14 +20,17 @@ inline unsigned int axis_bits(int leaf)
 }
 
 // floor(v / leaf) + bias, bias = ceil(32768 / leaf): the biased numerator u = v + bias*leaf is in [0, 2^17), and
-// floor(u / leaf) == (u * magic) >> 32 with magic = ceil(2^32 / leaf) — checked by the host over every u before the
-// launch (magic = 0: use '/'). Three variable-divisor integer divisions per point otherwise cost ~75 instructions.
+// floor(u / leaf) == (u * magic) >> 32 with magic = ceil(2^32 / leaf): the error magic*leaf - 2^32 is below leaf <= 2^15,
+// so u * error < 2^32 for every u < 2^17 (the host still checks all 65 536 of them before the launch). leaf = 1 has no
+// 32-bit magic: magic = 0 and the quotient is u itself (`pass` = all ones). No branch: a (uniform) test per division put
+// three branches and a 13-instruction divide into every point of the unrolled loops.
 struct VoxelDiv {
     unsigned int leaf, bias_leaf, magic;
     __device__ __forceinline__ unsigned int operator()(int v) const
     {
         const unsigned int u = (unsigned int)(v + (int)bias_leaf);
-        return magic ? __umulhi(u, magic) : u / leaf;
+        const unsigned int pass = magic ? 0u : ~0u;          // uniform: an SGPR select, hoisted out of the loops
+        return __umulhi(u, magic) + (u & pass);
     }
 };
 
