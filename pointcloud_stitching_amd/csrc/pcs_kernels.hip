@@ -879,6 +879,21 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
     store_staged(stage, head, tile_kept * PCS_POINT_BYTES, gdst);
 }
 
+// Request a stream's constants (and this launch's raster pointers) with ONE batch of scalar loads at the top of a
+// kernel. Left alone, hipcc asks for them one dependent group at a time — the kernarg, then n_points for the early
+// exit, then the raster pointers and the width, then the LUT pointers — four scalar round trips before the first
+// Z16 load of a workgroup can be issued, paid in full by the first wave of workgroups of every launch (1.8 rounds of
+// them make up an 8 x 720p launch). The empty asm only says "these are needed HERE".
+__device__ __forceinline__ void request_constants(const StreamParams& P, const void* a, const void* b, const void* c = nullptr)
+{
+    static_assert(sizeof(StreamParams) == 19 * 16, "request_constants covers the struct in 19 quads");
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    const u32x4s* q = reinterpret_cast<const u32x4s*>(&P);
+    asm volatile("" :: "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]), "s"(q[9]),
+                       "s"(q[10]), "s"(q[11]), "s"(q[12]), "s"(q[13]), "s"(q[14]), "s"(q[15]), "s"(q[16]), "s"(q[17]), "s"(q[18]),
+                       "s"(a), "s"(b), "s"(c));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Kernels
 // ------------------------------------------------------------------------------------------------
@@ -891,6 +906,7 @@ void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0
     __shared__ uint4 stage[kDenseStageBytes / 16];
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
+    request_constants(P, fp.depth[s], fp.color[s], payload_bytes);
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
@@ -907,10 +923,11 @@ void pcs_fused_dense_batch_kernel(const StreamParams* __restrict__ params, Batch
     __shared__ uint4 stage[kDenseStageBytes / 16];
     const int s = blockIdx.y;
     const StreamParams& P = params[s];
+    const int e = blockIdx.z * gridDim.y + s;
+    request_constants(P, bp.depth[e], bp.color[e], bp.payload[blockIdx.z]);
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
-    const int e = blockIdx.z * gridDim.y + s;
     DepthSource<DDIST, CDIST, Mth> src{bp.depth[e]};
     dense_tile(P, src, bp.color[e], tile0, n, bp.payload[blockIdx.z] + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
 }
@@ -998,6 +1015,7 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
 {
     __shared__ uint32_t wsum[kCountTiles][4];
     const int s = blockIdx.y;
+    request_constants(params[stream0 + s], fp.depth[s], tile_counts);
     count_tiles<DDIST, CDIST>(params[stream0 + s], fp.depth[s], flags, tile_counts, wsum);
 }
 
@@ -1009,6 +1027,7 @@ void pcs_fused_count_batch_kernel(const StreamParams* __restrict__ params, Batch
 {
     __shared__ uint32_t wsum[kCountTiles][4];
     const int s = blockIdx.y;
+    request_constants(params[s], bp.depth[blockIdx.z * gridDim.y + s], tile_counts);
     count_tiles<DDIST, CDIST>(params[s], bp.depth[blockIdx.z * gridDim.y + s], flags,
                               tile_counts + (size_t)blockIdx.z * total_tiles, wsum);
 }
@@ -1034,6 +1053,7 @@ void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0,
         *total_out = (int32_t)tot;
     }
     const StreamParams& P = params[stream0 + s];
+    request_constants(P, fp.depth[s], fp.color[s], payload_bytes);
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
@@ -1066,6 +1086,8 @@ void pcs_fused_emit_batch_kernel(const StreamParams* __restrict__ params, BatchP
         bc.counts[z][S] = (int32_t)tot;
     }
     const StreamParams& P = params[s];
+    // (no request_constants here: with it hipcc settles on 76 VGPRs = 6 waves/SIMD instead of 72 = 7, 27.5 vs 25.0 us per
+    // set; this launch is 4 x as long as a one-set launch, so its first wave of workgroups matters a quarter as much)
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
@@ -1200,6 +1222,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
 
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
+    request_constants(P, fp.depth[s], fp.color[s]);
     const uint32_t n = P.n_points;
     // Which pixels a round takes. rx == 0: 4096 consecutive pixels (any raster). rx > 0 (rasters whose width is a
     // multiple of 8): a 64 x 64-pixel SQUARE — 8 lanes x 8 pixels per row, 64 rows; a wavefront's loads still cover

@@ -8,7 +8,7 @@ src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "pc
 pats = [a for a in sys.argv[1:] if not a.endswith(".hip")]
 flags = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt".split()
 if src == "pcs_kernels.hip":
-    flags.append("-fno-slp-vectorize")
+    flags += ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 r = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
                    cwd=CSRC, capture_output=True, text=True)
 blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
