@@ -178,6 +178,9 @@ struct VoxelStage {
 hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
 hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
                         int32_t* d_out_points, hipStream_t st);
+// the same table fed from a 16-byte aligned payload (pcs_kernels.hip; the unaligned forms stay in pcs_voxel.hip)
+hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points,
+                                         const VoxelStage& vs, hipStream_t st);
 // max_w / max_h: the largest raster of the launch; patch_ok: every raster's width is a multiple of 8 (square patches)
 hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                                        uint32_t max_w, uint32_t max_h, bool patch_ok, uint32_t flags, MathSel math,

@@ -1201,25 +1201,169 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 #include "pcs_voxel_agg.h"
 
 constexpr int kVoxThreads = 512;
-constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 pixels per round; `rounds` of them share one table
+constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 points per round; `rounds` of them share one table
 
-// 512 lanes x 2 rounds rather than 1024 x 1: the kernel needs ~100 VGPRs (the stitch kernels' 8 points in flight plus
-// the table phase), which leaves room for one 1024-lane workgroup per CU — its load phase and its LDS phase then have
-// nothing to overlap with. Two 512-lane workgroups fit, and there is no barrier between the rounds.
+// The workgroup's LDS table: slot = key + the seven sums in three 64-bit words and one 32-bit word: (x, y), (z, count),
+// (R, G), B — four LDS adds per run instead of seven. Coordinates are summed BIASED (+32768, so every term is
+// non-negative and a 64-bit add never carries between its halves: <= 32 768 points x 65 535 < 2^31); the bias leaves at
+// the output.
+struct VoxTable {
+    unsigned long long *skey, *sxy, *szn, *srg;
+    unsigned int *sbl, *wtot, *base_s;
+};
+#define PCS_VOX_TABLE_DECL                                                                             \
+    __shared__ unsigned long long skey_[kSlots];                                                       \
+    __shared__ unsigned long long sxy_[kSlots], szn_[kSlots], srg_[kSlots];                            \
+    __shared__ unsigned int sbl_[kSlots];                                                              \
+    __shared__ unsigned int wtot_[kVoxThreads / 64];                                                   \
+    __shared__ unsigned int base_s_;                                                                   \
+    const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_}
+
+__device__ __forceinline__ void vox_table_init(const VoxTable& T)
+{
+    for (int j = threadIdx.x; j < kSlots; j += kVoxThreads) {
+        T.skey[j] = kEmptyKey;
+        T.sxy[j] = T.szn[j] = T.srg[j] = 0ull;
+        T.sbl[j] = 0u;
+    }
+    __syncthreads();
+}
+
+// One round: a lane's 8 consecutive records (bit k of `keep`: record k takes part) -> the table.
+__device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelStage& vs, const Record (&rec)[8], uint32_t keep)
+{
+    unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
+    unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl;
+    const VoxelDiv dv{vs.leaf, vs.bias_leaf, vs.magic};
+    const unsigned int bits = vs.bits, idx_bits = vs.idx_bits;
+    VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
+    const int lane = threadIdx.x & 63;
+    auto key_of = [&](const Record& r) {
+        return voxel_key(dv, (int)(short)(r.xy & 0xFFFFu), (int)(short)(r.xy >> 16), (int)(short)(r.zc & 0xFFFFu), bits);
+    };
+    // runs of equal keys among the lane's 8 pixels: summed in registers, the run's LAST point adds them to the table
+    unsigned int ax = 0, ay = 0, az = 0;                     // biased: sums of (coordinate + 32768)
+    unsigned int ar = 0, ag = 0, ab = 0, an = 0, failed = 0;
+    bool cont = false;                                       // point k continues the run of point k-1
+    unsigned long long kcur = key_of(rec[0]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const bool live = (keep >> k) & 1u;
+        const bool live_next = k < 7 && ((keep >> (k + 1)) & 1u);
+        const unsigned long long knext = k < 7 ? key_of(rec[k + 1]) : 0ull;
+        const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
+        const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
+        if (!cont) { ax = ay = az = 0u; ar = ag = ab = an = 0u; }
+        ax += (unsigned int)(x + 32768); ay += (unsigned int)(y + 32768); az += (unsigned int)(z + 32768);
+        ar += col & 0xFFu; ag += col >> 8; ab += blue; an += 1u;
+        const bool same_next = live_next && knext == kcur;
+        const bool actor = live && !same_next;
+        if (actor) {
+            const VoxelProbe pr(kcur);
+            unsigned int h = pr.first;
+            // first probe straight-line (it succeeds for all but a few per cent of the runs), the rest in a loop
+            unsigned long long old = atomicCAS(&skey[h], kEmptyKey, kcur);
+            bool placed = old == kEmptyKey || old == kcur;
+            if (__builtin_expect(!placed, 0)) {
+                for (int t = 1; t < kProbe; t++) {
+                    h = pr.next(h);
+                    old = atomicCAS(&skey[h], kEmptyKey, kcur);
+                    if (old == kEmptyKey || old == kcur) { placed = true; break; }
+                }
+            }
+            if (placed) {
+                atomicAdd(&sxy[h], (unsigned long long)ax | ((unsigned long long)ay << 32));
+                atomicAdd(&szn[h], (unsigned long long)az | ((unsigned long long)an << 32));
+                atomicAdd(&srg[h], (unsigned long long)ar | ((unsigned long long)ag << 32));
+                atomicAdd(&sbl[h], ab);
+            } else {
+                failed |= 1u << k;                           // the run ending at k goes out as a partial of its own
+            }
+        }
+        cont = live && same_next;
+        kcur = knext;
+    }
+    // Runs that found no slot (more voxels under this table than it can take: leaves of a few pixels) are appended
+    // as partials of their own; one global atomic per wavefront, only when it happens. The sums are rebuilt from
+    // the records: a failed run is the maximal stretch of kept points with the same key that ends at its bit.
+    if (__ballot(failed != 0u)) {
+        const unsigned int c = __popc(failed);
+        const unsigned int inc = wave_inclusive_scan(c);
+        unsigned int base = 0;
+        if (lane == 63) base = atomicAdd(vs.n_runs, inc);
+        unsigned int pos = (unsigned int)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+        int sx = 0, sy = 0, sz = 0;
+        unsigned int r = 0, g = 0, b = 0, cnt = 0;
+        unsigned long long kprev = 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool live = (keep >> k) & 1u;
+            const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
+            const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
+            const unsigned long long key = voxel_key(dv, x, y, z, bits);
+            const bool joins = k > 0 && live && ((keep >> (k - 1)) & 1u) && key == kprev;
+            if (!joins) { sx = sy = sz = 0; r = g = b = cnt = 0u; }
+            sx += x; sy += y; sz += z; r += col & 0xFFu; g += col >> 8; b += blue; cnt += 1u;
+            kprev = key;
+            if ((failed >> k) & 1u) {
+                if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
+                else { vs.keys[pos] = key; vs.idx[pos] = pos; }
+                part[pos] = VoxelPartial{sx, sy, sz, r, g, b, cnt, 0u};
+                pos++;
+            }
+        }
+    }
+}
+
+// End of the workgroup: one partial per occupied slot, one returning global atomic for all of them.
+__device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelStage& vs)
+{
+    unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
+    unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl; unsigned int* const wtot = T.wtot;
+    unsigned int& base_s = *T.base_s;
+    const unsigned int idx_bits = vs.idx_bits;
+    VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    // every lane owns four slots; one partial per occupied slot
+    unsigned int c = 0;
+#pragma unroll
+    for (int q = 0; q < kSlots / kVoxThreads; q++) c += skey[threadIdx.x * (kSlots / kVoxThreads) + q] != kEmptyKey;
+    const unsigned int inc = wave_inclusive_scan(c);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int w = 0; w < kVoxThreads / 64; w++) { const unsigned int t = wtot[w]; wtot[w] = tot; tot += t; }
+        base_s = tot ? atomicAdd(vs.n_runs, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int pos = base_s + wtot[wave] + inc - c;
+#pragma unroll
+    for (int q = 0; q < kSlots / kVoxThreads; q++) {
+        const int j = threadIdx.x * (kSlots / kVoxThreads) + q;
+        if (skey[j] != kEmptyKey) {
+            if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
+            else { vs.keys[pos] = skey[j]; vs.idx[pos] = pos; }
+            const unsigned long long xy = sxy[j], zn = szn[j], rg = srg[j];
+            const unsigned int cnt = (unsigned int)(zn >> 32);
+            const int bias = (int)(cnt << 15);                   // count x 32768 (count <= 32 768)
+            part[pos] = VoxelPartial{(int)(unsigned int)xy - bias, (int)(unsigned int)(xy >> 32) - bias, (int)(unsigned int)zn - bias,
+                                     (unsigned int)rg, (unsigned int)(rg >> 32), sbl[j], cnt, 0u};
+            pos++;
+        }
+    }
+}
+
+// 512 lanes x several rounds rather than 1024 x 1: the raster reader needs ~100 VGPRs (the stitch kernels' 8 points in
+// flight plus the table phase), which leaves room for one 1024-lane workgroup per CU — its load phase and its LDS phase
+// then have nothing to overlap with. Two 512-lane workgroups fit, and there is no barrier between the rounds.
 template <class Mth>
 __global__ __launch_bounds__(kVoxThreads)
 void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                                      VoxelStage vs, int rounds, int rx)
 {
-    // slot = key + the seven sums in three 64-bit words and one 32-bit word: (x, y), (z, count), (R, G), B — four LDS
-    // adds per run instead of seven. Coordinates are summed BIASED (+32768, so every term is non-negative and a
-    // 64-bit add never carries between its halves: <= 32 768 points x 65 535 < 2^31); the bias leaves at the output.
-    __shared__ unsigned long long skey[kSlots];
-    __shared__ unsigned long long sxy[kSlots], szn[kSlots], srg[kSlots];
-    __shared__ unsigned int sbl[kSlots];
-    __shared__ unsigned int wtot[kVoxThreads / 64];
-    __shared__ unsigned int base_s;
-
+    PCS_VOX_TABLE_DECL;
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
     request_constants(P, fp.depth[s], fp.color[s]);
@@ -1237,17 +1381,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     if (rx ? (py * 64u * ry >= Hh) : (tile0 >= n)) return;
     const uint8_t* __restrict__ color = fp.color[s];
     DepthSource<true, true, Mth> src{fp.depth[s]};
-    const VoxelDiv dv{vs.leaf, vs.bias_leaf, vs.magic};
-    const unsigned int bits = vs.bits, idx_bits = vs.idx_bits;
-    VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-
-    for (int j = threadIdx.x; j < kSlots; j += kVoxThreads) {
-        skey[j] = kEmptyKey;
-        sxy[j] = szn[j] = srg[j] = 0ull;
-        sbl[j] = 0u;
-    }
-    __syncthreads();
+    vox_table_init(T);
 
     for (int round = 0; round < rounds; round++) {
         uint32_t i0;
@@ -1279,113 +1413,52 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             ExactCvt exact;
             fill(exact);
         }
+        vox_table_round(T, vs, rec, keep);
+    }
+    vox_table_flush(T, vs);
+}
 
-        auto key_of = [&](const Record& r) {
-            return voxel_key(dv, (int)(short)(r.xy & 0xFFFFu), (int)(short)(r.xy >> 16), (int)(short)(r.zc & 0xFFFFu), bits);
-        };
-        // runs of equal keys among the lane's 8 pixels: summed in registers, the run's LAST point adds them to the table
-        unsigned int ax = 0, ay = 0, az = 0;                     // biased: sums of (coordinate + 32768)
-        unsigned int ar = 0, ag = 0, ab = 0, an = 0, failed = 0;
-        bool cont = false;                                       // point k continues the run of point k-1
-        unsigned long long kcur = key_of(rec[0]);
+// The same table fed from a packed payload (16-byte aligned): a lane's 8 consecutive records are 80 contiguous bytes,
+// five 16-byte loads. The point count comes from the host or (counted form) from device memory.
+__global__ __launch_bounds__(kVoxThreads)
+void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint32_t n_host, const int32_t* __restrict__ n_dev,
+                                       VoxelStage vs, int rounds)
+{
+    PCS_VOX_TABLE_DECL;
+    const uint32_t n = n_dev ? (uint32_t)max(*n_dev, 0) : n_host;
+    const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
+    if (tile0 >= n) return;
+    vox_table_init(T);
+    for (int round = 0; round < rounds; round++) {
+        const uint32_t i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
+        uint32_t w[20];
+        if (i0 + 8u <= n) {
+            const uint4* q = reinterpret_cast<const uint4*>(payload + (size_t)i0 * PCS_POINT_SHORTS);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const bool live = (keep >> k) & 1u;
-            const bool live_next = k < 7 && ((keep >> (k + 1)) & 1u);
-            const unsigned long long knext = k < 7 ? key_of(rec[k + 1]) : 0ull;
-            const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
-            const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
-            if (!cont) { ax = ay = az = 0u; ar = ag = ab = an = 0u; }
-            ax += (unsigned int)(x + 32768); ay += (unsigned int)(y + 32768); az += (unsigned int)(z + 32768);
-            ar += col & 0xFFu; ag += col >> 8; ab += blue; an += 1u;
-            const bool same_next = live_next && knext == kcur;
-            const bool actor = live && !same_next;
-            if (actor) {
-                const VoxelProbe pr(kcur);
-                unsigned int h = pr.first;
-                // first probe straight-line (it succeeds for all but a few per cent of the runs), the rest in a loop
-                unsigned long long old = atomicCAS(&skey[h], kEmptyKey, kcur);
-                bool placed = old == kEmptyKey || old == kcur;
-                if (__builtin_expect(!placed, 0)) {
-                    for (int t = 1; t < kProbe; t++) {
-                        h = pr.next(h);
-                        old = atomicCAS(&skey[h], kEmptyKey, kcur);
-                        if (old == kEmptyKey || old == kcur) { placed = true; break; }
-                    }
-                }
-                if (placed) {
-                    atomicAdd(&sxy[h], (unsigned long long)ax | ((unsigned long long)ay << 32));
-                    atomicAdd(&szn[h], (unsigned long long)az | ((unsigned long long)an << 32));
-                    atomicAdd(&srg[h], (unsigned long long)ar | ((unsigned long long)ag << 32));
-                    atomicAdd(&sbl[h], ab);
-                } else {
-                    failed |= 1u << k;                           // the run ending at k goes out as a partial of its own
-                }
-            }
-            cont = live && same_next;
-            kcur = knext;
-        }
-        // Runs that found no slot (more voxels under this table than it can take: leaves of a few pixels) are appended
-        // as partials of their own; one global atomic per wavefront, only when it happens. The sums are rebuilt from
-        // the records: a failed run is the maximal stretch of kept points with the same key that ends at its bit.
-        if (__ballot(failed != 0u)) {
-            const unsigned int c = __popc(failed);
-            const unsigned int inc = wave_inclusive_scan(c);
-            unsigned int base = 0;
-            if (lane == 63) base = atomicAdd(vs.n_runs, inc);
-            unsigned int pos = (unsigned int)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
-            int sx = 0, sy = 0, sz = 0;
-            unsigned int r = 0, g = 0, b = 0, cnt = 0;
-            unsigned long long kprev = 0ull;
+            for (int j = 0; j < 5; j++) { const uint4 v = q[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+        } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool live = (keep >> k) & 1u;
-                const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
-                const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
-                const unsigned long long key = voxel_key(dv, x, y, z, bits);
-                const bool joins = k > 0 && live && ((keep >> (k - 1)) & 1u) && key == kprev;
-                if (!joins) { sx = sy = sz = 0; r = g = b = cnt = 0u; }
-                sx += x; sy += y; sz += z; r += col & 0xFFu; g += col >> 8; b += blue; cnt += 1u;
-                kprev = key;
-                if ((failed >> k) & 1u) {
-                    if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
-                    else { vs.keys[pos] = key; vs.idx[pos] = pos; }
-                    part[pos] = VoxelPartial{sx, sy, sz, r, g, b, cnt, 0u};
-                    pos++;
-                }
+            for (int j = 0; j < 20; j++) {                        // ragged end: halfword by halfword, zeros past the end
+                const uint32_t h0 = (uint32_t)(2 * j), h1 = h0 + 1u;
+                const size_t base = (size_t)i0 * PCS_POINT_SHORTS;
+                const uint32_t lo = (i0 < n && base + h0 < (size_t)n * PCS_POINT_SHORTS) ? (uint16_t)payload[base + h0] : 0u;
+                const uint32_t hi = (i0 < n && base + h1 < (size_t)n * PCS_POINT_SHORTS) ? (uint16_t)payload[base + h1] : 0u;
+                w[j] = lo | (hi << 16);
             }
         }
-    }
-    __syncthreads();
-
-    // every lane owns four slots; one partial per occupied slot
-    unsigned int c = 0;
+        Record rec[8];
 #pragma unroll
-    for (int q = 0; q < kSlots / kVoxThreads; q++) c += skey[threadIdx.x * (kSlots / kVoxThreads) + q] != kEmptyKey;
-    const unsigned int inc = wave_inclusive_scan(c);
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int tot = 0;
-        for (int w = 0; w < kVoxThreads / 64; w++) { const unsigned int t = wtot[w]; wtot[w] = tot; tot += t; }
-        base_s = tot ? atomicAdd(vs.n_runs, tot) : 0u;
-    }
-    __syncthreads();
-    unsigned int pos = base_s + wtot[wave] + inc - c;
-#pragma unroll
-    for (int q = 0; q < kSlots / kVoxThreads; q++) {
-        const int j = threadIdx.x * (kSlots / kVoxThreads) + q;
-        if (skey[j] != kEmptyKey) {
-            if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
-            else { vs.keys[pos] = skey[j]; vs.idx[pos] = pos; }
-            const unsigned long long xy = sxy[j], zn = szn[j], rg = srg[j];
-            const unsigned int cnt = (unsigned int)(zn >> 32);
-            const int bias = (int)(cnt << 15);                   // count x 32768 (count <= 32 768)
-            part[pos] = VoxelPartial{(int)(unsigned int)xy - bias, (int)(unsigned int)(xy >> 32) - bias, (int)(unsigned int)zn - bias,
-                                     (unsigned int)rg, (unsigned int)(rg >> 32), sbl[j], cnt, 0u};
-            pos++;
+        for (int k = 0; k < 8; k += 2) {                          // two records = five dwords: xy zc b|x' y'|z' c'|b'
+            const uint32_t* o = w + (k >> 1) * 5;
+            rec[k].xy = o[0]; rec[k].zc = o[1]; rec[k].b = o[2] & 0xFFFFu;
+            rec[k + 1].xy = perm(o[3], o[2], kHiLo); rec[k + 1].zc = perm(o[4], o[3], kHiLo); rec[k + 1].b = o[4] >> 16;
         }
+        uint32_t keep = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) keep |= (uint32_t)(i0 + k < n) << k;
+        vox_table_round(T, vs, rec, keep);
     }
+    vox_table_flush(T, vs);
 }
 
 // ---- a2 twin -----------------------------------------------------------------------------------
@@ -1717,6 +1790,26 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
     if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
 #undef L
+    return hipGetLastError();
+}
+
+hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points,
+                                         const VoxelStage& vs, hipStream_t st)
+{
+    if (n_points == 0) return hipSuccess;
+    // Rounds of 4096 consecutive records per table (the stitched order is all a payload offers: no square patches).
+    // 29.8 M-point config-5 cloud, ms for the voxel grid with 2 / 3 / 4 / 6 rounds: 36 mm 0.48 / 0.40 / 0.46 / 0.60,
+    // 50 mm 0.35 / 0.31 / 0.26 / 0.26, 100 mm 0.22 / 0.19 / 0.18 / 0.17 (the 1024-lane reader of pcs_voxel.hip: 0.52 / 0.36 /
+    // 0.25). Below 30 mm the caller keeps that reader: crowded tables pass runs through with one global atomic per
+    // wavefront here, per workgroup there (25 mm: 1.05 vs 0.81 ms).
+    static const int env_rounds = [] { const char* v = getenv("PCS_VOXEL_ROUNDS"); return v ? atoi(v) : 0; }();
+    const uint64_t tiles = (n_points + kVoxRoundPoints - 1) / kVoxRoundPoints;
+    const uint64_t by_leaf = vs.leaf >= 80 ? 6 : vs.leaf >= 44 ? 4 : 3;
+    int rounds = (int)std::min<uint64_t>(by_leaf, std::max<uint64_t>(1, tiles / 1024));
+    if (env_rounds > 0) rounds = std::min(env_rounds, 8);
+    const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
+    hipLaunchKernelGGL(pcs_payload_voxel_partials_kernel, dim3((n_points + tile_points - 1) / tile_points), dim3(kVoxThreads), 0, st,
+                       d_payload, n_points, d_n_points, vs, rounds);
     return hipGetLastError();
 }
 

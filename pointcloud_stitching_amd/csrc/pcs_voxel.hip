@@ -804,7 +804,15 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
     const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
     const dim3 agg_grid((n_points + per_block - 1) / per_block);
     static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
-    if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
+    static const int lane8_ok = [] { const char* v = getenv("PCS_VOXEL_LANE8"); return v ? atoi(v) : 1; }();
+    if (lane8_ok && ((uintptr_t)d_payload & 15u) == 0u && (leaf_mm >= 30 || lane8_ok > 1)) {
+        // 16-byte aligned payload: the reader that shares its table code with the raster reader (pcs_kernels.hip)
+        VoxelStage vs{};
+        vs.keys = w.keys_a; vs.idx = w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
+        vs.leaf = pl.dv.leaf; vs.bias_leaf = pl.dv.bias_leaf; vs.magic = pl.dv.magic; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
+        e = launch_payload_voxel_partials(d_payload, n_points, d_n_points, vs, st);
+        if (e != hipSuccess) return e;
+    } else if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
         hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv, pl.bits,
                            pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
     else
