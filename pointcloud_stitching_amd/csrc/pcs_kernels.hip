@@ -1209,15 +1209,15 @@ constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 
 // the output.
 struct VoxTable {
     unsigned long long *skey, *sxy, *szn, *srg;
-    unsigned int *sbl, *wtot, *base_s;
+    unsigned int *sbl, *wtot, *base_s, *flag;
 };
 #define PCS_VOX_TABLE_DECL                                                                             \
     __shared__ unsigned long long skey_[kSlots];                                                       \
     __shared__ unsigned long long sxy_[kSlots], szn_[kSlots], srg_[kSlots];                            \
     __shared__ unsigned int sbl_[kSlots];                                                              \
     __shared__ unsigned int wtot_[kVoxThreads / 64];                                                   \
-    __shared__ unsigned int base_s_;                                                                   \
-    const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_}
+    __shared__ unsigned int base_s_, flag_;                                                            \
+    const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_, &flag_}
 
 __device__ __forceinline__ void vox_table_init(const VoxTable& T)
 {
@@ -1226,11 +1226,13 @@ __device__ __forceinline__ void vox_table_init(const VoxTable& T)
         T.sxy[j] = T.szn[j] = T.srg[j] = 0ull;
         T.sbl[j] = 0u;
     }
+    if (threadIdx.x == 0) *T.flag = 0u;
     __syncthreads();
 }
 
 // One round: a lane's 8 consecutive records (bit k of `keep`: record k takes part) -> the table.
-__device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelStage& vs, const Record (&rec)[8], uint32_t keep)
+__device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelStage& vs, const Record (&rec)[8], uint32_t keep,
+                                                bool crowded)
 {
     unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
     unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl;
@@ -1283,15 +1285,45 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
         cont = live && same_next;
         kcur = knext;
     }
-    // Runs that found no slot (more voxels under this table than it can take: leaves of a few pixels) are appended
-    // as partials of their own; one global atomic per wavefront, only when it happens. The sums are rebuilt from
-    // the records: a failed run is the maximal stretch of kept points with the same key that ends at its bit.
-    if (__ballot(failed != 0u)) {
+    // Runs that found no slot (more voxels under this table than it can take: leaves of a few pixels) are appended as
+    // partials of their own. The sums are rebuilt from the records: a failed run is the maximal stretch of kept points with
+    // the same key that ends at its bit. Where they go is reserved
+    //  * crowded (the launcher expects full tables: leaves below 30 mm): with ONE returning global atomic per workgroup and
+    //    round, and only when it happens — the workgroup learns that with one barrier per round (3 - 8 % of the kernel
+    //    when nothing ever fails, hence the switch);
+    //  * otherwise: with one atomic per wavefront that has a failed run — free when there is none, but serialised on the
+    //    counter's line when most wavefronts have one (65 k per 16 x 1080p frame-set at 10 mm: 490 us of the kernel's 627).
+    const unsigned long long any_failed = __ballot(failed != 0u);    // (all lanes: not inside a short-circuit)
+    unsigned int pos = 0;
+    bool emit = false;
+    if (crowded) {                                                    // uniform over the launch
+        if (lane == 0 && any_failed) *T.flag = 1u;
+        __syncthreads();
+        if (*T.flag) {                                                // workgroup-uniform
+            const int wave = threadIdx.x >> 6;
+            const unsigned int c = __popc(failed);
+            const unsigned int inc = wave_inclusive_scan(c);
+            if (lane == 63) T.wtot[wave] = inc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned int tot = 0;
+                for (int w = 0; w < kVoxThreads / 64; w++) { const unsigned int t = T.wtot[w]; T.wtot[w] = tot; tot += t; }
+                *T.base_s = atomicAdd(vs.n_runs, tot);
+                *T.flag = 0u;
+            }
+            __syncthreads();
+            pos = *T.base_s + T.wtot[wave] + inc - c;
+            emit = true;
+        }
+    } else if (any_failed) {
         const unsigned int c = __popc(failed);
         const unsigned int inc = wave_inclusive_scan(c);
         unsigned int base = 0;
         if (lane == 63) base = atomicAdd(vs.n_runs, inc);
-        unsigned int pos = (unsigned int)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+        pos = (unsigned int)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+        emit = true;
+    }
+    if (emit) {
         int sx = 0, sy = 0, sz = 0;
         unsigned int r = 0, g = 0, b = 0, cnt = 0;
         unsigned long long kprev = 0ull;
@@ -1313,6 +1345,7 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
             }
         }
     }
+    if (crowded) __syncthreads();         // wtot / base_s are free again before the next round (or the flush) uses them
 }
 
 // End of the workgroup: one partial per occupied slot, one returning global atomic for all of them.
@@ -1361,7 +1394,7 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
 template <class Mth>
 __global__ __launch_bounds__(kVoxThreads)
 void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
-                                     VoxelStage vs, int rounds, int rx)
+                                     VoxelStage vs, int rounds, int rx, int crowded)
 {
     PCS_VOX_TABLE_DECL;
     const int s = blockIdx.y;
@@ -1413,7 +1446,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             ExactCvt exact;
             fill(exact);
         }
-        vox_table_round(T, vs, rec, keep);
+        vox_table_round(T, vs, rec, keep, crowded != 0);
     }
     vox_table_flush(T, vs);
 }
@@ -1422,7 +1455,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
 // five 16-byte loads. The point count comes from the host or (counted form) from device memory.
 __global__ __launch_bounds__(kVoxThreads)
 void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint32_t n_host, const int32_t* __restrict__ n_dev,
-                                       VoxelStage vs, int rounds)
+                                       VoxelStage vs, int rounds, int crowded)
 {
     PCS_VOX_TABLE_DECL;
     const uint32_t n = n_dev ? (uint32_t)max(*n_dev, 0) : n_host;
@@ -1456,7 +1489,7 @@ void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint
         uint32_t keep = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) keep |= (uint32_t)(i0 + k < n) << k;
-        vox_table_round(T, vs, rec, keep);
+        vox_table_round(T, vs, rec, keep, crowded != 0);
     }
     vox_table_flush(T, vs);
 }
@@ -1786,7 +1819,7 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
         grid = dim3((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
     }
-#define L(M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx)
+#define L(M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx, vs.leaf < 30u ? 1 : 0)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
     if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
 #undef L
@@ -1800,16 +1833,16 @@ hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_po
     // Rounds of 4096 consecutive records per table (the stitched order is all a payload offers: no square patches).
     // 29.8 M-point config-5 cloud, ms for the voxel grid with 2 / 3 / 4 / 6 rounds: 36 mm 0.48 / 0.40 / 0.46 / 0.60,
     // 50 mm 0.35 / 0.31 / 0.26 / 0.26, 100 mm 0.22 / 0.19 / 0.18 / 0.17 (the 1024-lane reader of pcs_voxel.hip: 0.52 / 0.36 /
-    // 0.25). Below 30 mm the caller keeps that reader: crowded tables pass runs through with one global atomic per
-    // wavefront here, per workgroup there (25 mm: 1.05 vs 0.81 ms).
+    // 0.25). Below 30 mm the tables are crowded and runs are passed through per workgroup (vox_table_round): 10 mm 1.97 ms
+    // with 2 rounds (that reader: 2.43), 15 mm 1.35 (1.56), 25 mm 0.72 with 3 rounds (0.81).
     static const int env_rounds = [] { const char* v = getenv("PCS_VOXEL_ROUNDS"); return v ? atoi(v) : 0; }();
     const uint64_t tiles = (n_points + kVoxRoundPoints - 1) / kVoxRoundPoints;
-    const uint64_t by_leaf = vs.leaf >= 80 ? 6 : vs.leaf >= 44 ? 4 : 3;
+    const uint64_t by_leaf = vs.leaf >= 80 ? 6 : vs.leaf >= 44 ? 4 : vs.leaf >= 23 ? 3 : 2;
     int rounds = (int)std::min<uint64_t>(by_leaf, std::max<uint64_t>(1, tiles / 1024));
     if (env_rounds > 0) rounds = std::min(env_rounds, 8);
     const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
     hipLaunchKernelGGL(pcs_payload_voxel_partials_kernel, dim3((n_points + tile_points - 1) / tile_points), dim3(kVoxThreads), 0, st,
-                       d_payload, n_points, d_n_points, vs, rounds);
+                       d_payload, n_points, d_n_points, vs, rounds, vs.leaf < 30u ? 1 : 0);
     return hipGetLastError();
 }
 

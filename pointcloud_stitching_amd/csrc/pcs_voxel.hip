@@ -805,7 +805,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
     const dim3 agg_grid((n_points + per_block - 1) / per_block);
     static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
     static const int lane8_ok = [] { const char* v = getenv("PCS_VOXEL_LANE8"); return v ? atoi(v) : 1; }();
-    if (lane8_ok && ((uintptr_t)d_payload & 15u) == 0u && (leaf_mm >= 30 || lane8_ok > 1)) {
+    if (lane8_ok && ((uintptr_t)d_payload & 15u) == 0u) {
         // 16-byte aligned payload: the reader that shares its table code with the raster reader (pcs_kernels.hip)
         VoxelStage vs{};
         vs.keys = w.keys_a; vs.idx = w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
