@@ -174,6 +174,7 @@ struct VoxelStage {
     void*               part;          // VoxelPartial[capacity]
     unsigned int*       n_runs;        // partials appended so far
     uint32_t            leaf, bias_leaf, magic, bits, idx_bits;
+    uint32_t            track_bits;    // record which key bits vary (the sort may then skip a pass); 0: the host declared all of them varying
 };
 hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
 hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,

@@ -1209,15 +1209,16 @@ constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 
 // the output.
 struct VoxTable {
     unsigned long long *skey, *sxy, *szn, *srg;
-    unsigned int *sbl, *wtot, *base_s, *flag;
+    unsigned int *sbl, *wtot, *base_s, *flag, *kor;       // kor[4]: OR of the keys written (lo, hi), OR of their complements
 };
 #define PCS_VOX_TABLE_DECL                                                                             \
     __shared__ unsigned long long skey_[kSlots];                                                       \
     __shared__ unsigned long long sxy_[kSlots], szn_[kSlots], srg_[kSlots];                            \
     __shared__ unsigned int sbl_[kSlots];                                                              \
     __shared__ unsigned int wtot_[kVoxThreads / 64];                                                   \
-    __shared__ unsigned int base_s_, flag_;                                                            \
-    const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_, &flag_}
+    __shared__ unsigned int base_s_, flag_, kor_[4];                                                   \
+    const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_, &flag_, kor_};                    \
+    unsigned long long key_or = 0ull, key_orn = 0ull
 
 __device__ __forceinline__ void vox_table_init(const VoxTable& T)
 {
@@ -1227,12 +1228,13 @@ __device__ __forceinline__ void vox_table_init(const VoxTable& T)
         T.sbl[j] = 0u;
     }
     if (threadIdx.x == 0) *T.flag = 0u;
+    if (threadIdx.x < 4) T.kor[threadIdx.x] = 0u;
     __syncthreads();
 }
 
 // One round: a lane's 8 consecutive records (bit k of `keep`: record k takes part) -> the table.
 __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelStage& vs, const Record (&rec)[8], uint32_t keep,
-                                                bool crowded)
+                                                bool crowded, unsigned long long& key_or, unsigned long long& key_orn)
 {
     unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
     unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl;
@@ -1341,6 +1343,7 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
                 if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
                 else { vs.keys[pos] = key; vs.idx[pos] = pos; }
                 part[pos] = VoxelPartial{sx, sy, sz, r, g, b, cnt, 0u};
+                key_or |= key; key_orn |= ~key;
                 pos++;
             }
         }
@@ -1349,7 +1352,8 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
 }
 
 // End of the workgroup: one partial per occupied slot, one returning global atomic for all of them.
-__device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelStage& vs)
+__device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelStage& vs, unsigned long long key_or,
+                                                unsigned long long key_orn)
 {
     unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
     unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl; unsigned int* const wtot = T.wtot;
@@ -1383,8 +1387,36 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
             const int bias = (int)(cnt << 15);                   // count x 32768 (count <= 32 768)
             part[pos] = VoxelPartial{(int)(unsigned int)xy - bias, (int)(unsigned int)(xy >> 32) - bias, (int)(unsigned int)zn - bias,
                                      (unsigned int)rg, (unsigned int)(rg >> 32), sbl[j], cnt, 0u};
+            key_or |= skey[j]; key_orn |= ~skey[j];
             pos++;
         }
+    }
+    // which key bits vary at all (pcs_voxel.hip's sort drops the others): OR of every key this workgroup wrote and of
+    // every complement -> wavefront (DPP) -> LDS -> global ORs. Only when the launcher asked for it: the extra barrier and
+    // the read of the global words at the very end of every workgroup cost the 16 x 1080p launch 9 us (6 %), which a
+    // skipped pass repays three times over — where one can be skipped (pcs_voxel.hip: plan_for).
+    if (!vs.track_bits) return;
+    unsigned int v[4] = {(unsigned int)key_or, (unsigned int)(key_or >> 32), (unsigned int)key_orn, (unsigned int)(key_orn >> 32)};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned int x = v[q];
+        x |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+        x |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+        x |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+        x |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+        x |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15
+        x |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31
+        if (lane == 63 && x) atomicOr(&T.kor[q], x);
+    }
+    __syncthreads();
+    // The words live on their own 128-byte line (kVoxCtlOr), away from the partial counter every workgroup adds to, and a
+    // workgroup only issues an atomic if it has a bit the word does not show yet (a stale read costs a redundant OR,
+    // nothing else): after the first few workgroups almost none do. (Four unconditional ORs per workgroup on the
+    // counter's own line cost the 16 x 1080p launch 10 us.)
+    if (threadIdx.x < 4) {
+        unsigned int* g = vs.n_runs + kVoxCtlOr + threadIdx.x;
+        const unsigned int mine = T.kor[threadIdx.x];
+        if (mine & ~__builtin_nontemporal_load(g)) atomicOr(g, mine);
     }
 }
 
@@ -1446,9 +1478,9 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             ExactCvt exact;
             fill(exact);
         }
-        vox_table_round(T, vs, rec, keep, crowded != 0);
+        vox_table_round(T, vs, rec, keep, crowded != 0, key_or, key_orn);
     }
-    vox_table_flush(T, vs);
+    vox_table_flush(T, vs, key_or, key_orn);
 }
 
 // The same table fed from a packed payload (16-byte aligned): a lane's 8 consecutive records are 80 contiguous bytes,
@@ -1489,9 +1521,9 @@ void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint
         uint32_t keep = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) keep |= (uint32_t)(i0 + k < n) << k;
-        vox_table_round(T, vs, rec, keep, crowded != 0);
+        vox_table_round(T, vs, rec, keep, crowded != 0, key_or, key_orn);
     }
-    vox_table_flush(T, vs);
+    vox_table_flush(T, vs, key_or, key_orn);
 }
 
 // ---- a2 twin -----------------------------------------------------------------------------------

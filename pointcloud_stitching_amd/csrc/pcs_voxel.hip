@@ -271,15 +271,80 @@ __device__ __forceinline__ unsigned int sort_chunk_of(unsigned int m)
     return m >= (1u << 20) ? 8192u : m >= (512u << 10) ? 4096u : m >= (256u << 10) ? 2048u : 1024u;
 }
 
-__device__ __forceinline__ unsigned int digit_of(unsigned long long key, unsigned int shift) { return (unsigned int)(key >> shift) & (kRadix - 1); }
+// Which bits of the keys actually differ, learnt on the device: the pre-aggregation ORs every key it writes into
+// ctl[32..33] and every complement into ctl[34..35]; a bit varies iff it is set in both. Within each axis field the bits
+// above the highest varying one are the same in all keys, so dropping them changes neither order nor equality: the
+// passes sort the COMPACT key (the three fields' low w0 / w1 / w2 bits, concatenated), 11 bits at a time, and a cloud
+// that spans 8 m at a 10 mm leaf needs 3 passes instead of the 4 its 39-bit key would (200 mm: 2 instead of 3). The
+// host enqueues P = ceil(3 * bits / 11) passes; the first P - R of them return at once, real pass e reads buffer A when
+// e is even, B when odd, and the segmented mean reads whichever buffer the last real pass wrote.
+constexpr unsigned int kCtlOr = kVoxCtlOr, kCtlOrn = kVoxCtlOrn;
+struct SortPass {
+    bool skip, in_a, plain;          // plain: no pass is saved, the digit is a plain bit field of the key
+    unsigned int lo, w0, w1, p0, p1, p2;
+    unsigned long long m0, m1, m2;
+    __device__ __forceinline__ unsigned int digit(unsigned long long key) const
+    {
+        if (plain) return (unsigned int)(key >> (p0 + lo)) & (unsigned int)(kRadix - 1);       // uniform
+        const unsigned long long c = ((key >> p0) & m0) | (((key >> p1) & m1) << w0) | (((key >> p2) & m2) << (w0 + w1));
+        return (unsigned int)(c >> lo) & (unsigned int)(kRadix - 1);
+    }
+};
+// `bits` carries the launcher's tracking decision in bit 31 (kTrackFlag): without it nobody recorded the varying bits and
+// every bit counts.
+constexpr unsigned int kTrackFlag = 1u << 31;
+__device__ __forceinline__ unsigned int real_passes(const unsigned int* __restrict__ ctl, unsigned int bits_and_flag, unsigned int& w0,
+                                                    unsigned int& w1, unsigned int& w2)
+{
+    const unsigned int bits = bits_and_flag & ~kTrackFlag;
+    if (!(bits_and_flag & kTrackFlag)) {
+        w0 = w1 = w2 = bits;
+        return (3u * bits + (unsigned int)kRadixBits - 1u) / (unsigned int)kRadixBits;
+    }
+    const unsigned long long var = (ctl[kCtlOr] | ((unsigned long long)ctl[kCtlOr + 1] << 32)) &
+                                   (ctl[kCtlOrn] | ((unsigned long long)ctl[kCtlOrn + 1] << 32));
+    const unsigned int fm = (1u << bits) - 1u;
+    const unsigned int v0 = (unsigned int)var & fm, v1 = (unsigned int)(var >> bits) & fm, v2 = (unsigned int)(var >> (2u * bits)) & fm;
+    w0 = v0 ? 32u - (unsigned int)__clz((int)v0) : 0u;
+    w1 = v1 ? 32u - (unsigned int)__clz((int)v1) : 0u;
+    w2 = v2 ? 32u - (unsigned int)__clz((int)v2) : 0u;
+    return (w0 + w1 + w2 + (unsigned int)kRadixBits - 1u) / (unsigned int)kRadixBits;
+}
+__device__ __forceinline__ SortPass sort_pass(const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits,
+                                              unsigned int p, unsigned int P)
+{
+    SortPass sp;
+    unsigned int w2;
+    const unsigned int R = real_passes(ctl, bits, sp.w0, sp.w1, w2);
+    bits &= ~kTrackFlag;
+    const unsigned int skipped = P - R;                     // R <= P: the widths never exceed the fields
+    sp.plain = skipped == 0u;
+    sp.skip = p < skipped;
+    const unsigned int e = p - skipped;
+    sp.in_a = (e & 1u) == 0u;
+    sp.lo = e * (unsigned int)kRadixBits;
+    sp.p0 = idx_bits; sp.p1 = idx_bits + bits; sp.p2 = idx_bits + 2u * bits;
+    sp.m0 = (1ull << sp.w0) - 1ull; sp.m1 = (1ull << sp.w1) - 1ull; sp.m2 = (1ull << w2) - 1ull;
+    return sp;
+}
+// true: the sorted keys are in buffer A
+__device__ __forceinline__ bool sorted_in_a(const unsigned int* __restrict__ ctl, unsigned int bits)
+{
+    unsigned int w0, w1, w2;
+    return (real_passes(ctl, bits, w0, w1, w2) & 1u) == 0u;
+}
 
 // table[chunk][digit] = occurrences of the digit in the chunk
 __global__ __launch_bounds__(kSortThreads)
-void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ m_ptr,
-                           unsigned int shift, unsigned int* __restrict__ table)
+void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys_a, const unsigned long long* __restrict__ keys_b,
+                           const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits, unsigned int pass,
+                           unsigned int n_passes, unsigned int* __restrict__ table)
 {
     __shared__ unsigned int hist[kRadix];
-    const unsigned int m = *m_ptr;
+    const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
+    if (sp.skip) return;
+    const unsigned long long* __restrict__ keys = sp.in_a ? keys_a : keys_b;
+    const unsigned int m = ctl[0];
     const unsigned int csize = sort_chunk_of(m), per_thread = csize / kSortThreads;
     const unsigned int chunks = (m + csize - 1) / csize;
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -296,7 +361,7 @@ void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys, const un
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = c0 + (it0 + q) * kSortThreads + threadIdx.x;
-                if (e < c1) atomicAdd(&hist[digit_of(k[q], shift)], 1u);
+                if (e < c1) atomicAdd(&hist[sp.digit(k[q])], 1u);
             }
         }
         __syncthreads();
@@ -308,12 +373,16 @@ void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys, const un
 // One wavefront per digit: exclusive scan of the digit's column over the chunks (in place) + the digit's total. The
 // column is strided (one row per chunk), so up to 16 x 64 entries are requested before any is used.
 __global__ __launch_bounds__(256)
-void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned int* __restrict__ m_ptr,
-                              unsigned int* __restrict__ digit_total)
+void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned int* __restrict__ ctl,
+                              unsigned int* __restrict__ digit_total, unsigned int bits, unsigned int pass, unsigned int n_passes)
 {
     constexpr unsigned int kCols = 16;
     __shared__ unsigned int tot[16][16];
-    const unsigned int m = *m_ptr;
+    {
+        unsigned int w0, w1, w2;
+        if (pass < n_passes - real_passes(ctl, bits, w0, w1, w2)) return;       // a skipped pass
+    }
+    const unsigned int m = ctl[0];
     const unsigned int csize = sort_chunk_of(m);
     const unsigned int chunks = (m + csize - 1) / csize;
     if (chunks <= 256u) {
@@ -379,15 +448,22 @@ void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned i
 // index arrays at all.
 template <bool PACKED>
 __global__ __launch_bounds__(kSortThreads)
-void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ idx_in,
-                              unsigned long long* __restrict__ keys_out, unsigned int* __restrict__ idx_out,
-                              const unsigned int* __restrict__ m_ptr, unsigned int shift,
-                              const unsigned int* __restrict__ table, const unsigned int* __restrict__ digit_total)
+void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned int* __restrict__ idx_a,
+                              unsigned long long* __restrict__ keys_b, unsigned int* __restrict__ idx_b,
+                              const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits, unsigned int pass,
+                              unsigned int n_passes, const unsigned int* __restrict__ table,
+                              const unsigned int* __restrict__ digit_total)
 {
     __shared__ unsigned int cnt[kSortWaves][kRadix];      // 64 KiB
     __shared__ unsigned int dbase[kRadix];       //  8 KiB
     __shared__ unsigned int wsum[kSortWaves];
-    const unsigned int m = *m_ptr;
+    const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
+    if (sp.skip) return;
+    const unsigned long long* __restrict__ keys_in = sp.in_a ? keys_a : keys_b;
+    const unsigned int* __restrict__ idx_in = sp.in_a ? idx_a : idx_b;
+    unsigned long long* __restrict__ keys_out = sp.in_a ? keys_b : keys_a;
+    unsigned int* __restrict__ idx_out = sp.in_a ? idx_b : idx_a;
+    const unsigned int m = ctl[0];
     const unsigned int csize = sort_chunk_of(m);
     const unsigned int chunks = (m + csize - 1) / csize;
     if (blockIdx.x >= chunks) return;
@@ -425,7 +501,7 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                if (e < w1) atomicAdd(&cnt[wave][digit_of(k[q], shift)], 1u);
+                if (e < w1) atomicAdd(&cnt[wave][sp.digit(k[q])], 1u);
             }
         }
         __syncthreads();
@@ -450,7 +526,7 @@ void pcs_voxel_scatter_kernel(const unsigned long long* __restrict__ keys_in, co
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = w0 + (r0 + q) * 64 + lane;
                 const bool live = e < w1;
-                const unsigned int d = digit_of(k[q], shift);
+                const unsigned int d = sp.digit(k[q]);
                 unsigned long long peers = __ballot(live);
 #pragma unroll
                 for (int b = 0; b < kRadixBits; b++) {
@@ -484,11 +560,13 @@ constexpr unsigned int kSegThreads = 256, kSegGrid = 4096;
 
 // heads[b] = runs that START in block b (block = 256 consecutive sorted elements)
 __global__ __launch_bounds__(kSegThreads)
-void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ m_ptr,
-                            unsigned int idx_bits, unsigned int* __restrict__ heads)
+void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys_a, const unsigned long long* __restrict__ keys_b,
+                            const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits,
+                            unsigned int* __restrict__ heads)
 {
     __shared__ unsigned int wsum[4];
-    const unsigned int m = *m_ptr;
+    const unsigned long long* __restrict__ keys = sorted_in_a(ctl, bits) ? keys_a : keys_b;
+    const unsigned int m = ctl[0];
     const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
     for (unsigned int b = blockIdx.x; b < blocks; b += gridDim.x) {
         const unsigned int g = b * kSegThreads + threadIdx.x;
@@ -588,14 +666,18 @@ __device__ __forceinline__ void write_voxel(int16_t* __restrict__ out, unsigned 
 }
 
 __global__ __launch_bounds__(kSegThreads)
-void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ idx,
-                             const VoxelPartial* __restrict__ part, const unsigned int* __restrict__ m_ptr,
+void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys_a, const unsigned int* __restrict__ idx_a,
+                             const unsigned long long* __restrict__ keys_b, const unsigned int* __restrict__ idx_b,
+                             const VoxelPartial* __restrict__ part, const unsigned int* __restrict__ ctl, unsigned int bits,
                              unsigned int idx_bits, const unsigned int* __restrict__ block_base, int16_t* __restrict__ out,
                              BlockPiece* __restrict__ lead, BlockPiece* __restrict__ trail)
 {
     __shared__ SegSum wv[4];
     __shared__ unsigned int wheads[4];
-    const unsigned int m = *m_ptr;
+    const bool in_a = sorted_in_a(ctl, bits);
+    const unsigned long long* __restrict__ keys = in_a ? keys_a : keys_b;
+    const unsigned int* __restrict__ idx = in_a ? idx_a : idx_b;
+    const unsigned int m = ctl[0];
     const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (unsigned int b = blockIdx.x; b < blocks; b += gridDim.x) {
@@ -707,6 +789,7 @@ struct Plan {
     Workspace w;
     VoxelDiv dv;
     unsigned int bits, idx_bits;
+    bool track_bits;      // have the pre-aggregation record which key bits vary, so that the sort can skip passes
 };
 
 // Carves the workspace and derives the key layout for a cloud of at most n_points points.
@@ -743,6 +826,16 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     while ((1ull << pl.idx_bits) < (unsigned long long)n_points) pl.idx_bits++;
     static const int pack_ok = [] { const char* v = getenv("PCS_VOXEL_PACKED"); return v ? atoi(v) : 1; }();
     if (!pack_ok || 3u * pl.bits + pl.idx_bits > 64u) pl.idx_bits = 0;
+    // A pass is skipped when the varying bits fit one digit less than the key's 3 * bits. A scene some 8 m across has
+    // 3 * log2(8 m / leaf) varying bits: 30 of 39 at 10 mm (3 passes instead of 4: 16 x 1080p from the rasters 1.36 -> 1.22
+    // ms), 27 of 36 at 20 mm (0.65 -> 0.61 ms), 24 of 33 at 50 mm (3 of 3: nothing to gain), 21 of 30 at 100 mm (2 of 3).
+    // Recording the bits costs the raster reader ~9 us per 16 x 1080p frame-set and a skipped pass is still three (empty)
+    // launches, so it only pays where a pass is long: it is asked for when the key needs four or more passes (leaves below
+    // 33 mm) — at 100 / 200 mm, where the sort handles ~0.1 M partials, it measured +5 us. A decision about speed only:
+    // without the record every bit counts as varying. PCS_VOXEL_TRACK=0/1 overrides.
+    static const int track_env = [] { const char* v = getenv("PCS_VOXEL_TRACK"); return v ? atoi(v) : -1; }();
+    pl.track_bits = 3u * pl.bits > 3u * kRadixBits;
+    if (track_env >= 0) pl.track_bits = track_env != 0;
     return hipSuccess;
 }
 
@@ -750,35 +843,32 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
 hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
 {
     const Workspace& w = pl.w;
-    const unsigned int bits = pl.bits, idx_bits = pl.idx_bits;
-    unsigned long long *kin = w.keys_a, *kout = w.keys_b;
-    unsigned int *iin = w.idx_a, *iout = w.idx_b;
-    const VoxelPartial* parts = w.part;
+    const unsigned int idx_bits = pl.idx_bits;
+    const unsigned int n_passes = (3u * pl.bits + kRadixBits - 1u) / kRadixBits;  // the device may skip the first few (SortPass)
+    const unsigned int bits = pl.bits | (pl.track_bits ? kTrackFlag : 0u);         // what the kernels get: width + tracking flag
     const unsigned int* m_ptr = w.ctl;
 
     // grids sized for what the launch can need at most, capped: the kernels loop over chunks / blocks
     const unsigned int max_chunks = std::max((n_points + kSortChunk - 1) / kSortChunk,
                                              std::min(kSortMinRows, (n_points + kSortMinChunk - 1) / kSortMinChunk));
     const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
-    for (unsigned int pass_bit = 0; pass_bit < 3u * bits; pass_bit += kRadixBits) {
-        const unsigned int shift = pass_bit + idx_bits;
-        hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, m_ptr, shift, w.table);
-        hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, m_ptr, w.digit_total);
+    for (unsigned int pass = 0; pass < n_passes; pass++) {
+        hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits,
+                           pass, n_passes, w.table);
+        hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, w.ctl, w.digit_total, bits, pass, n_passes);
         if (idx_bits)
-            hipLaunchKernelGGL(pcs_voxel_scatter_kernel<true>, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, m_ptr, shift,
-                               w.table, w.digit_total);
+            hipLaunchKernelGGL(pcs_voxel_scatter_kernel<true>, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.idx_a, w.keys_b,
+                               w.idx_b, w.ctl, bits, idx_bits, pass, n_passes, w.table, w.digit_total);
         else
-            hipLaunchKernelGGL(pcs_voxel_scatter_kernel<false>, dim3(sort_grid), dim3(kSortThreads), 0, st, kin, iin, kout, iout, m_ptr, shift,
-                               w.table, w.digit_total);
-        unsigned long long* tk = kin; kin = kout; kout = tk;
-        unsigned int* ti = iin; iin = iout; iout = ti;
+            hipLaunchKernelGGL(pcs_voxel_scatter_kernel<false>, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.idx_a, w.keys_b,
+                               w.idx_b, w.ctl, bits, idx_bits, pass, n_passes, w.table, w.digit_total);
     }
     const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
     const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
-    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, m_ptr, idx_bits, w.heads);
+    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits, w.heads);
     hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, m_ptr, w.ctl + 1, d_out_points);
-    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, kin, iin, parts, m_ptr, idx_bits, w.heads, d_out,
-                       w.lead, w.trail);
+    hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.idx_a, w.keys_b, w.idx_b, w.part,
+                       w.ctl, bits, idx_bits, w.heads, d_out, w.lead, w.trail);
     const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
     hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, m_ptr, w.lead, w.trail, d_out);
     return hipGetLastError();
@@ -799,7 +889,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
     hipError_t e = plan_for(n_points, leaf_mm, d_ws, ws_bytes, pl);
     if (e != hipSuccess) return e;
     const Workspace& w = pl.w;
-    e = hipMemsetAsync(w.ctl, 0, 4 * sizeof(unsigned int), st);
+    e = hipMemsetAsync(w.ctl, 0, 64 * sizeof(unsigned int), st);     // m, voxels, ...; second line: OR and OR-of-complements of the keys
     if (e != hipSuccess) return e;
     const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
     const dim3 agg_grid((n_points + per_block - 1) / per_block);
@@ -810,14 +900,20 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
         VoxelStage vs{};
         vs.keys = w.keys_a; vs.idx = w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
         vs.leaf = pl.dv.leaf; vs.bias_leaf = pl.dv.bias_leaf; vs.magic = pl.dv.magic; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
+        vs.track_bits = pl.track_bits ? 1u : 0u;
         e = launch_payload_voxel_partials(d_payload, n_points, d_n_points, vs, st);
         if (e != hipSuccess) return e;
-    } else if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv, pl.bits,
-                           pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
-    else
-        hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv, pl.bits,
-                           pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
+    } else {
+        // the 1024-lane readers (payloads that are only 2- or 4-byte aligned) do not record which key bits vary: every bit
+        // counts, no pass is skipped
+        pl.track_bits = false;
+        if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
+            hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv,
+                               pl.bits, pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
+        else
+            hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv,
+                               pl.bits, pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
+    }
     return sort_and_reduce(pl, n_points, d_out, d_out_points, st);
 }
 
@@ -827,11 +923,12 @@ hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t
     Plan pl;
     hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, pl);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(pl.w.ctl, 0, 4 * sizeof(unsigned int), st);
+    e = hipMemsetAsync(pl.w.ctl, 0, 64 * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
     stage->keys = pl.w.keys_a; stage->idx = pl.w.idx_a; stage->part = pl.w.part; stage->n_runs = pl.w.ctl;
     stage->leaf = pl.dv.leaf; stage->bias_leaf = pl.dv.bias_leaf; stage->magic = pl.dv.magic;
     stage->bits = pl.bits; stage->idx_bits = pl.idx_bits;
+    stage->track_bits = pl.track_bits ? 1u : 0u;
     return hipSuccess;
 }
 

@@ -42,6 +42,9 @@ __device__ __forceinline__ unsigned long long voxel_key(const VoxelDiv& dv, int 
 
 // LDS hash table of one pre-aggregation workgroup
 constexpr int kSlots = 2048, kProbe = 12;
+// control words of a voxel call (unsigned int ctl[64]): [0] partials, [1] voxels; on their own line: [32..33] OR of the
+// voxel keys written, [34..35] OR of their complements (which key bits vary at all: pcs_voxel.hip's sort drops the others)
+constexpr unsigned int kVoxCtlOr = 32, kVoxCtlOrn = 34;
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 // Probe sequence of a key: double hashing (start and an odd stride from two multiplicative hashes), so a crowded table
