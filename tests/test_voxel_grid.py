@@ -279,6 +279,23 @@ def test_rasters_to_voxel_grid_full_table_passes_points_through(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("leaf", [12, 60])
+def test_rasters_to_voxel_grid_more_streams_than_one_launch(oracle, leaf):
+    """20 cameras = two launches of the raster reader (16 + 4) appending to the same partial arrays."""
+    shapes = [(64, 48)] * 19 + [(128, 96)]
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
+    color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+    n_max = sum(c.n_points for c in cfgs)
+    stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+    want = oracle.voxel_grid(stitched, leaf)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        got = _rasters_to_voxels(ctx, dd, dc, leaf, n_max)
+    assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.gpu
 def test_rasters_to_voxel_grid_random_configurations(oracle):
     """Random raster sizes (multiples of 8 or not, down to a single row / column), leaves, flags and scenes."""
     rng = np.random.default_rng(20260928)
