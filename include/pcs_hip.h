@@ -262,7 +262,7 @@ int pcs_voxel_grid_device_counted(pcs_ctx* ctx, const int16_t* d_payload, const 
  * *d_out_points) is exactly pcs_voxel_grid_device applied to the payload pcs_process_frames_device would write for the
  * same rasters under the context's flags (CUTOFF / DROP_INVALID honoured; the voxel sums are integers, so the order of
  * the points is irrelevant and neither the ordered placement nor the 10-byte records ever touch HBM; 16 x 1920x1080 at
- * a 50 mm leaf: 0.24 ms instead of 0.46 ms for pcs_process_frames_device + pcs_voxel_grid_device_counted). The output
+ * a 50 mm leaf: 0.245 ms instead of 0.37 ms for pcs_process_frames_device + pcs_voxel_grid_device_counted). The output
  * needs room for every pixel of the frame-set in the worst case (sum of the streams' n_points). With a downsample
  * stride the stitched cloud is built internally first (the stride is defined on the kept points' ORDER).             */
 int pcs_process_frames_voxel_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
