@@ -913,9 +913,11 @@ def main():
                                    "pipelined_ms_per_step": round(tpipe * 1e3, 3), "pipelined_value": round(set_points / tpipe / 1e6, 1),
                                    "h2d_ms": round(t_up * 1e3, 3), "h2d_GBps": round(up_bytes / t_up / 1e9, 1),
                                    "d2h_ms": round(t_dn * 1e3, 3), "d2h_GBps": round(pay.nbytes / t_dn / 1e9, 1),
-                                   "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous: H2D (36.9 MB) + kernel + D2H (73.7 MB) per "
-                                   "frame-set, with long-lived pageable (numpy) buffers and with buffers from pcs_host_malloc; bounded by the host link, "
-                                   "not by the kernel"}
+                                   "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous, per frame-set. ms_per_step: long-lived pageable "
+                                   "(numpy) buffers = staged, H2D (36.9 MB) + kernel + D2H (73.7 MB). pinned_*: every buffer from pcs_host_malloc = "
+                                   "ZERO COPY, the kernels read the rasters and write the payload over PCIe themselves, both directions at once. "
+                                   "pipelined_*: pcs_submit_frames / pcs_collect_frames (staged, upload of k+1 overlaps download of k). All bounded "
+                                   "by the host link, not by the kernel"}
         if world == 1 and not args.no_cpu_baseline:
             with Leg(out, "cpu_baseline"):
                 out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)

@@ -694,6 +694,33 @@ def test_half_pixel_texcoords_fuzzed_configurations(oracle):
             assert d is None, f"trial {trial} extra {extra}: {d}"
 
 
+@pytest.mark.parametrize("flags,stride", [(0, 1), (FLAG_DROP_INVALID, 1), (FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, 1), (FLAG_DROP_INVALID, 3)])
+@pytest.mark.parametrize("shapes", [[(640, 480)] * 3, [(1280, 720), (321, 243)]])
+def test_host_api_zero_copy_with_pinned_buffers(oracle, flags, stride, shapes):
+    """pcs_process_frames with page-locked rasters and stitched buffer (pcs_host_malloc): the kernels read and write the
+    host memory directly, no staging copies. Same bytes, counts and header as the staged route (pageable numpy arrays,
+    and pinned ones with one raster left pageable) and as the oracle."""
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
+    color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags, stride)
+    with PcsContext(cfgs, flags=flags, downsample=stride) as ctx:
+        pd = [ctx.host_array(d.shape, np.uint16) for d in depth]
+        pc = [ctx.host_array(c.shape, np.uint8) for c in color]
+        for dst, src in zip(pd + pc, depth + color):
+            dst[...] = src
+        out = ctx.host_array((2 + ctx.max_payload_shorts,), np.int16)
+        out[...] = 0x5555
+        for trial, (dd, cc) in enumerate([(pd, pc), (pd[:-1] + [depth[-1]], pc), (depth, color)]):     # zero copy, staged, staged
+            buf, counts, size = ctx.process_frames(dd, cc, out=out)
+            assert counts == wcounts and size == want.size * 2, trial
+            assert int(np.frombuffer(buf[:2].tobytes(), np.int32)[0]) == size
+            assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
+            if trial == 0 and flags:
+                assert (buf[2 + want.size:2 + want.size + 64] == 0x5555).all()     # nothing written past the kept points
+            out[...] = 0x5555
+
+
 # ---------------------------------------------------------------------------------------------
 # throughput forms: K frame-sets per launch, all cameras' rs2::points per launch
 # ---------------------------------------------------------------------------------------------
