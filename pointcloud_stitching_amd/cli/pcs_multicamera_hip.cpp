@@ -156,7 +156,28 @@ int main(int argc, char** argv)
     const size_t cam_cap_bytes = (size_t)10 * 4u * 1000 * 1000;           // per-camera receive buffer (reference: 10 MB, :554)
     size_t stitched_shorts = source ? PCS_HEADER_SHORTS + pcs_max_payload_shorts(ctx)
                                     : PCS_HEADER_SHORTS + (size_t)n_streams * cam_cap_bytes / 2;
-    std::vector<int16_t> stitched(stitched_shorts);
+    // page-locked, like the rasters handed to pcs_process_frames below: the call then runs zero copy (the kernels read
+    // the rasters and write the stitched payload over PCIe themselves)
+    struct Pinned {
+        pcs_ctx* ctx; int16_t* p = nullptr; size_t n = 0;
+        explicit Pinned(pcs_ctx* c) : ctx(c) {}
+        void release() { if (p) pcs_host_free(ctx, p); p = nullptr; n = 0; }     // before pcs_destroy
+        bool resize(size_t shorts)
+        {
+            if (shorts <= n) return true;
+            if (p) pcs_host_free(ctx, p);
+            p = nullptr; n = 0;
+            if (pcs_host_malloc(ctx, (void**)&p, shorts * sizeof(int16_t)) != PCS_OK) return false;
+            n = shorts;
+            return true;
+        }
+        int16_t* data() { return p; }
+        size_t size() const { return n; }
+    } stitched(ctx);
+    if (!stitched.resize(stitched_shorts)) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+    std::vector<uint16_t*> pin_d(source ? n_streams : 0, nullptr);
+    std::vector<uint8_t*> pin_c(source ? n_streams : 0, nullptr);
+    std::vector<size_t> pin_db(pin_d.size(), 0), pin_cb(pin_c.size(), 0);
     std::vector<std::vector<uint16_t>> depth(source ? n_streams : 0);
     std::vector<std::vector<uint8_t>> color(source ? n_streams : 0);
     std::vector<std::vector<uint8_t>> cam_buf(source ? 0 : n_streams, std::vector<uint8_t>(source ? 0 : cam_cap_bytes));
@@ -189,7 +210,7 @@ int main(int argc, char** argv)
                 }
             }
         }
-        if (stitched.size() < PCS_HEADER_SHORTS + vox_cap_points * PCS_POINT_SHORTS) stitched.resize(PCS_HEADER_SHORTS + vox_cap_points * PCS_POINT_SHORTS);
+        if (!stitched.resize(PCS_HEADER_SHORTS + vox_cap_points * PCS_POINT_SHORTS)) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
     }
     // the voxel cloud of whatever d_vox / d_nvox hold -> stitched (header + records)
     auto fetch_voxels = [&]() -> bool {
@@ -236,7 +257,23 @@ int main(int argc, char** argv)
                 stitch_start = clockTime::now();                   // generation is not part of the stitch
             }
             std::vector<const uint16_t*> dp(n_streams); std::vector<const uint8_t*> cp(n_streams);
-            for (int s = 0; s < n_streams; s++) { dp[s] = depth[s].data(); cp[s] = color[s].data(); }
+            for (int s = 0; s < n_streams; s++) {
+                const size_t db = depth[s].size() * sizeof(uint16_t), cb = color[s].size();
+                if (db > pin_db[s]) {
+                    if (pin_d[s]) pcs_host_free(ctx, pin_d[s]);
+                    if (pcs_host_malloc(ctx, (void**)&pin_d[s], db) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+                    pin_db[s] = db;
+                }
+                if (cb > pin_cb[s]) {
+                    if (pin_c[s]) pcs_host_free(ctx, pin_c[s]);
+                    if (pcs_host_malloc(ctx, (void**)&pin_c[s], cb) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+                    pin_cb[s] = cb;
+                }
+                memcpy(pin_d[s], depth[s].data(), db);
+                memcpy(pin_c[s], color[s].data(), cb);
+                dp[s] = pin_d[s]; cp[s] = pin_c[s];
+            }
+            if (!raw) stitch_start = clockTime::now();             // handing the frames over is the source's part, not the stitch
             if (voxel_leaf) {
                 for (int s = 0; s < n_streams; s++) {
                     if (pcs_memcpy_h2d(ctx, d_depth[s], depth[s].data(), depth[s].size() * 2) != PCS_OK ||
@@ -308,12 +345,15 @@ int main(int argc, char** argv)
     if (client_fd >= 0) ::close(client_fd);
     if (listen_fd >= 0) ::close(listen_fd);
     for (void* p : d_cam) if (p) pcs_device_free(ctx, p);
+    for (void* p : pin_d) if (p) pcs_host_free(ctx, p);
+    for (void* p : pin_c) if (p) pcs_host_free(ctx, p);
     for (void* p : d_depth) if (p) pcs_device_free(ctx, p);
     for (void* p : d_color) if (p) pcs_device_free(ctx, p);
     if (d_vox) pcs_device_free(ctx, d_vox);
     if (d_nvox) pcs_device_free(ctx, d_nvox);
     if (d_stitched) pcs_device_free(ctx, d_stitched);
     if (node) pcs_node_destroy(node);
+    stitched.release();
     pcs_destroy(ctx);
     return 0;
 }
