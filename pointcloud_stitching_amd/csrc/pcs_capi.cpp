@@ -899,6 +899,22 @@ int pcs_copy_pointclouds_xyzrgb_to_buffer_device(pcs_ctx* c, int n_clouds, const
     return PCS_OK;
 }
 
+// The device's view of a page-locked host allocation (pcs_host_malloc, hipHostMalloc, hipHostRegister); false for
+// pageable memory.
+static bool host_device_view(const void* h, void** d)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    *d = a.devicePointer;
+    return true;
+}
+static bool zero_copy_enabled()
+{
+    static const int zc_env = [] { const char* v = getenv("PCS_ZERO_COPY"); return v ? atoi(v) : 1; }();
+    return zc_env != 0;
+}
+
 int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* c, int stream, const float* vertices, const float* texcoords,
                                          int n_points, const uint8_t* color, int16_t* pc_buffer, int* out_points)
 {
@@ -913,6 +929,22 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* c, int stream, const float* ve
     const size_t vb = (size_t)n_points * 3 * sizeof(float), tb = (size_t)n_points * 2 * sizeof(float);
     const size_t ob = (size_t)n_points * PCS_POINT_BYTES;
     int rc;
+    if (zero_copy_enabled()) {
+        // page-locked arrays on every side (see pcs_process_frames): the kernel reads and writes them in place
+        void *zv = nullptr, *zt = nullptr, *zc = nullptr, *zo = nullptr;
+        if (host_device_view(vertices, &zv) && host_device_view(texcoords, &zt) && host_device_view(color, &zc) &&
+            host_device_view(pc_buffer, &zo)) {
+            rc = pcs_copy_pointcloud_xyzrgb_to_buffer_device(c, stream, static_cast<const float*>(zv), static_cast<const float*>(zt),
+                                                             n_points, static_cast<const uint8_t*>(zc), static_cast<int16_t*>(zo), nullptr);
+            if (rc) return rc;
+            int count = n_points;
+            if (has_pred(c->flags))
+                HIPCHK(c, hipMemcpyAsync(&count, c->d_counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (out_points) *out_points = count;
+            return PCS_OK;
+        }
+    }
     if ((rc = ensure(c, c->s_vertices, c->s_vertices_cap, vb))) return rc;
     if ((rc = ensure(c, c->s_texcoords, c->s_texcoords_cap, tb))) return rc;
     if ((rc = ensure_rasters(c))) return rc;
@@ -1105,22 +1137,6 @@ try {
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_device_batch: host allocation failed (%s)", ex.what());
-}
-
-// The device's view of a page-locked host allocation (pcs_host_malloc, hipHostMalloc, hipHostRegister); false for
-// pageable memory.
-static bool host_device_view(const void* h, void** d)
-{
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
-    *d = a.devicePointer;
-    return true;
-}
-static bool zero_copy_enabled()
-{
-    static const int zc_env = [] { const char* v = getenv("PCS_ZERO_COPY"); return v ? atoi(v) : 1; }();
-    return zc_env != 0;
 }
 
 int pcs_process_frames(pcs_ctx* c, const uint16_t* const* depth, const uint8_t* const* color, int16_t* stitched,

@@ -721,6 +721,27 @@ def test_host_api_zero_copy_with_pinned_buffers(oracle, flags, stride, shapes):
             out[...] = 0x5555
 
 
+@pytest.mark.parametrize("flags", [0, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT])
+@pytest.mark.parametrize("n", [1, 7, 2048, 70001])
+def test_a2_twin_zero_copy_with_pinned_arrays(oracle, flags, n):
+    """pcs_copy_pointcloud_xyzrgb_to_buffer with page-locked vertices, texcoords, colour and pc_buffer: the kernel reads
+    and writes them in place; same bytes and count as the staged route and the oracle."""
+    sc, V, T, col = random_points(n, 4321 + n)
+    want = oracle.pack(sc, V, T, col, flags)
+    with PcsContext([sc], flags=flags) as ctx:
+        pv = ctx.host_array(V.shape, np.float32); pv[...] = V
+        pt = ctx.host_array(T.shape, np.float32); pt[...] = T
+        pcol = ctx.host_array(col.shape, np.uint8); pcol[...] = col
+        pout = ctx.host_array((n + 4, 5), np.int16); pout[...] = 0x5555
+        out, cnt = ctx.copy_pointcloud_xyzrgb_to_buffer(0, pv, pt, pcol, pc_buffer=pout)
+        assert cnt == want.shape[0]
+        assert_same(out.reshape(-1, 5)[:cnt], want)
+        assert (out.reshape(-1, 5)[cnt if flags else n:] == 0x5555).all()
+        got2, cnt2 = ctx.copy_pointcloud_xyzrgb_to_buffer(0, V, T, col)               # staged
+        assert cnt2 == cnt
+        assert_same(got2, want)
+
+
 # ---------------------------------------------------------------------------------------------
 # throughput forms: K frame-sets per launch, all cameras' rs2::points per launch
 # ---------------------------------------------------------------------------------------------
