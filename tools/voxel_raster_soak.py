@@ -10,8 +10,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloud_stitching_amd import synthetic as S                                      # noqa: E402
 from pointcloud_stitching_amd.api import PcsContext                                      # noqa: E402
-from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID, FLAG_FORCE_IEEE  # noqa: E402
+from pointcloud_stitching_amd.types import (FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID, FLAG_FORCE_IEEE,  # noqa: E402
+                                            FLAG_TEXCOORD_HALF_PIXEL)
 from oracle import pcs_oracle as O                                                       # noqa: E402
+from tests.test_gpu_parity import _random_config                                         # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -30,7 +32,16 @@ while time.time() - t0 < budget:
     flags = int(rng.choice([0, FLAG_DROP_INVALID, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, FLAG_CUTOFF | FLAG_DROP_INVALID,
                             FLAG_DROP_INVALID | FLAG_FORCE_IEEE]))
     stride = int(rng.choice([1, 1, 1, 1, 2, 5]))
-    cfgs = [S.synth_stream_config(w, h, int(rng.integers(0, 8))) for (w, h) in shapes]
+    # a third of the frame-sets use random cameras (distortion models, depth->colour rotations, colour rasters of another
+    # size, configurations the arithmetic certificate must refuse) instead of the synthetic rig
+    rand_cam = rng.random() < 0.33
+    csizes = [(int(rng.choice([64, 100, 192, 320])), int(rng.choice([48, 75, 108, 180]))) if rand_cam else (w, h) for (w, h) in shapes]
+    if rand_cam:
+        cfgs = [_random_config(rng, w, h, cw, ch, rng.random() < 0.4) for (w, h), (cw, ch) in zip(shapes, csizes)]
+        if rng.random() < 0.3:
+            flags |= FLAG_TEXCOORD_HALF_PIXEL
+    else:
+        cfgs = [S.synth_stream_config(w, h, int(rng.integers(0, 8))) for (w, h) in shapes]
     depth, color = [], []
     for s, (w, h) in enumerate(shapes):
         kind = rng.random()
@@ -41,7 +52,7 @@ while time.time() - t0 < budget:
         else:
             d = np.full(w * h, int(rng.integers(0, 3000)), np.uint16)
         depth.append(np.ascontiguousarray(d, np.uint16).reshape(-1))
-        color.append(S.synth_color(w, h, s, seed=int(rng.integers(1, 1 << 30))))
+        color.append(S.synth_color(csizes[s][0], csizes[s][1], s, seed=int(rng.integers(1, 1 << 30))))
     n_max = sum(c.n_points for c in cfgs)
     stitched, _ = O.process_frames(cfgs, depth, color, flags, stride)
     with PcsContext(cfgs, flags=flags, downsample=stride) as ctx:
