@@ -289,11 +289,17 @@ int   pcs_kernel_timing(pcs_ctx* ctx, int enable);
 int   pcs_kernel_times_ms(pcs_ctx* ctx, float* ms, int capacity, int* n);
 
 /* Page-locked host memory for the buffers that cross PCIe every frame (the reference mallocs its `buffer`
- * once, src/pcs-camera-optimized.cpp:157). Optional: with long-lived, already-touched malloc'd buffers the
- * ROCm runtime's pageable path measured within 3 % of this (2.25 vs 2.19 ms per 8x720p frame-set); what is
- * expensive is handing over a freshly allocated buffer every call (first-touch page faults, 7.5 ms). */
+ * once, src/pcs-camera-optimized.cpp:157). When every buffer of a host call is page-locked the call runs zero copy
+ * (pcs_process_frames: 1.6 instead of 2.25 ms per 8x720p frame-set; pcs_copy_pointcloud_xyzrgb_to_buffer likewise);
+ * with pageable memory the calls stage through device buffers. What is really expensive is handing over a freshly
+ * allocated buffer every call (first-touch page faults, 7.5 ms). */
 int   pcs_host_malloc(pcs_ctx* ctx, void** h_ptr, size_t bytes);
 int   pcs_host_free(pcs_ctx* ctx, void* h_ptr);
+/* Page-lock memory the caller already owns (the reference's `buffer = (short*)malloc(sizeof(short) * BUF_SIZE)`,
+ * src/pcs-camera-optimized.cpp:157; a capture pipeline's frame pool) so that the host entry points run zero copy on it.
+ * Register once, unregister before free(). */
+int   pcs_host_register(pcs_ctx* ctx, void* h_ptr, size_t bytes);
+int   pcs_host_unregister(pcs_ctx* ctx, void* h_ptr);
 
 /* Thin device-memory helpers so a C/C++ host needs no HIP headers. */
 int   pcs_device_malloc(pcs_ctx* ctx, void** d_ptr, size_t bytes);

@@ -328,6 +328,13 @@ class PcsContext:
         buf = (C.c_uint8 * max(n, 16)).from_address(p.value)
         return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
+    def host_register(self, a: np.ndarray) -> None:
+        """Page-lock an array the caller owns (pcs_host_register); the host entry points then run zero copy on it."""
+        self._check(self._lib.pcs_host_register(self._h, _ptr(a), a.nbytes))
+
+    def host_unregister(self, a: np.ndarray) -> None:
+        self._check(self._lib.pcs_host_unregister(self._h, _ptr(a)))
+
     def device_malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         self._check(self._lib.pcs_device_malloc(self._h, C.byref(p), nbytes))

@@ -1587,6 +1587,28 @@ int pcs_host_free(pcs_ctx* c, void* h_ptr)
     return PCS_OK;
 }
 
+int pcs_host_register(pcs_ctx* c, void* h_ptr, size_t bytes)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!h_ptr || !bytes) return fail(c, PCS_ERR_INVALID_ARG, "pcs_host_register: NULL pointer or zero size");
+    DeviceGuard guard(c->device);
+    hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, PCS_ERR_HIP, "hipHostRegister(%p, %zu) failed: %s", h_ptr, bytes, hipGetErrorString(e));
+    }
+    return PCS_OK;
+}
+
+int pcs_host_unregister(pcs_ctx* c, void* h_ptr)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipHostUnregister(h_ptr));
+    return PCS_OK;
+}
+
 int pcs_device_malloc(pcs_ctx* c, void** d_ptr, size_t bytes)
 {
     if (!c || !d_ptr) return PCS_ERR_INVALID_ARG;

@@ -60,6 +60,8 @@ SYMBOLS = [
     ("pcs_kernel_times_ms", C.c_int, [_VP, _P(C.c_float), C.c_int, _P(C.c_int)]),
     ("pcs_host_malloc", C.c_int, [_VP, _P(_VP), C.c_size_t]),
     ("pcs_host_free", C.c_int, [_VP, _VP]),
+    ("pcs_host_register", C.c_int, [_VP, _VP, C.c_size_t]),
+    ("pcs_host_unregister", C.c_int, [_VP, _VP]),
     ("pcs_device_malloc", C.c_int, [_VP, _P(_VP), C.c_size_t]),
     ("pcs_device_free", C.c_int, [_VP, _VP]),
     ("pcs_memcpy_h2d", C.c_int, [_VP, _VP, _VP, C.c_size_t]),

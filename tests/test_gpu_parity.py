@@ -711,6 +711,16 @@ def test_host_api_zero_copy_with_pinned_buffers(oracle, flags, stride, shapes):
             dst[...] = src
         out = ctx.host_array((2 + ctx.max_payload_shorts,), np.int16)
         out[...] = 0x5555
+        # a caller's own (numpy = malloc'ed) arrays, page-locked in place: zero copy as well
+        rd = [np.array(d) for d in depth]; rc = [np.array(c) for c in color]
+        rout = np.full(2 + ctx.max_payload_shorts, 0x5555, np.int16)
+        for a in rd + rc + [rout]:
+            ctx.host_register(a)
+        buf, counts, size = ctx.process_frames(rd, rc, out=rout)
+        assert counts == wcounts and size == want.size * 2
+        assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
+        for a in rd + rc + [rout]:
+            ctx.host_unregister(a)
         for trial, (dd, cc) in enumerate([(pd, pc), (pd[:-1] + [depth[-1]], pc), (depth, color)]):     # zero copy, staged, staged
             buf, counts, size = ctx.process_frames(dd, cc, out=out)
             assert counts == wcounts and size == want.size * 2, trial
