@@ -72,6 +72,11 @@ def parse():
     ap.add_argument("--mode", choices=["dense", "drop_invalid", "cutoff", "pack", "pack_batch", "batch", "batch_drop_invalid"], default="dense",
                     help="diagnostic: make another kernel the headline of the line (for profiling one kernel at a time): "
                          "the compaction path, the a2 twin per stream / batched, or K frame-sets per launch")
+    ap.add_argument("--workload", choices=["stitch", "config5"], default="stitch",
+                    help="stitch (default): the metric's workload (BASELINE configs[2] at N=1, configs[3] at N=8). config5: BASELINE "
+                         "configs[4] — 16 x 1920x1080 streams sharded 16/N per GPU, invalid-depth compaction, voxel grid of the "
+                         "stitched cloud on rank 0 (per-rank voxel partials, one exchange, one sort + segmented mean)")
+    ap.add_argument("--leaf", type=int, default=50, help="config5: voxel leaf in millimetres")
     ap.add_argument("--batch-sets", type=int, default=4, help="frame-sets per launch of the batched-dense leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--preheat-ms", type=float, default=400.0,
@@ -206,8 +211,208 @@ class Leg:
         return False
 
 
+def run_config5(args):
+    """BASELINE.json configs[4]: 16 synthetic 1920x1080 streams, 16/N per GPU, wavefront invalid-depth compaction and a
+    voxel-grid downsample of the stitched cloud on rank 0. A step = one frame-set through
+      rank r : rasters -> voxel partials of its cameras (pcs_process_frames_voxel_partials_device; the points themselves
+               are never written: the voxel sums are integers, so the grid of the union IS the grid of the stitched cloud)
+      all    : all_gather of the partial counts, ONE grouped exchange of keys + partials to rank 0 (N > 1)
+      rank 0 : sort + segmented mean over everybody's partials (pcs_voxel_grid_from_partials_device).
+    The layout it replaces: src/pcs-multicamera-client.cpp:373-409 (concatenate on the centre) +
+    src/pcs-multicamera-optimized.cpp:226-248 (downsample there)."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from pointcloud_stitching_amd import synthetic as Syn
+    from pointcloud_stitching_amd.api import PcsContext
+    from pointcloud_stitching_amd.stitch import ShardedVoxelGrid
+    from pointcloud_stitching_amd.types import POINT_SHORTS, FLAG_DROP_INVALID
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 through python -m torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
+    debug_gloo = args.debug_backend == "gloo"
+    if debug_gloo:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if debug_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:   # a one-rank group keeps the code path identical (gloo: no device traffic at world 1)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+    full = (args.streams, args.width, args.height) == (8, 1280, 720)        # the stitch workload's defaults: not given
+    total_streams, W, H = (16, 1920, 1080) if full else (args.streams, args.width, args.height)
+    if total_streams % world:
+        raise SystemExit(f"config5 shards {total_streams} streams over {world} GPUs: not divisible")
+    S, LEAF = total_streams // world, args.leaf
+    npts = W * H
+    cfgs = [Syn.synth_stream_config(W, H, rank * S + s) for s in range(S)]
+    ctx = PcsContext(cfgs, device=local_rank, flags=FLAG_DROP_INVALID)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+
+    in_bytes = S * npts * 5
+    R = max(args.ring, 2) if args.ring else max(3, -(-2 * INFINITY_CACHE_BYTES // in_bytes) + 2)
+    dep0 = [torch.from_numpy(Syn.synth_depth(W, H, rank * S + s).reshape(-1).view(np.uint8)).to(dev) for s in range(S)]
+    col0 = [torch.from_numpy(Syn.synth_color(W, H, rank * S + s)).to(dev) for s in range(S)]
+    sets = [(dep0, col0)] + [([d.clone() for d in dep0], [c.clone() for c in col0]) for _ in range(R - 1)]
+    VP = C.c_void_p
+    ptrs = [([t.data_ptr() for t in d], [t.data_ptr() for t in c]) for d, c in sets]
+    svg = ShardedVoxelGrid(ctx, LEAF, dev)
+    out_shorts = svg.total_cap * POINT_SHORTS
+    vox = torch.empty(out_shorts if rank == 0 else 8, dtype=torch.int16, device=dev)
+    k = [0]
+
+    def pre():
+        d, c = ptrs[k[0] % R]; k[0] += 1
+        svg.pre_aggregate(d, c)
+
+    def reduce_():
+        if rank != 0:
+            return
+        if world == 1:      # nothing to size on the host: the partial count is read from device memory
+            ctx.voxel_grid_from_partials_device(svg.keys.data_ptr(), svg.parts.data_ptr(), svg.cap, LEAF, vox.data_ptr(), out_shorts,
+                                                svg.n_vox.data_ptr(), d_n_partials=svg.n_local.data_ptr())
+        else:
+            svg.reduce(vox.data_ptr(), out_shorts)
+
+    def step():
+        pre()
+        if world > 1:
+            svg.exchange()
+        reduce_()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- correctness before timing: the root's voxel cloud against the committed oracle digests where they apply --------------
+    step(); torch.cuda.synchronize(dev)
+    check = {}
+    if rank == 0:
+        nv = int(svg.n_vox[0].item())
+        digest = hashlib.sha256(vox[:nv * POINT_SHORTS].cpu().numpy().tobytes()).hexdigest()
+        check = {"voxels": nv, "voxel_sha256": digest, "golden": None}
+        gpath = os.path.join(ROOT, "tests", "golden", "config5_digests.json")
+        if (total_streams, W, H) == (16, 1920, 1080) and os.path.exists(gpath):
+            gold = json.load(open(gpath))["voxel"].get(str(LEAF))
+            if gold:
+                check["golden"] = bool(gold["voxels"] == nv and gold["sha256"] == digest)
+                if not check["golden"]:
+                    raise SystemExit(f"bench aborted: config5 voxel cloud differs from the oracle digest (leaf {LEAF} mm)")
+    for _ in range(max(args.warmup, 3)):
+        step()
+    barrier()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.timer_end()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        red = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if debug_gloo else dev)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed = float(red.item())
+
+    # ---- the phases on their own (synchronised between them: a diagnostic, not the timed region) ---------------------------------
+    ph = {"kernel": 0.0, "exchange": 0.0, "root_voxel": 0.0}
+    n_ph = 10
+    for _ in range(n_ph):
+        barrier(); a = time.perf_counter()
+        pre(); torch.cuda.synchronize(dev); b = time.perf_counter()
+        if world > 1:
+            svg.exchange(); torch.cuda.synchronize(dev)
+        c = time.perf_counter()
+        reduce_(); torch.cuda.synchronize(dev); d = time.perf_counter()
+        ph["kernel"] += b - a; ph["exchange"] += c - b; ph["root_voxel"] += d - c
+    # the dominant kernel, by HIP events on the launch stream
+    ctx.timer_begin()
+    for _ in range(20):
+        pre()
+    ctx.timer_end()
+    kern_ms = ctx.timer_elapsed_ms() / 20
+    m_local = int(svg.n_local[0].item())
+    counts = svg.counts if world > 1 else [m_local]
+    if world > 1:
+        mx = torch.tensor([ph["kernel"], ph["exchange"], ph["root_voxel"]], dtype=torch.float64,
+                          device=torch.device("cpu") if debug_gloo else dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        ph = dict(zip(("kernel", "exchange", "root_voxel"), [float(x) for x in mx.tolist()]))
+
+    if rank == 0:
+        pts_step = total_streams * npts
+        ms_per_step = elapsed * 1e3 / args.steps
+        algo = S * npts * 5 + m_local * 40            # this rank's launch: 2 B Z16 + 3 B RGB8 per pixel in, 40 B per partial out
+        ach = algo / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpoints/s in (16x1920x1080 streams: deproject+transform+RGB+pack, invalid-depth compaction, voxel grid of the stitched cloud)",
+            "value": round(pts_step * args.steps / elapsed / 1e6, 1), "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[4]: {total_streams} synthetic {W}x{H} Z16+RGB8 streams, {S} per GPU x {world} GPU(s), "
+                                   f"PCS_FLAG_DROP_INVALID (wavefront invalid-depth compaction), voxel-grid downsample (leaf {LEAF} mm) of the "
+                                   f"stitched cloud on rank 0: per-rank voxel partials, one exchange of the partials, one sort + segmented mean",
+                       "streams_total": total_streams, "streams_per_gpu": S, "width": W, "height": H, "leaf_mm": LEAF,
+                       "ring_frame_sets": R, "ring_inputs_between_rereads_mbytes": round((R - 1) * in_bytes / 1e6, 1),
+                       "parallelism": f"streams sharded {S}/GPU x {world}", "pipeline": "synchronous per step (the exchange is sized by "
+                       "data-dependent counts: one host round trip per step at N > 1; none at N = 1)"},
+            "check": check,
+            "phases_ms": {"kernel": round(ph["kernel"] * 1e3 / n_ph, 4), "exchange": round(ph["exchange"] * 1e3 / n_ph, 4),
+                          "root_voxel": round(ph["root_voxel"] * 1e3 / n_ph, 4),
+                          "note": "host clock with a device synchronisation after each phase, max over ranks; the timed region has none at N = 1"},
+            "partials_per_rank": counts, "partials_total": int(sum(counts)),
+            "exchange_bytes_per_step": int(sum(counts[1:]) * 40),
+            "payload_route_bytes_per_step": None,
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "pcs_fused_voxel_partials_kernel", "avg_launch_ms": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": int(algo),
+                         "note": "rank 0's pre-aggregation launch: 5 B per pixel in + 40 B per partial out; the kernel is VALU / LDS bound "
+                                 "(deprojection + pack + voxel key + LDS hash table per pixel), not HBM bound",
+                         "timing": "hipEvent pair on the launch stream around 20 back-to-back launches"},
+        }
+        if debug_gloo:
+            out["debug"] = "gloo control-flow test: all ranks on one GPU, host-staged exchange; numbers are meaningless"
+        if world == 1 and not args.no_cpu_baseline:
+            with Leg(out, "cpu_baseline"):
+                from oracle import pcs_oracle as O
+                ns = min(2, S)
+                hd = [Syn.synth_depth(W, H, s) for s in range(ns)]
+                hc = [Syn.synth_color(W, H, s) for s in range(ns)]
+                tc = time.perf_counter()
+                st_, _ = O.process_frames(cfgs[:ns], hd, hc, FLAG_DROP_INVALID, 1)
+                O.voxel_grid(st_, LEAF)
+                tc = time.perf_counter() - tc
+                out["cpu_baseline"] = {"value": round(ns * npts / tc / 1e6, 2), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                                       "sample": f"{ns} of {total_streams} streams: deprojection + pack + compaction + stitch + voxel grid by the "
+                                                 f"scalar CPU oracle, one pass ({tc:.1f} s); the reference itself has no voxel grid "
+                                                 f"(src/pcs-multicamera-optimized.cpp:17 only includes the header)"}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "config5":
+        return run_config5(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -298,6 +503,9 @@ def main():
     kept_frac = float(np.mean([(d != 0).mean() for d in host0[0]]))      # rho of the invalid-drop compaction
 
     gather = world > 1 and not args.no_gather
+    variable = gather and mode_flags != 0        # compaction: per-rank counts differ -> counts all-gathered, payloads sent point to point
+    d_cnt = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+    last_counts = [None]
     stitched = None
     if gather:
         from pointcloud_stitching_amd.stitch import RankStitcher
@@ -371,7 +579,8 @@ def main():
 
     def launch_dense(handle=None):
         dp, cp, out = call_args[next_slot()]
-        check(lib.pcs_process_frames_device(handle or h, dp, cp, out, payload_shorts, None), handle)
+        check(lib.pcs_process_frames_device(handle or h, dp, cp, out, payload_shorts,
+                                            VP(d_cnt.data_ptr()) if (variable and handle is None) else None), handle)
 
     def launch_pack_single():
         pr = build_pack_ring()
@@ -427,7 +636,13 @@ def main():
     step_no = [0]
 
     def step():
-        if gather:
+        if variable:
+            # the kept counts are data dependent: launch, all_gather the totals (read from the device word the kernel wrote),
+            # one grouped send/recv into the root buffer at the camera-order offsets. Synchronous per step.
+            slot = counter[0] % R
+            launch()
+            last_counts[0] = st.gather_variable(d_out[slot], d_cnt[S], stitched[0] if rank == 0 else None)
+        elif gather:
             k = step_no[0]; step_no[0] = k + 1
             if pending[k & 1] is not None:       # the buffer pair (slot's out, stitched[k&1]) is free again
                 pending[k & 1].wait()
@@ -494,8 +709,11 @@ def main():
             gather_error = (gather_error or "") + f" | all_reduce: {e}"[:200]
         if rank == 0 and gather:
             # a7: rank r's payload must sit at [r*n, (r+1)*n) of the stitched buffer; rank 0's own slice is checkable here
-            own = stitched[0][:payload_shorts]
-            if not torch.equal(own, d_out[first_slot]):
+            own_n = last_counts[0][0] * POINT_SHORTS if variable else payload_shorts
+            own = stitched[0][:own_n]
+            if variable:
+                first_slot = (counter[0] - 1) % R        # the slot of the most recent step
+            if not torch.equal(own, d_out[first_slot][:own_n]):
                 raise SystemExit("bench aborted: gathered slice of rank 0 differs from its payload")
     for _ in range(args.warmup):
         step()
@@ -596,8 +814,12 @@ def main():
             out["gather_error"] = gather_error
             out["config"]["gather_to_rank0"] = False
         if shard_only is not None:
-            gb = (world - 1) * payload_shorts * 2 * args.steps / elapsed / 1e9
-            out["gather"] = {"root_ingest_GBps": round(gb, 1), "bytes_per_peer_per_step": payload_shorts * 2,
+            peer_bytes = (sum(last_counts[0][1:]) * 10 / max(world - 1, 1)) if variable else payload_shorts * 2
+            gb = (world - 1) * peer_bytes * args.steps / elapsed / 1e9
+            out["gather"] = {"root_ingest_GBps": round(gb, 1), "bytes_per_peer_per_step": int(peer_bytes),
+                             "form": ("variable: all_gather of the kept counts (device) + grouped isend/irecv at camera-order offsets, "
+                                      "synchronous per step") if variable else "fixed: dist.gather into views of the root buffer, double-buffered",
+                             "counts_per_rank": last_counts[0] if variable else None,
                              "note": "value includes one RCCL gather of every rank's payload to rank 0 per step "
                                      "(double-buffered against the next kernel); it is bound by the peers' xGMI links "
                                      "into the root, not by the kernel",

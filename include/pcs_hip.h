@@ -275,6 +275,36 @@ int pcs_process_frames_voxel_device(pcs_ctx* ctx, const uint16_t* const* d_depth
 int pcs_voxel_grid(pcs_ctx* ctx, const int16_t* payload, int n_points, int leaf_mm,
                    int16_t* out, size_t out_shorts, int* out_points);
 
+/* ---- voxel PARTIALS: the exchange format of a multi-GPU voxel grid (BASELINE configs[4]: 16 streams, 2 per GPU) ---------- *
+ * The voxel sums are integers, so the grid of a stitched cloud is the grid of the UNION of its cameras' points in any
+ * order: each GPU pre-aggregates its own cameras into partials — one per voxel seen by a patch of pixels: the voxel's key
+ * (z, y, x voxel indices packed, a function of leaf_mm alone) and the seven sums — the partials of all GPUs are
+ * concatenated on the root (keys with keys, sums with sums; ~40 B per occupied voxel and patch instead of 10 B per point,
+ * 7x fewer bytes over xGMI for 16 x 1920x1080 at 50 mm) and ONE sort + segmented mean there gives exactly the bytes
+ * pcs_voxel_grid_device would give for the stitched cloud. The reference concatenates the cameras' full payloads on the
+ * centre (src/pcs-multicamera-client.cpp:373-409) and has no voxel grid (src/pcs-multicamera-optimized.cpp:17 only
+ * includes the header); libpcs_node / pointcloud_stitching_amd.stitch drive the exchange.                                */
+typedef struct pcs_voxel_partial {          /* 32 bytes */
+    int32_t  sx, sy, sz;                    /* sums of the int16 millimetre coordinates of the points of this partial      */
+    uint32_t r, g, b;                       /* sums of the colour bytes                                                      */
+    uint32_t n;                             /* points summed (>= 1)                                                          */
+    uint32_t pad;
+} pcs_voxel_partial;
+#define PCS_VOXEL_PARTIAL_WIRE_BYTES 40     /* one uint64 key + one pcs_voxel_partial                                        */
+
+/* Rasters -> partials of this context's streams under its flags (CUTOFF / DROP_INVALID / downsample honoured exactly as
+ * pcs_process_frames_voxel_device does). d_keys / d_partials need room for `capacity` >= pcs_max_payload_shorts / 5 entries
+ * (worst case: every kept point its own partial); *d_n_partials (device) receives how many were written. Asynchronous.    */
+int pcs_process_frames_voxel_partials_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                             int leaf_mm, uint64_t* d_keys, pcs_voxel_partial* d_partials, size_t capacity,
+                                             int32_t* d_n_partials);
+/* Partials (of any number of pcs_process_frames_voxel_partials_device calls with the SAME leaf_mm, concatenated in any
+ * order) -> the voxel grid. n_partials entries are read, or *d_n_partials (device, <= n_partials, which then is the
+ * capacity) when that pointer is given. The output needs room for n_partials points. Asynchronous.                       */
+int pcs_voxel_grid_from_partials_device(pcs_ctx* ctx, const uint64_t* d_keys, const pcs_voxel_partial* d_partials,
+                                        int n_partials, const int32_t* d_n_partials, int leaf_mm, int16_t* d_out,
+                                        size_t out_shorts, int32_t* d_out_points);
+
 /* ---- stream / timing plumbing ----------------------------------------------------------- */
 int   pcs_set_stream(pcs_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL = own stream) */
 void* pcs_get_stream(pcs_ctx* ctx);

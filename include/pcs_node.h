@@ -10,6 +10,10 @@
  *
  * This is the single-process form (ncclCommInitAll). The one-process-per-GPU form used by bench.py lives
  * in pointcloud_stitching_amd/stitch.py (torch.distributed / RCCL).
+ *
+ * Status: the one-GPU paths (n_devices == 1) run in the test-suite on hardware. With n_devices > 1 the RCCL exchange has
+ * not yet met a multi-GPU box (the development boxes have one GPU): treat the N > 1 paths, and in particular the
+ * pipelined pcs_node_submit_device / pcs_node_wait pair, as EXPERIMENTAL until a hardware run is on record.
  */
 #ifndef PCS_NODE_H
 #define PCS_NODE_H
@@ -23,7 +27,9 @@ extern "C" {
 typedef struct pcs_node pcs_node;
 
 /* Streams [r*streams_per_device, (r+1)*streams_per_device) belong to device_ids[r]; device_ids[0] is the root.
- * `streams` has n_devices*streams_per_device entries in global camera order. flags/downsample as pcs_config. */
+ * `streams` has n_devices*streams_per_device entries in global camera order. flags/downsample as pcs_config.
+ * Like pcs_create, refuses (PCS_ERR_INVALID_ARG, before any device is touched) a configuration whose stitched payload
+ * would not fit the wire format's int32 byte count (more than 214 748 364 points in all). */
 int  pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
                      const pcs_stream_config* streams, uint32_t flags, int downsample);
 void pcs_node_destroy(pcs_node* node);
@@ -48,11 +54,47 @@ int  pcs_node_process_device(pcs_node* node, const uint16_t* const* d_depth, con
  * blocks until that frame-set's stitched payload is complete on the root. Writing the loop as  submit(k+1); wait(k);
  * overlaps the xGMI exchange of frame-set k with the kernels of k+1 (each GPU keeps two payload buffers). The two
  * frame-sets need different stitched buffers. Without CUTOFF / DROP_INVALID nothing is read back from the GPUs;
- * with a predicate submit synchronises each GPU once (the exchange is sized by the data dependent counts).
- * PCS_ERR_CAPACITY from submit = two frame-sets already in flight. pcs_node_process_device = submit + wait.     */
+ * with a predicate submit reads every GPU's counts back (one asynchronous copy per GPU, all in flight together, then one
+ * wait per GPU: the exchange is sized by the data dependent counts).
+ * PCS_ERR_CAPACITY from submit = two frame-sets already in flight. pcs_node_process_device = submit + wait.
+ * An RCCL failure inside the exchange closes the group, aborts the communicators and leaves the node unusable
+ * (every later call fails with PCS_ERR_HIP); pcs_node_wait never blocks on a failed submit.                      */
 int  pcs_node_submit_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                             int16_t* d_stitched_payload_root, size_t stitched_shorts, int* ticket);
 int  pcs_node_wait(pcs_node* node, int ticket, int* points_per_stream, int* total_points);
+
+/* ---- BASELINE configs[4]: voxel-grid downsample of the cloud the node's cameras stitch to ---------------------------- *
+ * 16 x 1920x1080 streams, 2 per GPU, invalid-depth compaction, voxel grid of the stitched cloud on the root. Two routes, the
+ * SAME bytes (the voxel sums are integers, so neither the order of the points nor where they were pre-summed matters):
+ *   PCS_NODE_VOXEL_PARTIALS  every GPU pre-aggregates its own cameras into voxel partials
+ *                            (pcs_process_frames_voxel_partials_device), ONE grouped exchange moves the partials to the
+ *                            root (40 B per occupied voxel and pixel patch — 16 x 1080p at 50 mm: ~40 MB instead of the
+ *                            298 MB of packed points), one sort + segmented mean there
+ *                            (pcs_voxel_grid_from_partials_device). The default.
+ *   PCS_NODE_VOXEL_PAYLOADS  the literal shape of src/pcs-multicamera-client.cpp:373-409 + a downsample on the centre
+ *                            (src/pcs-multicamera-optimized.cpp:226-248): the (compacted) payloads are gathered to the root
+ *                            in camera order as pcs_node_process_device does, then pcs_voxel_grid_device on the stitched cloud.
+ * Device form: rasters on their owning GPUs, the voxel cloud (records, no header) left on the root GPU; *n_voxels on the
+ * host. Synchronous on return. d_voxels_root needs room for every pixel of the node in the worst case
+ * (pcs_node_max_payload_shorts with downsample 1). `stats` (optional) receives how the call spent its time.            */
+#define PCS_NODE_VOXEL_PARTIALS 0
+#define PCS_NODE_VOXEL_PAYLOADS 1
+typedef struct pcs_node_voxel_stats {
+    float    kernels_ms;         /* root GPU: start of the call -> its own pre-aggregation (or pack) kernel done           */
+    float    exchange_ms;        /* root GPU: -> every peer's partials (payload) received (includes waiting for the peers' kernels) */
+    float    root_voxel_ms;      /* root GPU: -> sort + segmented mean done                                                  */
+    int64_t  exchanged_bytes;    /* bytes the peers sent to the root                                                          */
+    int32_t  partials;           /* partials (route PARTIALS) or points (route PAYLOADS) the root reduced                    */
+    int32_t  voxels;
+} pcs_node_voxel_stats;
+int  pcs_node_process_voxel_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                   int leaf_mm, int route, int16_t* d_voxels_root, size_t voxels_shorts, int* n_voxels,
+                                   pcs_node_voxel_stats* stats);
+/* Host form: rasters uploaded to their owning GPUs, the voxel cloud downloaded into `out` with the wire header like
+ * pcs_node_process ([int32 bytes][records] when write_header; records always start at out + 2 shorts).              */
+int  pcs_node_process_voxel(pcs_node* node, const uint16_t* const* depth, const uint8_t* const* color, int leaf_mm, int route,
+                            int16_t* out, size_t out_shorts, int write_header, int* out_size_bytes,
+                            pcs_node_voxel_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -286,6 +286,24 @@ class PcsContext:
         self._check(self._lib.pcs_process_frames_voxel_device(self._h, dp, cp, int(leaf_mm), d_out, out_shorts,
                                                               d_out_points or None))
 
+    def process_frames_voxel_partials_device(self, d_depth: Sequence[int], d_color: Sequence[int], leaf_mm: int,
+                                             d_keys: int, d_partials: int, capacity: int, d_n_partials: int) -> None:
+        """Rasters -> voxel partials (raw keys + sums) in caller arrays: what a rank contributes to a multi-GPU voxel grid
+        (pcs_process_frames_voxel_partials_device)."""
+        if len(d_depth) != self.n_streams or len(d_color) != self.n_streams:
+            raise ValueError("need one depth and one colour pointer per stream")
+        dp = (C.c_void_p * self.n_streams)(*d_depth)
+        cp = (C.c_void_p * self.n_streams)(*d_color)
+        self._check(self._lib.pcs_process_frames_voxel_partials_device(self._h, dp, cp, int(leaf_mm), d_keys, d_partials,
+                                                                       int(capacity), d_n_partials))
+
+    def voxel_grid_from_partials_device(self, d_keys: int, d_partials: int, n_partials: int, leaf_mm: int, d_out: int,
+                                        out_shorts: int, d_out_points: int = 0, d_n_partials: int = 0) -> None:
+        """Concatenated partials of any number of ranks -> the voxel grid (pcs_voxel_grid_from_partials_device)."""
+        self._check(self._lib.pcs_voxel_grid_from_partials_device(self._h, d_keys, d_partials, int(n_partials),
+                                                                  d_n_partials or None, int(leaf_mm), d_out, out_shorts,
+                                                                  d_out_points or None))
+
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))

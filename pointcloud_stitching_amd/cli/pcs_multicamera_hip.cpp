@@ -19,6 +19,8 @@
 //              -V <mm> serve the voxel-grid downsample (leaf in mm, BASELINE config 5) of the stitched cloud instead of the
 //                      cloud itself: with -i one device call from the rasters (pcs_process_frames_voxel_device), with -c the
 //                      voxel grid of the concatenated payloads;  -Z  drop invalid-depth pixels (PCS_FLAG_DROP_INVALID, -i only)
+//              -G <n> -V <mm>  BASELINE configs[4]: cameras sharded over n GPUs, per-GPU voxel partials, one RCCL exchange, sort +
+//                      segmented mean on GPU 0 (libpcs_node: pcs_node_process_voxel); -R payloads gathers the packed payloads instead
 //     with neither -i nor -c the cameras are 8 synthetic 1280x720 streams on this node (there are no live cameras here).
 #include <chrono>
 #include <cstdio>
@@ -42,6 +44,7 @@ typedef std::chrono::duration<double, std::milli> timeMilli;
 static bool timer = false, serve = true;
 static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30, n_gpus = 0, voxel_leaf = 0;
 static bool drop_invalid = false;
+static int voxel_route = PCS_NODE_VOXEL_PARTIALS;
 static const char* source = nullptr;
 static const char* cameras = nullptr;
 static const char* dump_path = nullptr;
@@ -58,6 +61,8 @@ static void usage()
               << " -N <n> streams   -g <gpu>   -p <port> (default 9000)   -r <frame-sets>   -o <file>   -q no server\n"
               << " -G <n>           shard the -i cameras over n GPUs of this node (one process, RCCL gather to GPU 0)\n"
               << " -V <mm>          serve the voxel-grid downsample (leaf in millimetres) of the stitched cloud;  -Z drop invalid depth\n"
+              << "                  with -G: every GPU pre-aggregates its cameras, ONE exchange of the voxel partials, reduced on GPU 0\n"
+              << "                  (-R payloads: gather the packed payloads instead and downsample the stitched cloud on GPU 0)\n"
               << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
 }
 
@@ -65,7 +70,7 @@ int main(int argc, char** argv)
 {
     signal(SIGPIPE, SIG_IGN);
     int c;
-    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:Z")) != -1) {
+    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:ZR:")) != -1) {
         switch (c) {
             case 't': timer = true; break;
             case 'd': downsample = atoi(optarg); break;
@@ -82,6 +87,7 @@ int main(int argc, char** argv)
             case 'q': serve = false; break;
             case 'G': n_gpus = atoi(optarg); break;
             case 'V': voxel_leaf = atoi(optarg); break;
+            case 'R': voxel_route = (optarg[0] == 'p' && optarg[1] == 'a' && optarg[2] == 'y') ? PCS_NODE_VOXEL_PAYLOADS : PCS_NODE_VOXEL_PARTIALS; break;
             case 'Z': drop_invalid = true; break;
             case 's': case 'v': case 'n':
                 std::cerr << "-" << (char)c << " drives the reference's PCL viewer / PLY writer, which this build does not include" << std::endl;
@@ -93,7 +99,13 @@ int main(int argc, char** argv)
     if (source && cameras) { std::cerr << "give at most one of -i <src> or -c <edge list>" << std::endl; usage(); return 2; }
     if (!source && !cameras) source = "synth:1280x720";      // no live cameras on this node: the synthetic generator
     if (voxel_leaf < 0 || voxel_leaf > 32767) { std::cerr << "-V leaf must be 1..32767 mm" << std::endl; return 2; }
-    if (voxel_leaf && n_gpus > 0) { std::cerr << "-V runs on one GPU (omit -G)" << std::endl; return 2; }
+    if (optind < argc) {      // a leftover positional argument: most likely the pre-round-2 `-f <src>` spelling
+        std::cerr << "unexpected argument '" << argv[optind] << "': the frame source is given with -i <src> (-f is the reference's "
+                     "boolean switch)" << std::endl;
+        usage();
+        return 2;
+    }
+    if (voxel_leaf && n_gpus > 0 && cameras) { std::cerr << "-G shards cameras of this node (-i), not edge servers (-c)" << std::endl; return 2; }
     if (drop_invalid && !source) { std::cerr << "-Z applies to cameras on this node (-i); edge servers drop with their own -c" << std::endl; return 2; }
 
     // ---- frame source / edge connections -------------------------------------------------------
@@ -146,7 +158,7 @@ int main(int argc, char** argv)
         if (n_streams % n_gpus) { std::cerr << "-N " << n_streams << " streams do not divide over -G " << n_gpus << " GPUs" << std::endl; return 2; }
         std::vector<int> ids(n_gpus);
         for (int g = 0; g < n_gpus; g++) ids[g] = device + g;
-        rc = pcs_node_create(&node, n_gpus, ids.data(), n_streams / n_gpus, cfgs.data(), 0u, downsample);
+        rc = pcs_node_create(&node, n_gpus, ids.data(), n_streams / n_gpus, cfgs.data(), cfg.flags, downsample);
         if (rc != PCS_OK) { std::cerr << "pcs_node_create: " << pcs_strerror(rc) << ": " << pcs_node_last_error(nullptr) << std::endl; return 1; }
         std::cout << "Sharding " << n_streams << " cameras over " << n_gpus << " GPU(s), RCCL gather to GPU " << device << std::endl;
     }
@@ -198,9 +210,9 @@ int main(int argc, char** argv)
             vox_cap_points = 0;
             for (auto& sc : cfgs) vox_cap_points += (size_t)sc.depth.width * sc.depth.height;
         }
-        if (pcs_device_malloc(ctx, &d_vox, vox_cap_points * PCS_POINT_BYTES + 64) != PCS_OK ||
-            pcs_device_malloc(ctx, &d_nvox, 64) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
-        if (source) {
+        if (!node && (pcs_device_malloc(ctx, &d_vox, vox_cap_points * PCS_POINT_BYTES + 64) != PCS_OK ||
+                      pcs_device_malloc(ctx, &d_nvox, 64) != PCS_OK)) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+        if (source && !node) {      // (with -G the node library stages the rasters on their owning GPUs itself)
             d_depth.resize(n_streams, nullptr); d_color.resize(n_streams, nullptr);
             for (int s = 0; s < n_streams; s++) {
                 const size_t db = (size_t)cfgs[s].depth.width * cfgs[s].depth.height * 2;
@@ -274,7 +286,17 @@ int main(int argc, char** argv)
                 dp[s] = pin_d[s]; cp[s] = pin_c[s];
             }
             if (!raw) stitch_start = clockTime::now();             // handing the frames over is the source's part, not the stitch
-            if (voxel_leaf) {
+            if (voxel_leaf && node) {
+                // BASELINE configs[4]: the cameras' voxel partials are pre-aggregated on their GPUs, exchanged once, reduced on GPU 0
+                pcs_node_voxel_stats vstats;
+                rc = pcs_node_process_voxel(node, dp.data(), cp.data(), voxel_leaf, voxel_route, stitched.data(), stitched.size(), 1,
+                                            &size_bytes, &vstats);
+                if (rc != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
+                if (timer)
+                    std::cout << "Voxel grid over " << n_gpus << " GPU(s): kernels " << vstats.kernels_ms << " ms, exchange " << vstats.exchange_ms
+                              << " ms (" << vstats.exchanged_bytes << " B), root " << vstats.root_voxel_ms << " ms, " << vstats.partials
+                              << (voxel_route == PCS_NODE_VOXEL_PARTIALS ? " partials -> " : " points -> ") << vstats.voxels << " voxels" << std::endl;
+            } else if (voxel_leaf) {
                 for (int s = 0; s < n_streams; s++) {
                     if (pcs_memcpy_h2d(ctx, d_depth[s], depth[s].data(), depth[s].size() * 2) != PCS_OK ||
                         pcs_memcpy_h2d(ctx, d_color[s], color[s].data(), color[s].size()) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }

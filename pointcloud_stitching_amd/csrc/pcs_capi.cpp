@@ -83,6 +83,7 @@ struct pcs_ctx {
     float*                          s_vertices = nullptr; size_t s_vertices_cap = 0;
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
     void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
+    unsigned int*                   d_vox_ctl = nullptr;       // 64 words: control block of pcs_process_frames_voxel_partials_device
     int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
     int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
     uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
@@ -579,6 +580,18 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         int rc = validate_stream(cfg->streams[s], s);
         if (rc) return rc;
     }
+    {   // The wire header and the counts are int32 (src/pcs-camera-optimized.cpp:697, 718): bound the stitched payload, in
+        // 64 bits, before a device is touched — the per-stream bases below are 32-bit sums of up to 64 streams.
+        uint64_t all = 0, tiles = 0;
+        for (int s = 0; s < cfg->n_streams; s++) {
+            const uint64_t np = (uint64_t)cfg->streams[s].depth.width * (uint64_t)cfg->streams[s].depth.height;
+            all += (np + (uint64_t)cfg->downsample - 1) / (uint64_t)cfg->downsample;
+            tiles += (np + kTilePoints - 1) / kTilePoints;
+        }
+        if (all * PCS_POINT_BYTES > 0x7FFFFFFFull || tiles > 0x7FFFFFFFull)
+            return fail(nullptr, PCS_ERR_INVALID_ARG, "stitched payload of %llu points exceeds the int32 byte-count header "
+                        "(214 748 364 points)", (unsigned long long)all);
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -653,16 +666,6 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
     }
     c->max_payload_points = out_base;
     c->total_tiles = tile_base;
-    {   // the wire header and the counts are int32 (src/pcs-camera-optimized.cpp:697, 718): bound the stitched payload
-        uint64_t all = 0;
-        for (int s = 0; s < c->n_streams; s++) all += (c->h_params[s].n_points + (uint64_t)c->downsample - 1) / c->downsample;
-        if (all * PCS_POINT_BYTES > 0x7FFFFFFFull) {
-            const int rc = fail(nullptr, PCS_ERR_UNSUPPORTED, "stitched payload of %llu points exceeds the int32 byte-count header "
-                                "(214 748 364 points)", (unsigned long long)all);
-            pcs_destroy(c);
-            return rc;
-        }
-    }
     CREATE_CHK(hipMalloc((void**)&c->d_tile_counts, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_tile_prefix, sizeof(uint32_t) * std::max<uint32_t>(tile_base, 1)));
     CREATE_CHK(hipMalloc((void**)&c->d_stream_base, sizeof(uint32_t) * (c->n_streams + 1)));
@@ -757,7 +760,7 @@ void pcs_destroy(pcs_ctx* c)
     }
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->d_batch_scratch, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->d_batch_scratch, c->d_vox_ctl, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1466,6 +1469,88 @@ try {
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_device: host allocation failed (%s)", ex.what());
+}
+
+// ---- voxel partials (exchange format of the multi-GPU voxel grid) ------------------------------------
+int pcs_process_frames_voxel_partials_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                             int leaf_mm, uint64_t* d_keys, pcs_voxel_partial* d_partials, size_t capacity,
+                                             int32_t* d_n_partials)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!d_depth || !d_color || !d_keys || !d_partials || !d_n_partials) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
+    if (((uintptr_t)d_keys & 7u) || ((uintptr_t)d_partials & 31u))
+        return fail(c, PCS_ERR_INVALID_ARG, "d_keys must be 8-byte and d_partials 32-byte aligned");
+    const int S = c->n_streams;
+    for (int s = 0; s < S; s++) {
+        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
+    }
+    const size_t cap = c->max_payload_points;
+    if (capacity < cap)
+        return fail(c, PCS_ERR_CAPACITY, "partial arrays hold %zu entries; the worst case (every kept point its own partial) needs %zu",
+                    capacity, cap);
+    DeviceGuard guard(c->device);
+    if (!c->d_vox_ctl) HIPCHK(c, hipMalloc((void**)&c->d_vox_ctl, 64 * sizeof(unsigned int)));
+    static_assert(sizeof(pcs_voxel_partial) == 32, "pcs_voxel_partial is the kernels' 32-byte VoxelPartial");
+    VoxelStage vs{};
+    HIPCHK(c, voxel_partials_stage(leaf_mm, reinterpret_cast<unsigned long long*>(d_keys), d_partials, c->d_vox_ctl, &vs, c->stream));
+    static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
+    bool all_patch = true;
+    for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
+    const bool fused = fused_env >= 0 ? fused_env != 0 : (all_patch || leaf_mm >= 36);      // as pcs_process_frames_voxel_device
+    if (c->downsample != 1 || !fused) {
+        // the stride is defined on the ORDER of the kept points: build this GPU's stitched cloud, pre-aggregate that
+        int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
+        if (rc) return rc;
+        rc = run_fused_device(c, d_depth, d_color, c->s_payload, cap * PCS_POINT_SHORTS, c->d_counts, true);
+        if (rc) return rc;
+        if (cap) HIPCHK(c, launch_payload_voxel_partials(c->s_payload, (uint32_t)cap, c->d_counts + S, vs, c->stream));
+    } else {
+        for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
+            const int nl = std::min(kLaunchStreams, S - s0);
+            FramePtrs fp{};
+            uint32_t mp = 0, mw = 0, mh = 0;
+            bool fast = true, ident = true, patch_ok = true;
+            for (int k = 0; k < nl; k++) {
+                const StreamParams& q = c->h_params[s0 + k];
+                fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
+                mp = std::max(mp, q.n_points);
+                mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
+                patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
+                fast &= q.cert_fast != 0; ident &= q.ident_r != 0;
+            }
+            const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
+            HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->flags, sel, fp, vs, c->stream));
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(d_n_partials, c->d_vox_ctl, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_partials_device: host allocation failed (%s)", ex.what());
+}
+
+int pcs_voxel_grid_from_partials_device(pcs_ctx* c, const uint64_t* d_keys, const pcs_voxel_partial* d_partials, int n_partials,
+                                        const int32_t* d_n_partials, int leaf_mm, int16_t* d_out, size_t out_shorts,
+                                        int32_t* d_out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_partials < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_partials %d < 0", n_partials);
+    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
+    if (n_partials > 0 && (!d_keys || !d_partials || !d_out)) return fail(c, PCS_ERR_INVALID_ARG, "NULL device pointer");
+    if (((uintptr_t)d_keys & 7u) || ((uintptr_t)d_partials & 31u))
+        return fail(c, PCS_ERR_INVALID_ARG, "d_keys must be 8-byte and d_partials 32-byte aligned");
+    if (out_shorts < (size_t)n_partials * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every partial its own voxel) needs %zu",
+                    out_shorts, (size_t)n_partials * PCS_POINT_SHORTS);
+    DeviceGuard guard(c->device);
+    const size_t need = voxel_workspace_bytes((uint32_t)n_partials);
+    if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
+    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    if (rc) return rc;
+    HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,
+                                         d_n_partials, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out, d_out_points, c->stream));
+    return PCS_OK;
 }
 
 int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,

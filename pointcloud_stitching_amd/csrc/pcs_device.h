@@ -170,7 +170,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
 // the counters, launch_fused_voxel_partials (pcs_kernels.hip) appends the partials, voxel_finish sorts and reduces.
 struct VoxelStage {
     unsigned long long* keys;
-    unsigned int*       idx;
+    unsigned int*       idx;           // nullptr with idx_bits == 0: raw keys only (exchange format)
     void*               part;          // VoxelPartial[capacity]
     unsigned int*       n_runs;        // partials appended so far
     uint32_t            leaf, bias_leaf, magic, bits, idx_bits;
@@ -179,6 +179,14 @@ struct VoxelStage {
 hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
 hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
                         int32_t* d_out_points, hipStream_t st);
+// Partials as an exchange format (multi-GPU config 5): a stage that appends (raw voxel key, sums) to caller arrays
+// (d_ctl: 64 words, [0] = partials appended), and the sort + segmented mean over caller-held partials from any number of
+// such stages (same leaf).
+hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_ctl, VoxelStage* stage,
+                                hipStream_t st);
+hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const void* d_partials, uint32_t n_partials,
+                                      const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
+                                      int32_t* d_out_points, hipStream_t st);
 // the same table fed from a 16-byte aligned payload (pcs_kernels.hip; the unaligned forms stay in pcs_voxel.hip)
 hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points,
                                          const VoxelStage& vs, hipStream_t st);

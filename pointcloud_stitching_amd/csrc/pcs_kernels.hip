@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
             kprev = key;
             if ((failed >> k) & 1u) {
                 if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
-                else { vs.keys[pos] = key; vs.idx[pos] = pos; }
+                else { vs.keys[pos] = key; if (vs.idx) vs.idx[pos] = pos; }
                 part[pos] = VoxelPartial{sx, sy, sz, r, g, b, cnt, 0u};
                 key_or |= key; key_orn |= ~key;
                 pos++;
@@ -1381,7 +1381,7 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
         const int j = threadIdx.x * (kSlots / kVoxThreads) + q;
         if (skey[j] != kEmptyKey) {
             if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
-            else { vs.keys[pos] = skey[j]; vs.idx[pos] = pos; }
+            else { vs.keys[pos] = skey[j]; if (vs.idx) vs.idx[pos] = pos; }
             const unsigned long long xy = sxy[j], zn = szn[j], rg = srg[j];
             const unsigned int cnt = (unsigned int)(zn >> 32);
             const int bias = (int)(cnt << 15);                   // count x 32768 (count <= 32 768)

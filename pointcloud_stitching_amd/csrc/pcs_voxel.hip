@@ -746,6 +746,24 @@ void pcs_voxel_fixup_kernel(const unsigned int* __restrict__ m_ptr, const BlockP
     }
 }
 
+// Partials that arrive from outside the pre-aggregation of this call (other GPUs' pre-aggregations, gathered to the root:
+// BASELINE configs[4]) enter the sort here: keys_in holds RAW voxel keys; the sort wants (key << idx_bits) | index, or key
+// and index side by side. Also publishes the element count for the device-driven kernels that follow.
+__global__ __launch_bounds__(256)
+void pcs_voxel_import_kernel(const unsigned long long* __restrict__ keys_in, unsigned int m_host, const int32_t* __restrict__ m_dev,
+                             unsigned int capacity, unsigned int idx_bits, unsigned long long* __restrict__ keys_a,
+                             unsigned int* __restrict__ idx_a, unsigned int* __restrict__ ctl)
+{
+    unsigned int m = m_dev ? (unsigned int)max(*m_dev, 0) : m_host;
+    m = min(m, capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = m;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < m; i += gridDim.x * 256u) {
+        const unsigned long long k = keys_in[i];
+        if (idx_bits) keys_a[i] = (k << idx_bits) | i;
+        else { keys_a[i] = k; idx_a[i] = i; }
+    }
+}
+
 struct Workspace {
     unsigned long long *keys_a, *keys_b;
     unsigned int *idx_a, *idx_b;
@@ -792,6 +810,34 @@ struct Plan {
     bool track_bits;      // have the pre-aggregation record which key bits vary, so that the sort can skip passes
 };
 
+// floor(v / leaf) by multiply-shift for one leaf (verified over every int16 coordinate) + the bits one axis takes.
+hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
+{
+    if (leaf_mm < 1 || leaf_mm > 32767) return hipErrorInvalidValue;
+    bits = axis_bits(leaf_mm);
+    const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
+    dv = VoxelDiv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
+    // floor(u / leaf) == umulhi(u, magic) for every biased coordinate u = v + bias*leaf, v in [-32768, 32767]:
+    // verified here over all 65 536 of them (once per leaf per host thread). leaf 1 has no 32-bit magic: magic = 0 makes
+    // the kernels pass u through. A failed check (impossible by the bound in pcs_voxel_agg.h) refuses the call.
+    thread_local int cached_leaf = 0;
+    thread_local unsigned int cached_magic = 0;
+    thread_local bool cached_ok = false;
+    if (cached_leaf != leaf_mm) {
+        const unsigned long long magic = leaf_mm == 1 ? 0ull : ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
+        bool ok = magic < (1ull << 32);
+        const unsigned int lo = dv.bias_leaf - 32768u, hi = dv.bias_leaf + 32767u;
+        for (unsigned int u = lo; ok && u <= hi; u++)
+            ok = (unsigned int)(((unsigned long long)u * magic) >> 32) + (magic ? 0u : u) == u / (unsigned)leaf_mm;
+        cached_leaf = leaf_mm;
+        cached_magic = (unsigned int)magic;
+        cached_ok = ok;
+    }
+    if (!cached_ok) return hipErrorInvalidValue;
+    dv.magic = cached_magic;
+    return hipSuccess;
+}
+
 // Carves the workspace and derives the key layout for a cloud of at most n_points points.
 hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes, Plan& pl)
 {
@@ -799,27 +845,9 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     uint8_t* base = static_cast<uint8_t*>(d_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
     pl.w = carve(base, n_points);
-    pl.bits = axis_bits(leaf_mm);
-    const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
-    pl.dv = VoxelDiv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
-    {   // floor(u / leaf) == umulhi(u, magic) for every biased coordinate u = v + bias*leaf, v in [-32768, 32767]:
-        // verified here over all 65 536 of them (once per leaf per host thread). leaf 1 has no 32-bit magic: magic = 0 makes
-        // the kernels pass u through. A failed check (impossible by the bound in pcs_voxel_agg.h) refuses the call.
-        thread_local int cached_leaf = 0;
-        thread_local unsigned int cached_magic = 0;
-        thread_local bool cached_ok = false;
-        if (cached_leaf != leaf_mm) {
-            const unsigned long long magic = leaf_mm == 1 ? 0ull : ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
-            bool ok = magic < (1ull << 32);
-            const unsigned int lo = pl.dv.bias_leaf - 32768u, hi = pl.dv.bias_leaf + 32767u;
-            for (unsigned int u = lo; ok && u <= hi; u++)
-                ok = (unsigned int)(((unsigned long long)u * magic) >> 32) + (magic ? 0u : u) == u / (unsigned)leaf_mm;
-            cached_leaf = leaf_mm;
-            cached_magic = (unsigned int)magic;
-            cached_ok = ok;
-        }
-        if (!cached_ok) return hipErrorInvalidValue;
-        pl.dv.magic = cached_magic;
+    {
+        const hipError_t e = div_for(leaf_mm, pl.dv, pl.bits);
+        if (e != hipSuccess) return e;
     }
     // one 64-bit word per element when the packed key and the partial's index fit together
     pl.idx_bits = 1;
@@ -939,6 +967,46 @@ hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_
     hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, pl);
     if (e != hipSuccess) return e;
     return sort_and_reduce(pl, capacity_points, d_out, d_out_points, st);
+}
+
+// ---- partials as an exchange format (multi-GPU config 5) -----------------------------------------------------------------
+// A stage whose partials land in CALLER arrays as (raw key, sums): nothing of the sort's layout (index bits) leaks into them,
+// so partials of several pre-aggregations — other GPUs' — can be concatenated and handed to launch_voxel_from_partials.
+hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_ctl, VoxelStage* stage,
+                                hipStream_t st)
+{
+    VoxelDiv dv;
+    unsigned int bits;
+    hipError_t e = div_for(leaf_mm, dv, bits);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_ctl, 0, 64 * sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+    stage->keys = d_keys; stage->idx = nullptr; stage->part = d_partials; stage->n_runs = d_ctl;
+    stage->leaf = dv.leaf; stage->bias_leaf = dv.bias_leaf; stage->magic = dv.magic;
+    stage->bits = bits; stage->idx_bits = 0u; stage->track_bits = 0u;
+    return hipSuccess;
+}
+
+// Sort + segmented mean over n_partials (or *d_n_partials, at most n_partials) caller-held partials with raw keys.
+hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const void* d_partials, uint32_t n_partials,
+                                      const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
+                                      int32_t* d_out_points, hipStream_t st)
+{
+    if (n_partials == 0) {
+        if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
+        return hipSuccess;
+    }
+    Plan pl;
+    hipError_t e = plan_for(n_partials, leaf_mm, d_ws, ws_bytes, pl);
+    if (e != hipSuccess) return e;
+    pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
+    pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place
+    e = hipMemsetAsync(pl.w.ctl, 0, 64 * sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+    const unsigned int grid = std::min<unsigned int>((n_partials + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(pcs_voxel_import_kernel, dim3(grid), dim3(256), 0, st, d_keys, n_partials, d_n_partials, n_partials,
+                       pl.idx_bits, pl.w.keys_a, pl.w.idx_a, pl.w.ctl);
+    return sort_and_reduce(pl, n_partials, d_out, d_out_points, st);
 }
 
 }  // namespace pcs

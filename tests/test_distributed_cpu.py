@@ -72,3 +72,55 @@ def test_two_rank_gather_reproduces_camera_order_concat(oracle, flags):
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _partials_worker(rank, world, port, q):
+    """The config-5 exchange step on its own: every rank holds m_r (key, partial) pairs; ONE grouped exchange lands
+    keys behind keys and partials behind partials on the root, in rank order; the counts come from a tensor (as they do on
+    the device: a view of the word the pre-aggregation kernel wrote), not from a host int."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointcloud_stitching_amd.stitch import RankStitcher, KEY_BYTES, PARTIAL_BYTES
+        st = RankStitcher()
+        m = [1234, 0, 777][rank]
+        rng = np.random.default_rng(100 + rank)
+        cap = 2000
+        keys = torch.zeros((cap * world if rank == 0 else cap) * KEY_BYTES, dtype=torch.uint8)
+        parts = torch.zeros((cap * world if rank == 0 else cap) * PARTIAL_BYTES, dtype=torch.uint8)
+        mine_k = rng.integers(0, 256, m * KEY_BYTES, dtype=np.uint8)
+        mine_p = rng.integers(0, 256, m * PARTIAL_BYTES, dtype=np.uint8)
+        keys[:mine_k.size] = torch.from_numpy(mine_k); parts[:mine_p.size] = torch.from_numpy(mine_p)
+        counts = st.gather_counts(torch.tensor([m, 99], dtype=torch.int32)[0], "cpu")
+        st.gather_bytes([keys, parts], [[c * KEY_BYTES for c in counts], [c * PARTIAL_BYTES for c in counts]],
+                        [keys, parts] if rank == 0 else None)
+        ok = counts == [1234, 0, 777]
+        if rank == 0:
+            want_k = np.concatenate([np.random.default_rng(100 + r).integers(0, 256, c * KEY_BYTES, dtype=np.uint8) for r, c in enumerate(counts)])
+            # (each rank drew its keys first, then its partials, from its own generator: replay that order)
+            want_k, want_p = [], []
+            for r, c in enumerate(counts):
+                g = np.random.default_rng(100 + r)
+                want_k.append(g.integers(0, 256, c * KEY_BYTES, dtype=np.uint8))
+                want_p.append(g.integers(0, 256, c * PARTIAL_BYTES, dtype=np.uint8))
+            want_k, want_p = np.concatenate(want_k), np.concatenate(want_p)
+            ok = ok and bool((keys.numpy()[:want_k.size] == want_k).all()) and bool((parts.numpy()[:want_p.size] == want_p).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_rank_partials_exchange_lands_in_rank_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partials_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
