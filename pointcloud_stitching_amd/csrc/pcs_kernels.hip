@@ -22,7 +22,13 @@
 // Float->int follows x86 cvttss2si including its "integer indefinite" result for NaN / out of range,
 // which v_cvt_i32_f32 (saturating) does not give by itself.
 
+#include <cstddef>
+
 #include "pcs_device.h"
+
+#ifndef EMIT_WAVES
+#define EMIT_WAVES 6      // 7 fits 72 VGPRs only with scratch spills in some instantiations and measured no faster
+#endif
 
 namespace pcs {
 
@@ -125,6 +131,7 @@ using LazyCvt = FastCvt<true>;
 // to IeeeMath on the inputs it is launched for (see "certification" in pcs_capi.cpp and DESIGN.md);
 // tools/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
 struct IeeeMath {
+    static constexpr bool kIdentR = false;
     // 0 exact conversions, 1 fast with overflow tracking, 2 fast, overflow certified impossible.
     // The tracked fast form is exact for every input (its redo path IS the exact form), so even the
     // fallback policy uses it; only the quotients stay on the IEEE expansion here.
@@ -167,6 +174,7 @@ struct IeeeMath {
 //    R*p + t is p + t: the dropped products are exact (1*x) or signed zeros that cannot change a sum.
 template <bool IDENT_R, bool NO_OVERFLOW = false>
 struct CertMath {
+    static constexpr bool kIdentR = IDENT_R;
     static constexpr int kCvtMode = NO_OVERFLOW ? 2 : 1;
     static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
                                                float& P0, float& P1, float& P2)
@@ -444,26 +452,42 @@ struct DepthSource {
     // pixel splits the lane's code into 16 basic blocks, which stops the scheduler from interleaving the
     // pixels and the compiler from packing pairs of them into v_pk_* instructions (measured: the emit
     // kernel ran 27 us with per-pixel tests vs 19 us for the dense kernel without them).
+    // The fast path in two steps, for kernels that want to do something between requesting a lane's inputs and using them
+    // (the single-pass compaction counts and publishes from the raw Z16 words first): fast() says whether it applies
+    // (uniform over the launch's stream), fetch() issues the loads, deproject() consumes them.
+    struct Raw { uint4 dv; f32x4 ma, mb; float my; };
+    __device__ __forceinline__ bool fast(const StreamParams& P) const { return (P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0; }
+    __device__ __forceinline__ Raw fetch(const StreamParams& P, uint32_t i0) const
+    {
+        // all 8 pixels on one raster row; one 16-byte depth load, two 16-byte LUT loads
+        // floor(i0 / W) by the host-verified multiply-shift (i0 < 2^31)
+        const uint32_t r = P.w_magic ? (__umulhi(i0, P.w_magic) >> P.w_shift) : i0 / (uint32_t)P.W;
+        const uint32_t c0 = i0 - r * (uint32_t)P.W;
+        Raw q;
+        q.dv = *reinterpret_cast<const uint4*>(depth + i0);
+        const gptr<float> lut_x = as_global(P.mx);
+        q.ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
+        q.mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
+        q.my = as_global(P.my)[r];
+        return q;
+    }
+    template <bool DD, bool CD>
+    __device__ __forceinline__ void deproject(const StreamParams& P, const Raw& q, PointIn (&p)[8]) const
+    {
+        const uint32_t dw[4] = {q.dv.x, q.dv.y, q.dv.z, q.dv.w};
+        const float mxs[8] = {q.ma.x, q.ma.y, q.ma.z, q.ma.w, q.mb.x, q.mb.y, q.mb.z, q.mb.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+            p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], q.my);
+        }
+    }
+
     template <bool DD, bool CD>
     __device__ __forceinline__ void load8_impl(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8]) const
     {
-        if ((P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0) {
-            // all 8 pixels on one raster row; one 16-byte depth load, two 16-byte LUT loads
-            // floor(i0 / W) by the host-verified multiply-shift (i0 < 2^31)
-            const uint32_t r = P.w_magic ? (__umulhi(i0, P.w_magic) >> P.w_shift) : i0 / (uint32_t)P.W;
-            const uint32_t c0 = i0 - r * (uint32_t)P.W;
-            const uint4 dv = *reinterpret_cast<const uint4*>(depth + i0);
-            const gptr<float> lut_x = as_global(P.mx);
-            const f32x4 ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
-            const f32x4 mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
-            const float my = as_global(P.my)[r];
-            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
-            const float mxs[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
-                p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], my);
-            }
+        if (fast(P)) {
+            deproject<DD, CD>(P, fetch(P, i0), p);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -884,14 +908,31 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
 // exit, then the raster pointers and the width, then the LUT pointers — four scalar round trips before the first
 // Z16 load of a workgroup can be issued, paid in full by the first wave of workgroups of every launch (1.8 rounds of
 // them make up an 8 x 720p launch). The empty asm only says "these are needed HERE".
+// LEAN: leave out the two quads that hold nothing but distortion coefficients (dk[1..4], ck[0..3]; a stream that has any
+// fetches them when it gets there) and, for IDENT_R policies, the two quads of the depth->colour rotation that p + t never
+// reads. What this buys is SGPRs at the point where the most of them are live: the hardware admits a 256-lane workgroup per
+// CU only while its waves' SGPR allocation allows it — 7 per CU up to 96 SGPRs, 6 from 97 (MI355X_MICROARCH.md, residency) —
+// and the emit kernel's extra arguments had pushed it to 103.
+template <bool LEAN = false, bool IDENT_R = false>
 __device__ __forceinline__ void request_constants(const StreamParams& P, const void* a, const void* b, const void* c = nullptr)
 {
     static_assert(sizeof(StreamParams) == 19 * 16, "request_constants covers the struct in 19 quads");
+    static_assert(offsetof(StreamParams, dk) == 39 * 4 && offsetof(StreamParams, ck) == 44 * 4 && offsetof(StreamParams, R) == 12 * 4,
+                  "quads 10, 11 = dk[1..4], ck[0..3]; quads 3, 4 = R[0..7]");
     typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
     const u32x4s* q = reinterpret_cast<const u32x4s*>(&P);
-    asm volatile("" :: "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]), "s"(q[9]),
-                       "s"(q[10]), "s"(q[11]), "s"(q[12]), "s"(q[13]), "s"(q[14]), "s"(q[15]), "s"(q[16]), "s"(q[17]), "s"(q[18]),
-                       "s"(a), "s"(b), "s"(c));
+    if (LEAN && IDENT_R)
+        asm volatile("" :: "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]), "s"(q[9]),
+                           "s"(q[12]), "s"(q[13]), "s"(q[14]), "s"(q[15]), "s"(q[16]), "s"(q[17]), "s"(q[18]),
+                           "s"(a), "s"(b), "s"(c));
+    else if (LEAN)
+        asm volatile("" :: "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]), "s"(q[9]),
+                           "s"(q[12]), "s"(q[13]), "s"(q[14]), "s"(q[15]), "s"(q[16]), "s"(q[17]), "s"(q[18]),
+                           "s"(a), "s"(b), "s"(c));
+    else
+        asm volatile("" :: "s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]), "s"(q[9]),
+                           "s"(q[10]), "s"(q[11]), "s"(q[12]), "s"(q[13]), "s"(q[14]), "s"(q[15]), "s"(q[16]), "s"(q[17]), "s"(q[18]),
+                           "s"(a), "s"(b), "s"(c));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1015,7 +1056,8 @@ void pcs_fused_count_kernel(const StreamParams* __restrict__ params, int stream0
 {
     __shared__ uint32_t wsum[kCountTiles][4];
     const int s = blockIdx.y;
-    request_constants(params[stream0 + s], fp.depth[s], tile_counts);
+    // (no request_constants here: the usual route needs four words of the stream's constants, and 98 SGPRs would cap the
+    // kernel at 6 workgroups per CU where 8 fit)
     count_tiles<DDIST, CDIST>(params[stream0 + s], fp.depth[s], flags, tile_counts, wsum);
 }
 
@@ -1027,7 +1069,6 @@ void pcs_fused_count_batch_kernel(const StreamParams* __restrict__ params, Batch
 {
     __shared__ uint32_t wsum[kCountTiles][4];
     const int s = blockIdx.y;
-    request_constants(params[s], bp.depth[blockIdx.z * gridDim.y + s], tile_counts);
     count_tiles<DDIST, CDIST>(params[s], bp.depth[blockIdx.z * gridDim.y + s], flags,
                               tile_counts + (size_t)blockIdx.z * total_tiles, wsum);
 }
@@ -1036,7 +1077,7 @@ void pcs_fused_count_batch_kernel(const StreamParams* __restrict__ params, Batch
 // per lane riding on the tile's existing barrier — was built and measured: 32.4 vs 32.5 us on 8 x 720p and 127 vs 107 us
 // on 16 x 1080p. Whatever the scan launch costs, extra memory instructions in the emit tile cost at least as much.)
 template <bool PRED, bool DS1, class Mth>
-__global__ __launch_bounds__(kBlockThreads, 6)      // 6 waves/SIMD (<= 80 VGPRs): measured faster than the unconstrained 5
+__global__ __launch_bounds__(kBlockThreads, EMIT_WAVES)
 void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                            uint32_t ds, const uint32_t* __restrict__ tile_prefix,
                            const uint32_t* __restrict__ stream_kept, uint8_t* __restrict__ payload_bytes,
@@ -1053,7 +1094,7 @@ void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0,
         *total_out = (int32_t)tot;
     }
     const StreamParams& P = params[stream0 + s];
-    request_constants(P, fp.depth[s], fp.color[s], payload_bytes);
+    request_constants<true, Mth::kIdentR>(P, fp.depth[s], fp.color[s], payload_bytes);
     const uint32_t n = P.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;

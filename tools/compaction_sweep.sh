@@ -7,7 +7,7 @@ B="python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-host-api"
 for geo in "8 1280 720 300" "16 1920 1080 100"; do
   set -- $geo; S=$1; W=$2; H=$3; K=$4
   for mode in drop_invalid cutoff; do
-    for path in three single; do
+    for path in ${PATHS:-three single}; do
       f=$OUT/${S}x${H}_${mode}_$path.json
       PCS_COMPACT_PATH=$path $B --mode $mode --streams $S --width $W --height $H --steps $K > $f 2>>$OUT/err.log
       python - "$f" "${S}x${W}x${H} $mode $path" <<'PY'
