@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""GPU box: time rasters -> voxel grid in one call (pcs_process_frames_voxel_device, 16 x 1920x1080, DROP_INVALID, ring of 4
+input sets) for a list of leaves under the current environment, and check the 50 / 200 mm clouds against the oracle digests.
+   python tools/voxel_probe.py [leaves=50,200] [reps=40]"""
+import hashlib
+import json
+import os
+import sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pointcloud_stitching_amd import synthetic as Syn
+from pointcloud_stitching_amd.api import PcsContext
+
+leaves = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "50,200").split(",")]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+S, W, H = 16, 1920, 1080
+gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config5_digests.json")))["voxel"]
+dev = torch.device("cuda", 0)
+cfgs = [Syn.synth_stream_config(W, H, s) for s in range(S)]
+ctx = PcsContext(cfgs, flags=4)
+stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream); ctx.set_stream(stream.cuda_stream)
+n = W * H
+dep0 = [torch.from_numpy(Syn.synth_depth(W, H, s).reshape(-1).view(np.uint8)).to(dev) for s in range(S)]
+col0 = [torch.from_numpy(Syn.synth_color(W, H, s)).to(dev) for s in range(S)]
+sets = [(dep0, col0)] + [([d.clone() for d in dep0], [c.clone() for c in col0]) for _ in range(3)]
+vox = torch.empty(S * n * 5, dtype=torch.int16, device=dev)
+nv = torch.zeros(2, dtype=torch.int32, device=dev)
+k = [0]
+def call(leaf):
+    d, c = sets[k[0] % 4]; k[0] += 1
+    ctx.process_frames_voxel_device([t.data_ptr() for t in d], [t.data_ptr() for t in c], leaf, vox.data_ptr(), vox.numel(), nv.data_ptr())
+tag = " ".join(f"{k_}={v}" for k_, v in sorted(os.environ.items()) if k_.startswith("PCS_VOXEL"))
+for leaf in leaves:
+    for _ in range(4):
+        call(leaf)
+    torch.cuda.synchronize()
+    ctx.timer_begin()
+    for _ in range(reps):
+        call(leaf)
+    ctx.timer_end()
+    ms = ctx.timer_elapsed_ms() / reps
+    m = int(nv[0].item())
+    ok = ""
+    if str(leaf) in gold:
+        dig = hashlib.sha256(vox[:m * 5].cpu().numpy().tobytes()).hexdigest()
+        ok = "digest OK" if (dig == gold[str(leaf)]["sha256"] and m == gold[str(leaf)]["voxels"]) else "DIGEST MISMATCH"
+    print(f"[{tag}] leaf {leaf:4d} mm: {ms:7.4f} ms per frame-set, {m} voxels {ok}", flush=True)
+ctx.close()
