@@ -499,8 +499,7 @@ struct DepthSource {
         }
     }
 
-    __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8],
-                                          void* /*lds*/) const
+    __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8]) const
     {
         if (i0 >= n) {
 #pragma unroll
@@ -510,55 +509,39 @@ struct DepthSource {
         if ((DDIST || CDIST) && (P.ddist | P.cdist | P.tex_half)) load8_impl<DDIST, CDIST>(P, i0, n, p);
         else load8_impl<false, false>(P, i0, n, p);
     }
-    static constexpr bool kUsesLdsInput = false;
 };
 
-// rs2::points arrays (vertices + texcoords) -> points (the a2 twin's input).
-// The AoS arrays are pulled in with lane-contiguous 16-byte loads and transposed through LDS; a lane
-// then picks up its 8 points (96 B + 64 B) from LDS.
+// rs2::points arrays (vertices + texcoords) -> points (the a2 twin's input), read straight into registers: a lane's 8 points
+// are 96 contiguous bytes of vertices and 64 of texcoords (six + four 16-byte loads, all in flight together). A wavefront's
+// k-th load touches 64 separate 16-byte pieces, but its six vertex loads cover the same 48 cache lines back to back, so the
+// L1 does the merging. (Rounds 1-2 transposed the arrays through 40 KB of LDS with lane-contiguous loads — textbook
+// coalescing, but the LDS round trip, its barrier and the fat workgroups cost far more than the L1 does: one 1280x720 cloud
+// per launch 11.0 -> 7.1 us = 34 -> 53 % of HBM peak, eight clouds in one launch 61 -> 71 %.)
 struct VertexSource {
     using Math = IeeeMath;
     const float* __restrict__ vertices;
     const float* __restrict__ texcoords;
 
-    static constexpr bool kUsesLdsInput = true;
-    static constexpr uint32_t kLdsFloats = kTilePoints * 5;   // 40 KiB
-
-    __device__ __forceinline__ void stage_tile(uint32_t tile0, uint32_t n, float* lds) const
+    __device__ __forceinline__ void load8(const StreamParams&, uint32_t i0, uint32_t n, PointIn (&p)[8]) const
     {
-        const uint32_t pts = min(kTilePoints, n - tile0);
-        float* lv = lds;                      // [pts*3]
-        float* lt = lds + kTilePoints * 3;    // [pts*2]
-        const float* gv = vertices + (size_t)tile0 * 3;
-        const float* gt = texcoords + (size_t)tile0 * 2;
-        const uint32_t nv = pts * 3, nt = pts * 2;
-        if ((((uintptr_t)gv | (uintptr_t)gt) & 15) == 0) {
-            const uint32_t nv4 = nv >> 2, nt4 = nt >> 2;
-            for (uint32_t j = threadIdx.x; j < nv4; j += kBlockThreads)
-                reinterpret_cast<float4*>(lv)[j] = reinterpret_cast<const float4*>(gv)[j];
-            for (uint32_t j = threadIdx.x; j < nt4; j += kBlockThreads)
-                reinterpret_cast<float4*>(lt)[j] = reinterpret_cast<const float4*>(gt)[j];
-            for (uint32_t j = (nv4 << 2) + threadIdx.x; j < nv; j += kBlockThreads) lv[j] = gv[j];
-            for (uint32_t j = (nt4 << 2) + threadIdx.x; j < nt; j += kBlockThreads) lt[j] = gt[j];
-        } else {
-            for (uint32_t j = threadIdx.x; j < nv; j += kBlockThreads) lv[j] = gv[j];
-            for (uint32_t j = threadIdx.x; j < nt; j += kBlockThreads) lt[j] = gt[j];
-        }
-    }
-
-    __device__ __forceinline__ void load8(const StreamParams&, uint32_t i0, uint32_t n, PointIn (&p)[8],
-                                          void* lds) const
-    {
-        const float* lv = reinterpret_cast<const float*>(lds);
-        const float* lt = lv + kTilePoints * 3;
-        const uint32_t l0 = (threadIdx.x * kPointsPerLane);
+        if (i0 + 8u <= n && ((((uintptr_t)vertices) | ((uintptr_t)texcoords)) & 15u) == 0u) {
+            const float4* gv = reinterpret_cast<const float4*>(vertices + (size_t)i0 * 3);
+            const float4* gt = reinterpret_cast<const float4*>(texcoords + (size_t)i0 * 2);
+            float4 v[6], t[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (i0 + k < n) {
-                const uint32_t j = l0 + k;
-                p[k] = PointIn{lv[3 * j], lv[3 * j + 1], lv[3 * j + 2], lt[2 * j], lt[2 * j + 1]};
-            } else {
-                p[k] = PointIn{0, 0, 0, 0, 0};
+            for (int k = 0; k < 6; k++) v[k] = gv[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = gt[k];
+            const float* fv = reinterpret_cast<const float*>(v);
+            const float* ft = reinterpret_cast<const float*>(t);
+#pragma unroll
+            for (int k = 0; k < 8; k++) p[k] = PointIn{fv[3 * k], fv[3 * k + 1], fv[3 * k + 2], ft[2 * k], ft[2 * k + 1]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const size_t i = (size_t)i0 + k;
+                if (i < n) p[k] = PointIn{vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2], texcoords[2 * i], texcoords[2 * i + 1]};
+                else p[k] = PointIn{0, 0, 0, 0, 0};
             }
         }
     }
@@ -600,12 +583,11 @@ __device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, 
 template <class Src>
 __device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src, const uint8_t* __restrict__ color,
                                            uint32_t tile0, uint32_t n, uint8_t* __restrict__ out_bytes,
-                                           uint4* stage, void* lds_in)
+                                           uint4* stage)
 {
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
     PointIn p[8];
-    src.load8(P, i0, n, p, lds_in);
-    if (Src::kUsesLdsInput) __syncthreads();     // staging aliases the input region
+    src.load8(P, i0, n, p);
 
     uint32_t w[20];
     auto fill = [&](auto& cv) {
@@ -653,12 +635,12 @@ template <class Src, bool PRED, bool DS1>
 __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& src, const uint8_t* __restrict__ color,
                                              uint32_t tile0, uint32_t n, uint32_t flags, uint32_t ds,
                                              uint32_t g0, uint32_t out_first, uint8_t* __restrict__ payload_bytes,
-                                             uint8_t* stage, uint32_t* wsum, void* lds_in)
+                                             uint8_t* stage, uint32_t* wsum)
 {
     if (DS1) ds = 1u;
     const uint32_t i0 = tile0 + threadIdx.x * kPointsPerLane;
     PointIn p[8];
-    src.load8(P, i0, n, p, lds_in);
+    src.load8(P, i0, n, p);
 
     uint32_t keep, ex = 0;
     if (PRED) {
@@ -705,7 +687,6 @@ __device__ __forceinline__ void generic_tile(const StreamParams& P, const Src& s
         const uint32_t pts = min(kTilePoints, n - tile0);
         lane_first = min(threadIdx.x * kPointsPerLane, pts);
         tile_kept = pts;
-        if (Src::kUsesLdsInput) __syncthreads();
     }
 
     // output range of the tile, in points: q = out_first + ceil(g/ds) for g in [g0, g0 + tile_kept)
@@ -819,7 +800,7 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
 
     DepthSource<true, true, Mth> src{fp.depth[s]};
     PointIn p[8];
-    src.load8(P, i0, n, p, nullptr);
+    src.load8(P, i0, n, p);
     const uint32_t keep = keep_mask8(p, i0, n, a.flags);
 
     uint32_t wave_total;
@@ -952,7 +933,7 @@ void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
     DepthSource<DDIST, CDIST, Mth> src{fp.depth[s]};
-    dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
+    dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage);
 }
 
 // K frame-sets of the same streams in one launch: blockIdx.z = frame-set, blockIdx.y = stream. Same tile code, same
@@ -970,7 +951,7 @@ void pcs_fused_dense_batch_kernel(const StreamParams* __restrict__ params, Batch
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
     DepthSource<DDIST, CDIST, Mth> src{bp.depth[e]};
-    dense_tile(P, src, bp.color[e], tile0, n, bp.payload[blockIdx.z] + (size_t)P.out_base * PCS_POINT_BYTES, stage, nullptr);
+    dense_tile(P, src, bp.color[e], tile0, n, bp.payload[blockIdx.z] + (size_t)P.out_base * PCS_POINT_BYTES, stage);
 }
 
 // Count pass: kept points per tile. (Folding the per-stream scan into this launch through a last-arriver
@@ -1034,7 +1015,7 @@ __device__ __forceinline__ void count_tiles(const StreamParams& P, const uint16_
         for (int q = 0; q < kCountTiles; q++) {
             const uint32_t i0 = (tile_first + q) * kTilePoints + threadIdx.x * kPointsPerLane;
             PointIn p[8];
-            src.load8(P, i0, n, p, nullptr);
+            src.load8(P, i0, n, p);
             c[q] = __popc(keep_mask8(p, i0, n, flags));
         }
     }
@@ -1106,7 +1087,7 @@ void pcs_fused_emit_kernel(const StreamParams* __restrict__ params, int stream0,
         for (int e = 0; e < stream0 + s; e++) out_first += DS1 ? stream_kept[e] : (stream_kept[e] + ds - 1) / ds;
     }
     generic_tile<DepthSource<true, true, Mth>, PRED, DS1>(P, src, fp.color[s], tile0, n, flags, ds, g0, out_first,
-                                                  payload_bytes, stage, wsum, nullptr);
+                                                  payload_bytes, stage, wsum);
 }
 
 // K frame-sets of ordered compaction (stride 1): blockIdx.z = frame-set. Prefixes at tile_prefix + z * total_tiles, the
@@ -1137,7 +1118,7 @@ void pcs_fused_emit_batch_kernel(const StreamParams* __restrict__ params, BatchP
     uint32_t out_first = 0;
     for (int e = 0; e < s; e++) out_first += kept[e];
     generic_tile<DepthSource<true, true, Mth>, true, true>(P, src, bp.color[z * S + s], tile0, n, flags, 1u, g0, out_first,
-                                                           bp.payload[z], stage, wsum, nullptr);
+                                                           bp.payload[z], stage, wsum);
 }
 
 // Exclusive scan of the tile counts, one workgroup of 1024 lanes PER STREAM (streams scan concurrently).
@@ -1499,7 +1480,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
         }
         PointIn p[8];
-        src.load8(P, i0, n, p, nullptr);
+        src.load8(P, i0, n, p);
         const uint32_t keep = keep_mask8(p, i0, n, flags);
 
         Record rec[8];
@@ -1570,17 +1551,15 @@ void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint
 // ---- a2 twin -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_pack_dense_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp,
-                           uint8_t* __restrict__ out_bytes)
+                                  uint8_t* __restrict__ out_bytes)
 {
-    __shared__ __attribute__((aligned(16))) float lds[VertexSource::kLdsFloats];   // input; output staging aliases it
+    __shared__ uint4 stage[kDenseStageBytes / 16];
     const StreamParams& P = params[stream];
     const uint32_t n = vp.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
     VertexSource src{vp.vertices, vp.texcoords};
-    src.stage_tile(tile0, n, lds);
-    __syncthreads();
-    dense_tile(P, src, vp.color, tile0, n, out_bytes, reinterpret_cast<uint4*>(lds), lds);
+    dense_tile(P, src, vp.color, tile0, n, out_bytes, stage);
 }
 
 __global__ __launch_bounds__(kBlockThreads)
@@ -1613,20 +1592,15 @@ __global__ __launch_bounds__(kBlockThreads)
 void pcs_pack_emit_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp, uint32_t flags,
                           const uint32_t* __restrict__ tile_prefix, uint8_t* __restrict__ out_bytes)
 {
-    __shared__ __attribute__((aligned(16))) float lds[VertexSource::kLdsFloats];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t wsum[4];
     const StreamParams& P = params[stream];
     const uint32_t n = vp.n_points;
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
     VertexSource src{vp.vertices, vp.texcoords};
-    src.stage_tile(tile0, n, lds);
-    __syncthreads();
     const uint32_t g0 = PRED ? tile_prefix[blockIdx.x] : tile0;
-    // staging must not alias the input here (lanes still read inputs while others stage) unless we
-    // barrier after load8 — generic_tile does (PRED path barriers in the scan; non-PRED explicitly).
-    generic_tile<VertexSource, PRED, true>(P, src, vp.color, tile0, n, flags, 1u, g0, 0u, out_bytes,
-                                     reinterpret_cast<uint8_t*>(lds), wsum, lds);
+    generic_tile<VertexSource, PRED, true>(P, src, vp.color, tile0, n, flags, 1u, g0, 0u, out_bytes, stage, wsum);
 }
 
 // Batched a2 twin (no predicate): blockIdx.y = cloud. One launch for all cameras of a frame-set instead of one
@@ -1635,7 +1609,7 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_pack_batch_kernel(const StreamParams* __restrict__ params, PackBatch pb)
 {
-    __shared__ __attribute__((aligned(16))) float lds[VertexSource::kLdsFloats];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t wsum[4];
     const int e = blockIdx.y;
     const VertexPtrs vp = pb.v[e];
@@ -1644,13 +1618,10 @@ void pcs_pack_batch_kernel(const StreamParams* __restrict__ params, PackBatch pb
     const uint32_t tile0 = blockIdx.x * kTilePoints;
     if (tile0 >= n) return;
     VertexSource src{vp.vertices, vp.texcoords};
-    src.stage_tile(tile0, n, lds);
-    __syncthreads();
     if (ALIGNED)
-        dense_tile(P, src, vp.color, tile0, n, pb.out[e], reinterpret_cast<uint4*>(lds), lds);
+        dense_tile(P, src, vp.color, tile0, n, pb.out[e], reinterpret_cast<uint4*>(stage));
     else
-        generic_tile<VertexSource, false, true>(P, src, vp.color, tile0, n, 0u, 1u, tile0, 0u, pb.out[e],
-                                                reinterpret_cast<uint8_t*>(lds), wsum, lds);
+        generic_tile<VertexSource, false, true>(P, src, vp.color, tile0, n, 0u, 1u, tile0, 0u, pb.out[e], stage, wsum);
 }
 
 // ---- a5 alone ----------------------------------------------------------------------------------
