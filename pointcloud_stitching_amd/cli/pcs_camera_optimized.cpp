@@ -35,7 +35,7 @@ typedef std::chrono::duration<double, std::milli> timeMilli;
 
 static const char* filename = nullptr;
 static bool display_updates = false, send_buffer = false, cutoff = false, use_hip = false, compress = false;
-static bool cutoff_compat = false, drop_invalid = false, pull_mode = false, half_pixel = false;
+static bool cutoff_compat = false, drop_invalid = false, pull_mode = false, half_pixel = false, pageable = false;
 static int num_of_threads = 1, device = 0, n_streams = 1, downsample = 1, max_frames = 60, port = 8000;
 static const char* dump_path = nullptr;
 static const char* extrinsics_path = nullptr;
@@ -54,13 +54,16 @@ static void print_usage()
            "  -g <dev>  GPU ordinal   -r <frames>   -o <file> dump last stitched buffer   -p <port>\n"
            "  -P        serve frames on 'Z' pull requests (the live server's protocol) instead of pushing them\n"
            "  -e <file> camera-to-world matrices, 16 row-major floats per line (python -m pointcloud_stitching_amd.calibration)\n"
-           "  -H        texture coordinates as older librealsense releases: (pixel + 0.5) / size\n\n");
+           "  -H        texture coordinates as older librealsense releases: (pixel + 0.5) / size\n"
+           "  -M        hand the frames over in ordinary pageable memory, as librealsense owns them in the reference's timed region\n"
+           "            (:291-293): uploads are staged then. Default: frames copied to page-locked rasters BEFORE the timer starts\n"
+           "            (zero copy) - the printed times then belong to a capture pipeline that delivers page-locked frames\n\n");
 }
 
 static void parseArgs(int argc, char** argv)
 {
     int c;
-    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:e:PH")) != -1) {
+    while ((c = getopt(argc, argv, "hf:vst:cmzg:n:d:iCr:o:p:e:PHM")) != -1) {
         switch (c) {
             case 'h': print_usage(); exit(0);
             case 'f': filename = optarg; break;
@@ -81,6 +84,7 @@ static void parseArgs(int argc, char** argv)
             case 'p': port = atoi(optarg); break;
             case 'e': extrinsics_path = optarg; break;
             case 'P': pull_mode = true; send_buffer = true; break;
+            case 'M': pageable = true; break;
             default: print_usage(); exit(2);
         }
     }
@@ -232,15 +236,19 @@ int main(int argc, char** argv)
         i++;
         for (int s = 0; s < n_streams; s++) {
             const size_t db = src.depth[s].size() * sizeof(uint16_t), cb = src.color[s].size();
-            if (db > pin_db[s]) {
+            if (!pageable && db > pin_db[s]) {
                 if (pin_d[s]) pcs_host_free(ctx, pin_d[s]);
                 if (pcs_host_malloc(ctx, (void**)&pin_d[s], db) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
                 pin_db[s] = db;
             }
-            if (cb > pin_cb[s]) {
+            if (!pageable && cb > pin_cb[s]) {
                 if (pin_c[s]) pcs_host_free(ctx, pin_c[s]);
                 if (pcs_host_malloc(ctx, (void**)&pin_c[s], cb) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
                 pin_cb[s] = cb;
+            }
+            if (pageable) {       // -M: the frame source's own (pageable) memory goes straight in, like librealsense's frames do
+                dptr[s] = src.depth[s].data(); cptr[s] = src.color[s].data();
+                continue;
             }
             memcpy(pin_d[s], src.depth[s].data(), db);
             memcpy(pin_c[s], src.color[s].data(), cb);
@@ -295,7 +303,9 @@ int main(int argc, char** argv)
     // every buffer handed to pcs_process_frames is page-locked, so unless PCS_ZERO_COPY=0 the kernels read the rasters and
     // write the payload over PCIe themselves: their time then is a link figure, not an HBM one
     const char* zc_env = getenv("PCS_ZERO_COPY");
-    const bool zero_copy = !(zc_env && atoi(zc_env) == 0);
+    const bool zero_copy = !(zc_env && atoi(zc_env) == 0) && !pageable;
+    std::cout << "### Frame hand-over : " << (pageable ? "pageable rasters (-M): staged uploads inside the timed region, as the reference's frames"
+                                                       : "page-locked rasters filled before the timer starts (zero copy)") << std::endl;
     if (zero_copy) {
         std::cout << "### AVG Kernel Time: " << kavg << " ms  (hipEvent; zero copy: rasters read from and payload written to host memory over PCIe)" << std::endl;
         if (kavg > 0)

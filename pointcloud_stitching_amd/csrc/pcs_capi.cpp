@@ -103,6 +103,9 @@ struct pcs_ctx {
     hipStream_t                     dl_stream = nullptr;
     int                             next_ticket = 0, next_collect = 0;
 
+    struct ZcEntry { const void* host; size_t bytes; void* dev; int verdict; };
+    std::vector<ZcEntry>            zc_cache;                  // zero-copy eligibility verdicts (host_device_view)
+
     std::string                     err;
 };
 
@@ -908,15 +911,48 @@ int pcs_copy_pointclouds_xyzrgb_to_buffer_device(pcs_ctx* c, int n_clouds, const
     return PCS_OK;
 }
 
-// The device's view of a page-locked host allocation (pcs_host_malloc, hipHostMalloc, hipHostRegister); false for
-// pageable memory.
-static bool host_device_view(const void* h, void** d)
+// The device's view of a page-locked host range (pcs_host_malloc, hipHostMalloc, hipHostRegister).
+//   1  the page-locked allocation covers ALL `bytes` the kernels will touch from `h` on: *d is the device view (zero copy)
+//   0  pageable memory: the caller stages
+//  -1  page-locked, but the allocation ends before h + bytes (a buffer registered in part, an interior pointer too close to
+//      the end of a registration): neither route can take it — a kernel would run off the end of the mapping and fault on
+//      the GPU, and the HIP runtime refuses copies that straddle the edge of a registration — so the call is refused
+// The verdict is cached per (pointer, bytes): a frame loop that hands the same buffers over every frame does no driver
+// look-ups after the first; pcs_host_free / pcs_host_unregister drop the cache.
+static int host_device_view(pcs_ctx* c, const void* h, size_t bytes, void** d)
 {
+    for (const auto& e : c->zc_cache)
+        if (e.host == h && e.bytes == bytes) { *d = e.dev; return e.verdict; }
+    void* dev = nullptr;
+    int verdict = 0;
     hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, h) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
-    *d = a.devicePointer;
-    return true;
+    if (hipPointerGetAttributes(&a, h) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer) {
+        verdict = -1;
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) == hipSuccess && base) {
+            const size_t off = (size_t)((const char*)a.devicePointer - (const char*)base);
+            if (off <= size && bytes <= size - off) { dev = a.devicePointer; verdict = 1; }
+        } else if (bytes > 0) {
+            // (the runtime reports no range for hipHostRegister'ed memory) the LAST byte must be page-locked too, and sit in
+            // the same mapping: its device view is the first byte's plus the distance
+            (void)hipGetLastError();
+            hipPointerAttribute_t z{};
+            const char* last = static_cast<const char*>(h) + (bytes - 1);
+            if (hipPointerGetAttributes(&z, last) == hipSuccess && z.type == hipMemoryTypeHost && z.devicePointer &&
+                (const char*)z.devicePointer - (const char*)a.devicePointer == (ptrdiff_t)(bytes - 1)) { dev = a.devicePointer; verdict = 1; }
+        }
+    }
+    (void)hipGetLastError();
+    if (c->zc_cache.size() >= 64) c->zc_cache.erase(c->zc_cache.begin());
+    c->zc_cache.push_back({h, bytes, dev, verdict});
+    *d = dev;
+    return verdict;
+}
+static int partly_locked(pcs_ctx* c, const char* what, int idx)
+{
+    return fail(c, PCS_ERR_INVALID_ARG, "%s %d is page-locked for only part of the range this call touches: register the whole "
+                "buffer (pcs_host_register) or none of it", what, idx);
 }
 static bool zero_copy_enabled()
 {
@@ -941,8 +977,10 @@ int pcs_copy_pointcloud_xyzrgb_to_buffer(pcs_ctx* c, int stream, const float* ve
     if (zero_copy_enabled()) {
         // page-locked arrays on every side (see pcs_process_frames): the kernel reads and writes them in place
         void *zv = nullptr, *zt = nullptr, *zc = nullptr, *zo = nullptr;
-        if (host_device_view(vertices, &zv) && host_device_view(texcoords, &zt) && host_device_view(color, &zc) &&
-            host_device_view(pc_buffer, &zo)) {
+        const int v4[4] = {host_device_view(c, vertices, vb, &zv), host_device_view(c, texcoords, tb, &zt),
+                           host_device_view(c, color, P.color_bytes, &zc), host_device_view(c, pc_buffer, ob, &zo)};
+        for (int k = 0; k < 4; k++) if (v4[k] < 0) return partly_locked(c, "array", k);
+        if (v4[0] == 1 && v4[1] == 1 && v4[2] == 1 && v4[3] == 1) {
             rc = pcs_copy_pointcloud_xyzrgb_to_buffer_device(c, stream, static_cast<const float*>(zv), static_cast<const float*>(zt),
                                                              n_points, static_cast<const uint8_t*>(zc), static_cast<int16_t*>(zo), nullptr);
             if (rc) return rc;
@@ -1168,13 +1206,21 @@ try {
         std::vector<const uint8_t*> zcol(c->n_streams);
         void* zout = nullptr;
         bool zero_copy = zero_copy_enabled() && stitched_shorts >= need && ((uintptr_t)stitched & 3u) == 0;
-        auto device_view = host_device_view;
-        for (int s = 0; zero_copy && s < c->n_streams; s++) {
+        // (every buffer is looked at even when zero copy is already off the table: a partly page-locked one is refused here
+        // with a reason instead of failing inside a staging copy)
+        for (int s = 0; s < c->n_streams; s++) {
             void *a = nullptr, *b = nullptr;
-            zero_copy = device_view(depth[s], &a) && device_view(color[s], &b);
+            const int va = host_device_view(c, depth[s], (size_t)c->h_params[s].n_points * sizeof(uint16_t), &a);
+            const int vb = host_device_view(c, color[s], c->h_params[s].color_bytes, &b);
+            if (va < 0 || vb < 0) return partly_locked(c, va < 0 ? "depth raster" : "colour raster", s);
+            zero_copy = zero_copy && va == 1 && vb == 1;
             zd[s] = static_cast<const uint16_t*>(a); zcol[s] = static_cast<const uint8_t*>(b);
         }
-        if (zero_copy) zero_copy = device_view(stitched, &zout);
+        {
+            const int vo = host_device_view(c, stitched, std::min(stitched_shorts, need) * sizeof(int16_t), &zout);
+            if (vo < 0) return partly_locked(c, "stitched buffer", 0);
+            zero_copy = zero_copy && vo == 1;
+        }
         if (zero_copy) {
             int16_t* zpay = static_cast<int16_t*>(zout) + PCS_HEADER_SHORTS;
             rc = run_fused_device(c, zd.data(), zcol.data(), zpay, c->max_payload_points * PCS_POINT_SHORTS, c->d_counts, true);
@@ -1289,7 +1335,16 @@ try {
     DeviceGuard guard(c->device);
     // whatever happens below, the slot is released and the ticket consumed: a failed frame-set is dropped, it must
     // not wedge the pipeline (later tickets could otherwise never be collected)
-    struct Release { pcs_ctx* c; pcs_ctx::PipeSlot* sl; ~Release() { sl->busy = false; c->next_collect++; } } release{c, sl};
+    // ... and on a FAILED exit both streams are drained first: the slot's kernels or its download may still be in flight, and
+    // the next submit would reuse its rasters, payload and counts under them
+    struct Release {
+        pcs_ctx* c; pcs_ctx::PipeSlot* sl; bool ok = false;
+        ~Release()
+        {
+            if (!ok) { (void)hipStreamSynchronize(c->stream); if (c->dl_stream) (void)hipStreamSynchronize(c->dl_stream); }
+            sl->busy = false; c->next_collect++;
+        }
+    } release{c, sl};
     HIPCHK(c, hipStreamWaitEvent(c->dl_stream, sl->done, 0));
     std::vector<int32_t> h(c->n_streams + 1);
     size_t total;
@@ -1314,6 +1369,7 @@ try {
     if (write_header) std::memcpy(stitched, &size, sizeof size);
     if (points_per_stream) for (int s = 0; s < c->n_streams; s++) points_per_stream[s] = h[s];
     if (out_size_bytes) *out_size_bytes = size;
+    release.ok = true;
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_collect_frames: host allocation failed (%s)", ex.what());
@@ -1674,6 +1730,8 @@ int pcs_host_free(pcs_ctx* c, void* h_ptr)
     if (!c) return PCS_ERR_INVALID_ARG;
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->dl_stream) HIPCHK(c, hipStreamSynchronize(c->dl_stream));
+    c->zc_cache.clear();
     HIPCHK(c, hipHostFree(h_ptr));
     return PCS_OK;
 }
@@ -1696,6 +1754,8 @@ int pcs_host_unregister(pcs_ctx* c, void* h_ptr)
     if (!c) return PCS_ERR_INVALID_ARG;
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->dl_stream) HIPCHK(c, hipStreamSynchronize(c->dl_stream));     // a pipelined download may still target the range
+    c->zc_cache.clear();
     HIPCHK(c, hipHostUnregister(h_ptr));
     return PCS_OK;
 }

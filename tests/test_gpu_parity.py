@@ -731,6 +731,54 @@ def test_host_api_zero_copy_with_pinned_buffers(oracle, flags, stride, shapes):
             out[...] = 0x5555
 
 
+def test_host_api_partially_registered_buffers_are_refused_not_faulted(oracle):
+    """Zero copy needs the page-locked range to cover EVERYTHING the kernels touch. A stitched buffer of which only the first
+    half is registered, an interior pointer too close to the end of a registration and a raster registered without its last
+    pages are refused with PCS_ERR_INVALID_ARG and a reason (the HIP runtime also refuses staging copies that straddle the
+    edge of a registration) — before any kernel could run off the end of a mapping and fault on the GPU. Fully registered
+    and fully pageable buffers keep working on the same context."""
+    shapes = [(640, 480)] * 2
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
+    color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+    want, wcounts = oracle.process_frames(cfgs, depth, color)
+    with PcsContext(cfgs) as ctx:
+        rd = [np.array(d) for d in depth]; rc = [np.array(c) for c in color]
+        big = np.full(4 * (2 + ctx.max_payload_shorts), 0x5555, np.int16)
+        rout = big[:2 + ctx.max_payload_shorts]
+        for a in rd + rc:
+            ctx.host_register(a)
+        # (a) output registered for its first half only
+        ctx.host_register(rout[:rout.size // 2])
+        with pytest.raises(PcsError) as e:
+            ctx.process_frames(rd, rc, out=rout)
+        assert e.value.status == -1 and "page-locked for only part" in str(e.value)
+        ctx.host_unregister(rout[:rout.size // 2])
+        # (b) whole output registered, handed over through an interior pointer that leaves too little room behind it
+        ctx.host_register(rout)
+        tail = big[rout.size // 2:rout.size // 2 + 2 + ctx.max_payload_shorts]      # starts inside the registration, ends outside
+        with pytest.raises(PcsError) as e:
+            ctx.process_frames(rd, rc, out=tail)
+        assert e.value.status == -1
+        # (c) a raster registered without its last 8 KiB
+        ctx.host_unregister(rd[0])
+        ctx.host_register(rd[0].reshape(-1)[:rd[0].size - 4096])
+        with pytest.raises(PcsError) as e:
+            ctx.process_frames(rd, rc, out=rout)
+        assert e.value.status == -1 and "depth raster 0" in str(e.value)
+        ctx.host_unregister(rd[0].reshape(-1)[:rd[0].size - 4096])
+        # everything registered in full: zero copy; everything pageable: staged — the same bytes
+        ctx.host_register(rd[0])
+        buf, counts, size = ctx.process_frames(rd, rc, out=rout)
+        assert counts == wcounts and size == want.size * 2
+        assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
+        for a in rd + rc + [rout]:
+            ctx.host_unregister(a)
+        buf, counts, size = ctx.process_frames(rd, rc, out=rout)
+        assert counts == wcounts
+        assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
+
+
 @pytest.mark.parametrize("flags", [0, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT])
 @pytest.mark.parametrize("n", [1, 7, 2048, 70001])
 def test_a2_twin_zero_copy_with_pinned_arrays(oracle, flags, n):
