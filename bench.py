@@ -248,12 +248,6 @@ def run_config5(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    else:   # a one-rank group keeps the code path identical (gloo: no device traffic at world 1)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:
-            import socket
-            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
-        dist.init_process_group("gloo", rank=0, world_size=1)
 
     full = (args.streams, args.width, args.height) == (8, 1280, 720)        # the stitch workload's defaults: not given
     total_streams, W, H = (16, 1920, 1080) if full else (args.streams, args.width, args.height)
@@ -380,7 +374,6 @@ def run_config5(args):
                           "note": "host clock with a device synchronisation after each phase, max over ranks; the timed region has none at N = 1"},
             "partials_per_rank": counts, "partials_total": int(sum(counts)),
             "exchange_bytes_per_step": int(sum(counts[1:]) * 40),
-            "payload_route_bytes_per_step": None,
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": None, "kernel": "pcs_fused_voxel_partials_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": int(algo),
@@ -393,20 +386,23 @@ def run_config5(args):
         if world == 1 and not args.no_cpu_baseline:
             with Leg(out, "cpu_baseline"):
                 from oracle import pcs_oracle as O
-                ns = min(2, S)
+                ns = min(8, S)
                 hd = [Syn.synth_depth(W, H, s) for s in range(ns)]
                 hc = [Syn.synth_color(W, H, s) for s in range(ns)]
-                tc = time.perf_counter()
-                st_, _ = O.process_frames(cfgs[:ns], hd, hc, FLAG_DROP_INVALID, 1)
-                O.voxel_grid(st_, LEAF)
-                tc = time.perf_counter() - tc
-                out["cpu_baseline"] = {"value": round(ns * npts / tc / 1e6, 2), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                best, passes, t_end = float("inf"), 0, time.perf_counter() + args.cpu_seconds
+                while passes < 1 or time.perf_counter() < t_end:
+                    tc = time.perf_counter()
+                    st_, _ = O.process_frames(cfgs[:ns], hd, hc, FLAG_DROP_INVALID, 1)
+                    O.voxel_grid(st_, LEAF)
+                    best = min(best, time.perf_counter() - tc); passes += 1
+                out["cpu_baseline"] = {"value": round(ns * npts / best / 1e6, 2), "unit": "Mpoints/s", "cores": 1, "kind": "port",
                                        "sample": f"{ns} of {total_streams} streams: deprojection + pack + compaction + stitch + voxel grid by the "
-                                                 f"scalar CPU oracle, one pass ({tc:.1f} s); the reference itself has no voxel grid "
-                                                 f"(src/pcs-multicamera-optimized.cpp:17 only includes the header)"}
+                                                 f"scalar CPU oracle, best of {passes} passes ({best:.2f} s each); the reference itself has no "
+                                                 f"voxel grid (src/pcs-multicamera-optimized.cpp:17 only includes the header)"}
         print(json.dumps(out), flush=True)
     ctx.close()
-    dist.destroy_process_group()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():

@@ -41,9 +41,12 @@ class RankStitcher:
     def __init__(self, group=None, root: int = 0):
         self.group = group
         self.root = root
+        self._h_counts: Optional[torch.Tensor] = None
+        if not dist.is_initialized():          # one GPU, no process group: every exchange is the identity
+            self.rank, self.world, self.host_staged = 0, 1, False
+            return
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self._h_counts: Optional[torch.Tensor] = None
         # gloo moves host memory only: device tensors are staged through the host then (the CPU tests, and the
         # two-ranks-on-one-GPU control-flow tests of the GPU tier; RCCL — backend "nccl" — moves device memory itself)
         self.host_staged = dist.get_backend(group) == "gloo"
@@ -70,6 +73,8 @@ class RankStitcher:
             t = local_count.reshape(1).to(device=device, dtype=torch.int64)
         else:
             t = torch.tensor([int(local_count)], dtype=torch.int64, device=device)
+        if self.world == 1:
+            return [int(t.item())]
         if self.host_staged and device.type == "cuda":
             t, device = t.cpu(), torch.device("cpu")
         out = torch.empty(self.world, dtype=torch.int64, device=device)

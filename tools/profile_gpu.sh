@@ -6,8 +6,9 @@
 #   <tag>_pmc_summary.json   per-kernel means of the PMC counters (one rocprofv3 pass per counter group, --pmc only)
 #   traffic.json             HBM bytes per launch of the headline kernel (2 x FETCH_SIZE + WRITE_SIZE, KiB units)
 # Runs: the headline line (dense, --no-extra-legs so the average is over cold launches of ONE kernel), then one
-# run per other kernel family (bench.py --mode ...), then the config-5 tail (tools/voxel_bench.py).
-TAG=${1:-r02}
+# run per other kernel family (bench.py --mode ...), the config-5 tail (tools/voxel_bench.py) and the config-5 workload
+# (bench.py --workload config5: partials + sort + segmented mean from caller-held partials).
+TAG=${1:-r03}
 STEPS=${2:-200}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -24,14 +25,15 @@ RUNS[pack_batch]="$BENCH --mode pack_batch"
 RUNS[batch]="$BENCH --mode batch"
 RUNS[batch_drop_invalid]="$BENCH --mode batch_drop_invalid"
 RUNS[voxel]="python $PWD/tools/voxel_bench.py 16 1920 1080 50,200"
-ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch batch_drop_invalid voxel"
+RUNS[config5]="python $PWD/bench.py --workload config5 --steps 60 --warmup 5 --no-cpu-baseline"
+ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch batch_drop_invalid voxel config5"
 cd /tmp
 for R in $ORDER; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -- ${RUNS[$R]} > $OUT/stats_$R.log 2>&1
   echo "stats $R rc=$?"
 done
 # PMC passes (their own runs, --pmc + --kernel-trace only): HBM traffic for every family, the instruction mix for the headline
-for R in dense drop_invalid pack_batch batch batch_drop_invalid voxel; do
+for R in dense drop_invalid pack pack_batch batch batch_drop_invalid voxel config5; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${R}_$C -- ${RUNS[$R]} > $OUT/pmc_${R}_$C.log 2>&1
     echo "pmc $R $C rc=$?"
