@@ -74,7 +74,7 @@ struct pcs_ctx {
     // Rasters of all streams are carved from ONE slab at 256-byte granularity. Separate hipMalloc()s hand
     // out 2 MiB-aligned bases; the streams' tiles advance in lockstep, so equal offsets from power-of-two
     // aligned bases compete for the same sets of the memory-side Infinity Cache: with inputs that were just
-    // written (and so sit in that cache) the 8x720p launch measured 22.7 us vs 19.0 us (tools/kernel_lab.hip,
+    // written (and so sit in that cache) the 8x720p launch measured 22.7 us vs 19.0 us (tools/lab/kernel_lab.hip,
     // "allocation mode", 6-set ring). With cold inputs streamed from HBM the layout makes no difference.
     uint8_t*                        s_slab = nullptr;
     std::vector<uint16_t*>          s_depth;

@@ -129,7 +129,7 @@ using LazyCvt = FastCvt<true>;
 
 // Arithmetic policy of the depth->colour projection. Every policy the product launches is bit-identical
 // to IeeeMath on the inputs it is launched for (see "certification" in pcs_capi.cpp and DESIGN.md);
-// tools/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
+// tools/lab/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
 struct IeeeMath {
     static constexpr bool kIdentR = false;
     // 0 exact conversions, 1 fast with overflow tracking, 2 fast, overflow certified impossible.
@@ -559,7 +559,7 @@ __device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, 
     const uint32_t first_full = (head + 15u) >> 4;           // first chunk entirely inside
     const uint32_t last_full = end >> 4;                     // one past the last chunk entirely inside
     // nontemporal: the payload is written once and never re-read by this kernel; keeping it out of the
-    // caches' way measured +7 % on the store-dominated stream (tools/kernel_lab.hip, skeleton nt-store)
+    // caches' way measured +7 % on the store-dominated stream (tools/lab/kernel_lab.hip, skeleton nt-store)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     for (uint32_t j = first_full + threadIdx.x; j < last_full; j += kBlockThreads)
         __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(lds)[j], reinterpret_cast<u32x4*>(g0) + j);

@@ -2,7 +2,7 @@
 """Print VGPR / spill / occupancy / LDS of every kernel in pcs_kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage).
 Usage: python tools/kernel_resources.py [substring ...]"""
 import os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "pointcloud_stitching_amd", "csrc")
 src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "pcs_kernels.hip"
 pats = [a for a in sys.argv[1:] if not a.endswith(".hip")]

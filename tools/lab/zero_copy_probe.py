@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pointcloud_stitching_amd import synthetic as S          # noqa: E402
 from pointcloud_stitching_amd.api import PcsContext          # noqa: E402
 from pointcloud_stitching_amd.types import POINT_SHORTS      # noqa: E402
