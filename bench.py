@@ -859,6 +859,27 @@ def main():
                                      "path": os.environ.get("PCS_COMPACT_PATH", "three (default: count + scan + emit)"),
                                      "note": "PCS_FLAG_DROP_INVALID, order-preserving (= the reference's -c -m -t1 order), same cold ring; "
                                              "bytes = 2 (Z16) + 3 (RGB8) + 10*rho (records)"}
+                with Leg(out["compaction"], "caller_counts"):
+                    # a producer that counts as it writes the depth image hands the per-tile kept counts over
+                    # (pcs_process_frames_device_counted): scan + emit only, the Z16 rasters are read once
+                    tcs = []
+                    for slot in range(R):
+                        tcs.append(torch.cat([d.view(torch.int16).ne(0).view(-1, 2048).sum(1, dtype=torch.int32) for d in d_depth[slot]]))
+
+                    def launch_cc():
+                        slot = next_slot()
+                        dp, cp, outp = call_args[slot]
+                        check(lib.pcs_process_frames_device_counted(ctx_c._h, dp, cp, VP(tcs[slot].data_ptr()), outp, payload_shorts, None), ctx_c._h)
+                    if npts % 2048 == 0:
+                        for _ in range(50):
+                            launch_cc()
+                        torch.cuda.synchronize(dev)
+                        ms_cc = timed(launch_cc, n_leg, ctx_c)
+                        ach_cc = set_points * (5 + 10 * rho) / (ms_cc * 1e-3) / 1e9
+                        out["compaction"]["caller_counts"] = {
+                            "ms_per_step": round(ms_cc, 5), "achieved": round(ach_cc, 1), "frac": round(ach_cc / HBM_PEAK_GBS, 4),
+                            "note": "pcs_process_frames_device_counted: per-tile kept counts handed in by the producer of the depth "
+                                    "image (here: computed beforehand, outside the timed region), scan + emit only"}
                 if KB >= 2:
                     # K frame-sets per call: three launches (count, scan, emit) for all K sets, nothing order-dependent
                     def launch_cb():

@@ -222,6 +222,21 @@ int pcs_collect_frames(pcs_ctx* ctx, int ticket, int16_t* stitched, size_t stitc
 int pcs_process_frames_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                               int16_t* d_payload, size_t payload_shorts, int32_t* d_counts);
 
+/* The same with the per-tile kept counts HANDED IN by a producer that already knows them (whatever wrote the depth image on
+ * the GPU — a decoder, a filter, a simulator — can count as it writes): the count pass, and with it the second read of the
+ * Z16 rasters, does not run (8 x 1280x720 with invalid-depth drop: 5.3 us of kernel time and 14.7 MB of reads per frame-set
+ * less; in a back-to-back frame loop, where the next call's count pass hides behind the tail of the previous emit launch
+ * anyway, 32.1 -> 31.2 us per frame-set).
+ * A tile is PCS_TILE_POINTS consecutive pixels of one stream (row-major, the last tile of a stream may be short);
+ * d_tile_kept[pcs_stream_tile_base(ctx, s) + t] = how many pixels of tile t of stream s the context's predicate keeps
+ * (PCS_FLAG_DROP_INVALID alone: its non-zero depth words). pcs_stream_tile_base(ctx, n_streams) = entries in all. The counts
+ * must be exact for the output to be the stitched cloud; WRONG counts garble the cloud but cannot write outside the payload's
+ * worst-case capacity (they are clamped to a tile). Without CUTOFF / DROP_INVALID the counts are ignored.              */
+#define PCS_TILE_POINTS 2048
+int pcs_stream_tile_base(const pcs_ctx* ctx, int stream);
+int pcs_process_frames_device_counted(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                      const uint32_t* d_tile_kept, int16_t* d_payload, size_t payload_shorts, int32_t* d_counts);
+
 /* Throughput form: n_sets frame-sets of the SAME streams per call. d_depth / d_color hold n_sets * n_streams device
  * pointers, frame-set major (entry k*n_streams + s = stream s of frame-set k); d_payload[k] is frame-set k's payload
  * pointer (each with payload_shorts capacity), d_counts (optional) n_sets pointers as in pcs_process_frames_device.

@@ -208,6 +208,18 @@ class PcsContext:
         self._check(self._lib.pcs_process_frames_device(self._h, dp, cp, d_payload, payload_shorts,
                                                         d_counts or None))
 
+    def stream_tile_base(self, stream: int) -> int:
+        """Index of the stream's first tile in a per-tile array (stream == n_streams: the number of tiles in all)."""
+        return int(self._lib.pcs_stream_tile_base(self._h, stream))
+
+    def process_frames_device_counted(self, d_depth: Sequence[int], d_color: Sequence[int], d_tile_kept: int, d_payload: int,
+                                      payload_shorts: int, d_counts: int = 0) -> None:
+        """pcs_process_frames_device with the per-tile kept counts handed in by the producer (no count pass)."""
+        dp = (C.c_void_p * self.n_streams)(*d_depth)
+        cp = (C.c_void_p * self.n_streams)(*d_color)
+        self._check(self._lib.pcs_process_frames_device_counted(self._h, dp, cp, d_tile_kept, d_payload, payload_shorts,
+                                                                d_counts or None))
+
     def process_frames_device_batch(self, d_depth: Sequence[Sequence[int]], d_color: Sequence[Sequence[int]],
                                     d_payload: Sequence[int], payload_shorts: int,
                                     d_counts: Optional[Sequence[int]] = None) -> None:

@@ -401,7 +401,8 @@ int acquire_event_pair(pcs_ctx* c, std::pair<hipEvent_t, hipEvent_t>& pr)
 
 // The fused path for device-resident rasters. Counts end up in d_counts (if non-null).
 int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
-                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts, bool force_three_pass = false)
+                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts, bool force_three_pass = false,
+                     const uint32_t* d_tile_kept = nullptr)
 {
     if (payload_shorts < c->max_payload_points * PCS_POINT_SHORTS && !has_pred(c->flags))
         return fail(c, PCS_ERR_CAPACITY, "payload buffer holds %zu shorts, %zu needed", payload_shorts,
@@ -419,7 +420,7 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(ev.first, c->stream));
     }
-    const bool one_launch = pred && c->downsample == 1 && c->single_pass_ok && !force_three_pass;
+    const bool one_launch = pred && c->downsample == 1 && c->single_pass_ok && !force_three_pass && !d_tile_kept;
     const bool single_pass = one_launch && c->compact_path == 1;
     if (single_pass) {
         if (!c->d_ticket) {
@@ -466,7 +467,9 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
         return PCS_OK;
     }
     if (pred) {
-        for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
+        // (a caller that knows how many points each tile keeps — whatever wrote the depth image on the GPU — hands the counts
+        // over and the count pass, with its second read of the Z16 rasters, does not run at all)
+        for (int s0 = 0; !d_tile_kept && s0 < c->n_streams; s0 += kLaunchStreams) {
             const int nl = std::min(kLaunchStreams, c->n_streams - s0);
             FramePtrs fp{};
             uint32_t mp = 0;
@@ -474,7 +477,7 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
             HIPCHK(c, launch_fused_count(c->d_params, s0, nl, mp, c->flags, fp, c->d_tile_counts, c->stream));
         }
         // per-stream counts come from the scan; the grand total from the first emit launch (no last-arriver atomic)
-        HIPCHK(c, launch_scan(c->d_params, c->n_streams, c->downsample, c->d_tile_counts, c->d_tile_prefix,
+        HIPCHK(c, launch_scan(c->d_params, c->n_streams, c->downsample, d_tile_kept ? d_tile_kept : c->d_tile_counts, c->d_tile_prefix,
                               c->d_stream_base, d_counts ? d_counts : c->d_counts, nullptr, c->stream));
     }
     for (int s0 = 0; s0 < c->n_streams; s0 += kLaunchStreams) {
@@ -1056,6 +1059,28 @@ try {
     return run_fused_device(c, d_depth, d_color, d_payload, payload_shorts, d_counts);
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_device: host allocation failed (%s)", ex.what());
+}
+
+int pcs_process_frames_device_counted(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                      const uint32_t* d_tile_kept, int16_t* d_payload, size_t payload_shorts, int32_t* d_counts)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!d_depth || !d_color || !d_payload || !d_tile_kept) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if ((uintptr_t)d_tile_kept & 3u) return fail(c, PCS_ERR_INVALID_ARG, "d_tile_kept must be 4-byte aligned");
+    for (int s = 0; s < c->n_streams; s++) {
+        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
+    }
+    DeviceGuard guard(c->device);
+    return run_fused_device(c, d_depth, d_color, d_payload, payload_shorts, d_counts, true, has_pred(c->flags) ? d_tile_kept : nullptr);
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_device_counted: host allocation failed (%s)", ex.what());
+}
+
+int pcs_stream_tile_base(const pcs_ctx* c, int stream)
+{
+    if (!c || stream < 0 || stream > c->n_streams) return PCS_ERR_INVALID_ARG;
+    return stream == c->n_streams ? (int)c->total_tiles : (int)c->h_params[stream].tile_base;
 }
 
 // K frame-sets per launch (throughput form). The dense path (no predicate, stride 1, 16-byte aligned payloads, every

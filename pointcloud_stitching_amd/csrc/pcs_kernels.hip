@@ -1140,7 +1140,9 @@ void pcs_scan_kernel(const StreamParams* __restrict__ params, int stream0, int n
     __syncthreads();
     for (uint32_t t0 = 0; t0 < tiles; t0 += 1024) {
         const uint32_t t = t0 + threadIdx.x;
-        const uint32_t c = (t < tiles) ? tile_counts[tb + t] : 0u;
+        // (a count can never exceed a tile: clamped, so that counts handed in by a caller — pcs_process_frames_device_counted —
+        // cannot steer a tile's stores past the payload's worst-case capacity whatever they contain)
+        const uint32_t c = (t < tiles) ? min(tile_counts[tb + t], min(kTilePoints, n - t * kTilePoints)) : 0u;
         uint32_t wave_total;
         const uint32_t ex = wave_exclusive_scan(c, wave_total);
         if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = wave_total;

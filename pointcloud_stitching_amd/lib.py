@@ -41,6 +41,8 @@ SYMBOLS = [
     ("pcs_process_frames", C.c_int,
      [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_process_frames_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _VP]),
+    ("pcs_process_frames_device_counted", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, _VP, C.c_size_t, _VP]),
+    ("pcs_stream_tile_base", C.c_int, [_VP, C.c_int]),
     ("pcs_process_frames_device_batch", C.c_int, [_VP, C.c_int, _P(_VP), _P(_VP), _P(_VP), C.c_size_t, _P(_VP)]),
     ("pcs_submit_frames", C.c_int, [_VP, _P(_VP), _P(_VP), _P(C.c_int)]),
     ("pcs_collect_frames", C.c_int, [_VP, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),

@@ -467,6 +467,56 @@ def compaction_path(request, monkeypatch):
     return request.param
 
 
+@pytest.mark.parametrize("flags", [FLAG_DROP_INVALID, FLAG_CUTOFF | FLAG_DROP_INVALID, FLAG_CUTOFF])
+def test_caller_provided_tile_counts_replace_the_count_pass(oracle, flags):
+    """pcs_process_frames_device_counted: a producer that knows how many pixels of every 2048-pixel tile the predicate keeps
+    hands the counts over; scan + emit alone must give the oracle's bytes. Garbage counts (any uint32) may garble the cloud
+    but must neither fail nor write outside the payload (guard words behind it stay intact)."""
+    shapes = [(640, 480), (200, 37), (1280, 720)]
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
+    color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+    for d in depth:
+        d[10:30, :] //= 4          # bring part of the scene inside the 1.5 m cutoff
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags)
+    tile = 2048
+    kept = []
+    for cfg, d in zip(cfgs, depth):
+        v, _ = oracle.deproject(cfg, d)
+        k = np.ones(d.size, bool)
+        if flags & FLAG_CUTOFF:
+            k &= (v[:, 2] > 0) & (v[:, 2] <= np.float32(1.5)) & (v[:, 0] > -2) & (v[:, 0] <= 2)
+        if flags & FLAG_DROP_INVALID:
+            k &= d.reshape(-1) != 0
+        pad = (-k.size) % tile
+        kept.append(np.r_[k, np.zeros(pad, bool)].reshape(-1, tile).sum(1).astype(np.uint32))
+    with PcsContext(cfgs, flags=flags) as ctx:
+        assert [ctx.stream_tile_base(s) for s in range(4)] == list(np.r_[0, np.cumsum([k.size for k in kept])])
+        counts_h = np.concatenate(kept)
+        n_max = ctx.max_payload_shorts
+        dd = [ctx.device_malloc(d.nbytes) for d in depth]; dc = [ctx.device_malloc(c.nbytes) for c in color]
+        for ptr, a in zip(dd + dc, depth + color):
+            ctx.memcpy_h2d(ptr, a)
+        d_tc = ctx.device_malloc(counts_h.nbytes); ctx.memcpy_h2d(d_tc, counts_h)
+        d_pay = ctx.device_malloc(n_max * 2 + 256); d_cnt = ctx.device_malloc(16)
+        guard = np.full(128, 0x5A5A, np.int16)
+        ctx.memcpy_h2d(d_pay + n_max * 2, guard)
+        ctx.process_frames_device_counted(dd, dc, d_tc, d_pay, n_max, d_cnt)
+        ctx.synchronize()
+        cnt = np.empty(4, np.int32); ctx.memcpy_d2h(cnt, d_cnt)
+        assert list(cnt[:3]) == wcounts and int(cnt[3]) == want.shape[0]
+        got = np.empty(want.size, np.int16); ctx.memcpy_d2h(got, d_pay)
+        assert_same(got.reshape(-1, 5), want)
+        rng = np.random.default_rng(5)
+        for trial in range(3):
+            junk = rng.integers(0, 2**32, counts_h.size, dtype=np.uint64).astype(np.uint32)
+            ctx.memcpy_h2d(d_tc, junk)
+            ctx.process_frames_device_counted(dd, dc, d_tc, d_pay, n_max, d_cnt)
+            ctx.synchronize()
+            back = np.empty(128, np.int16); ctx.memcpy_d2h(back, d_pay + n_max * 2)
+            assert (back == guard).all(), trial
+
+
 def test_single_pass_compaction_chained_launches_and_mixed_sizes(oracle, compaction_path):
     # 21 streams -> two launches chained through stream_end; mixed raster sizes -> ticket->(stream, tile) search
     sizes = [(64, 48), (128, 96), (104, 40), (200, 37), (640, 480)]
