@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised soak of pcs_process_frames_voxel_device (rasters -> voxel grid, no stitched cloud) against the oracle's
-voxel grid over the oracle's stitched cloud.   tools/voxel_raster_soak.py [seconds] [seed]"""
+"""Randomised soak of pcs_process_frames_voxel_device (rasters -> voxel grid, no stitched cloud) and of the partials exchange
+format (cameras split over several contexts, partials merged on one) against the oracle's voxel grid over the oracle's
+stitched cloud.   tools/voxel_raster_soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -18,7 +19,7 @@ from tests.test_gpu_parity import _random_config                                
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
-runs = patch_runs = bad = 0
+runs = patch_runs = shard_runs = bad = 0
 while time.time() - t0 < budget:
     n = int(rng.integers(1, 5))
     shapes = []
@@ -75,5 +76,48 @@ while time.time() - t0 < budget:
             if got.shape != want.shape or (got != want).any():
                 bad += 1
                 print("MISMATCH", shapes, flags, stride, leaf, got.shape, want.shape, flush=True)
-print(f"{runs} raster->voxel calls ({patch_runs} through the square-patch reader), {bad} mismatches in {time.time() - t0:.0f} s")
+    # the exchange format (config 5 sharded): the same cameras split over 1..n contexts, every shard's partials appended to the
+    # root's arrays in a random shard order, one sort + segmented mean over all of them
+    if n >= 1:
+        k = int(rng.integers(1, n + 1))
+        cuts = sorted(rng.choice(np.arange(1, n), k - 1, replace=False).tolist()) if k > 1 else []
+        bounds = [0] + cuts + [n]
+        leaf = int(rng.choice([1, 7, 29, 36, 50, 200, 4000]))
+        want = O.voxel_grid(stitched, leaf)
+        ctxs = [PcsContext(cfgs[a:b], flags=flags, downsample=stride) for a, b in zip(bounds[:-1], bounds[1:])]
+        try:
+            root = ctxs[0]
+            caps = [c.max_payload_shorts // 5 for c in ctxs]
+            d_k = root.device_malloc(sum(caps) * 8 + 64); d_p = root.device_malloc(sum(caps) * 32 + 64)
+            off = 0
+            for r in rng.permutation(len(ctxs)):
+                c = ctxs[r]; a, b = bounds[r], bounds[r + 1]
+                dd = [c.device_malloc(max(d.nbytes, 16)) for d in depth[a:b]]
+                dc = [c.device_malloc(max(x.nbytes, 16)) for x in color[a:b]]
+                for ptr, arr in zip(dd + dc, depth[a:b] + color[a:b]):
+                    c.memcpy_h2d(ptr, arr)
+                k_r = c.device_malloc(caps[r] * 8 + 64); p_r = c.device_malloc(caps[r] * 32 + 64); n_r = c.device_malloc(64)
+                c.process_frames_voxel_partials_device(dd, dc, leaf, k_r, p_r, caps[r], n_r)
+                c.synchronize()
+                m = np.empty(1, np.int32); c.memcpy_d2h(m, n_r); m = int(m[0])
+                if m:
+                    hk = np.empty(m, np.uint64); hp = np.empty(m * 8, np.uint32)
+                    c.memcpy_d2h(hk, k_r); c.memcpy_d2h(hp, p_r)
+                    root.memcpy_h2d(d_k + off * 8, hk); root.memcpy_h2d(d_p + off * 32, hp)
+                off += m
+            d_o = root.device_malloc(max(off, 1) * 10 + 64); d_n = root.device_malloc(64)
+            root.voxel_grid_from_partials_device(d_k, d_p, off, leaf, d_o, max(off, 1) * 5, d_n)
+            root.synchronize()
+            nv = np.empty(1, np.int32); root.memcpy_d2h(nv, d_n)
+            got = np.empty(max(int(nv[0]), 1) * 5, np.int16); root.memcpy_d2h(got, d_o)
+            got = got[:int(nv[0]) * 5].reshape(-1, 5)
+            shard_runs += 1
+            if got.shape != want.shape or (got != want).any():
+                bad += 1
+                print("MISMATCH (sharded partials)", shapes, flags, stride, leaf, bounds, got.shape, want.shape, flush=True)
+        finally:
+            for c in ctxs:
+                c.close()
+print(f"{runs} raster->voxel calls ({patch_runs} through the square-patch reader), {shard_runs} sharded partial merges, "
+      f"{bad} mismatches in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
