@@ -35,6 +35,10 @@ ALGO_BYTES_PER_POINT = 15            # 2 B Z16 + 3 B RGB8 + 10 B packed record (
 PACK_BYTES_PER_POINT = 33            # a2 twin: 12 B vertex + 8 B texcoord + 3 B RGB8 + 10 B record
 HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 INFINITY_CACHE_BYTES = 256 << 20     # MI355X memory-side cache: a ring whose inputs fit it is not an HBM measurement
+# A collective that never completes (the RCCL paths have not met a multi-GPU box yet) must end the run, not hang it: the process
+# group's watchdog gives up after this long.
+import datetime
+PG_TIMEOUT = datetime.timedelta(seconds=300)
 POLICY = {0: "ieee", 1: "certified", 2: "certified+identityR", 3: "certified+noOverflow",
           4: "certified+identityR+noOverflow"}
 
@@ -245,9 +249,9 @@ def run_config5(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if debug_gloo:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=PG_TIMEOUT)
 
     full = (args.streams, args.width, args.height) == (8, 1280, 720)        # the stitch workload's defaults: not given
     total_streams, W, H = (16, 1920, 1080) if full else (args.streams, args.width, args.height)
@@ -433,9 +437,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if debug_gloo:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=PG_TIMEOUT)
 
     W, H = args.width, args.height
     strong = args.scaling == "strong"

@@ -57,6 +57,11 @@ def test_bench_line_has_the_contract_keys():
     assert c5["pipeline_ms_per_frame_set"] > 0
     assert c5["one_call"]["voxels"] == c5["voxels"] and c5["one_call"]["ms_per_frame_set"] > 0
     assert comp["batched"]["frac"] > comp["frac"]
+    assert comp["caller_counts"]["frac"] > 0.2 and comp["path"].startswith("three")
+    assert d["pack_twin"]["per_stream_launches_frac"] > 0.4          # round 3: the arrays are read straight into registers
+    c1080 = d["color_1080p"]                                          # the real-camera geometry (depth 720p, colour 1080p, distortion)
+    assert 0.2 < c1080["frac"] < d["general_rotation"]["frac"] and "1920x1080" in c1080["workload"]
+    assert "leg_errors" not in d, d.get("leg_errors")
 
 
 def _bench_line(*extra, launcher=()):
