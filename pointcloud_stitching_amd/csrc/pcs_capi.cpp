@@ -1546,7 +1546,7 @@ try {
             fast &= q.cert_fast != 0; ident &= q.ident_r != 0;
         }
         const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
-        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->flags, sel, fp, vs, c->stream));
+        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
     }
     HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out, d_out_points, c->stream));
     if (c->kernel_timing) {
@@ -1608,7 +1608,7 @@ try {
                 fast &= q.cert_fast != 0; ident &= q.ident_r != 0;
             }
             const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
-            HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->flags, sel, fp, vs, c->stream));
+            HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
         }
     }
     HIPCHK(c, hipMemcpyAsync(d_n_partials, c->d_vox_ctl, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));

@@ -173,7 +173,8 @@ struct VoxelStage {
     unsigned int*       idx;           // nullptr with idx_bits == 0: raw keys only (exchange format)
     void*               part;          // VoxelPartial[capacity]
     unsigned int*       n_runs;        // partials appended so far
-    uint32_t            leaf, bias_leaf, magic, bits, idx_bits;
+    uint32_t            leaf, bits, idx_bits;
+    float               div_inv, div_c;   // voxel index of a coordinate: (unsigned)fmaf(v, div_inv, div_c) (pcs_voxel_agg.h: VoxelDiv)
     uint32_t            track_bits;    // record which key bits vary (the sort may then skip a pass); 0: the host declared all of them varying
 };
 hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
@@ -192,8 +193,8 @@ hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_po
                                          const VoxelStage& vs, hipStream_t st);
 // max_w / max_h: the largest raster of the launch; patch_ok: every raster's width is a multiple of 8 (square patches)
 hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                                       uint32_t max_w, uint32_t max_h, bool patch_ok, uint32_t flags, MathSel math,
-                                       const FramePtrs& fp, const VoxelStage& vs, hipStream_t st);
+                                       uint32_t max_w, uint32_t max_h, bool patch_ok, bool any_dist, uint32_t flags,
+                                       MathSel math, const FramePtrs& fp, const VoxelStage& vs, hipStream_t st);
 
 // a7 with stride.
 hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,

@@ -22,9 +22,19 @@
 // Float->int follows x86 cvttss2si including its "integer indefinite" result for NaN / out of range,
 // which v_cvt_i32_f32 (saturating) does not give by itself.
 
+// Two translation units from this one source (Makefile): pcs_kernels.o (PCS_TU_VOXEL=0: everything but the voxel readers,
+// SLP vectorisation off — packed FP32 measured 1-2 % slower on the HBM-bound kernels) and pcs_kernels_voxel.o
+// (PCS_TU_VOXEL=1: the raster / payload voxel readers, SLP on — that kernel is VALU-bound and v_pk_fma_f32 / v_pk_mul_f32
+// take 15 % of its vector instructions away: 146 -> 140 us per 16 x 1080p frame-set). A packed op is two independent,
+// individually rounded IEEE operations: the bits do not change.
+
 #include <cstddef>
 
 #include "pcs_device.h"
+
+#ifndef PCS_TU_VOXEL
+#define PCS_TU_VOXEL 0
+#endif
 
 #ifndef EMIT_WAVES
 #define EMIT_WAVES 6      // 7 fits 72 VGPRs only with scratch spills in some instantiations and measured no faster
@@ -765,6 +775,7 @@ struct CompactArgs {
     int32_t             last_launch;  // this launch holds the frame-set's last stream
 };
 
+#if !PCS_TU_VOXEL   // ---- kernels of the main translation unit (see the note at the top of the file) ----
 template <class Mth>
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int stream0, int n_launch, FramePtrs fp,
@@ -884,6 +895,8 @@ void pcs_fused_compact_kernel(const StreamParams* __restrict__ params, int strea
     store_staged(stage, head, tile_kept * PCS_POINT_BYTES, gdst);
 }
 
+#endif  // !PCS_TU_VOXEL
+
 // Request a stream's constants (and this launch's raster pointers) with ONE batch of scalar loads at the top of a
 // kernel. Left alone, hipcc asks for them one dependent group at a time — the kernarg, then n_points for the early
 // exit, then the raster pointers and the width, then the LUT pointers — four scalar round trips before the first
@@ -919,6 +932,7 @@ __device__ __forceinline__ void request_constants(const StreamParams& P, const v
 // ------------------------------------------------------------------------------------------------
 // Kernels
 // ------------------------------------------------------------------------------------------------
+#if !PCS_TU_VOXEL
 
 template <bool DDIST, bool CDIST, class Mth>
 __global__ __launch_bounds__(kBlockThreads, 7)     // <= 72 VGPRs for every instantiation (one landed on 73 -> 6 waves/SIMD); A/B on one box: no measurable change, 8 spills and is slower
@@ -1213,6 +1227,9 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
     }
 }
 
+#endif  // !PCS_TU_VOXEL
+
+#if PCS_TU_VOXEL
 // ---- rasters -> voxel partials (config 5 without the stitched payload) ---------------------------------------------
 // pcs_process_frames_voxel_device: the voxel grid of the cloud pcs_process_frames_device would stitch, without writing
 // that cloud (10 B per kept point out, 10 B back in for the pre-aggregation) and without its ordered placement (count
@@ -1262,7 +1279,7 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
 {
     unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
     unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl;
-    const VoxelDiv dv{vs.leaf, vs.bias_leaf, vs.magic};
+    const VoxelDiv dv{vs.div_inv, vs.div_c};
     const unsigned int bits = vs.bits, idx_bits = vs.idx_bits;
     VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
     const int lane = threadIdx.x & 63;
@@ -1447,7 +1464,7 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
 // 512 lanes x several rounds rather than 1024 x 1: the raster reader needs ~100 VGPRs (the stitch kernels' 8 points in
 // flight plus the table phase), which leaves room for one 1024-lane workgroup per CU — its load phase and its LDS phase
 // then have nothing to overlap with. Two 512-lane workgroups fit, and there is no barrier between the rounds.
-template <class Mth>
+template <bool DD, bool CD, class Mth>
 __global__ __launch_bounds__(kVoxThreads)
 void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
                                      VoxelStage vs, int rounds, int rx, int crowded)
@@ -1469,7 +1486,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
     if (rx ? (py * 64u * ry >= Hh) : (tile0 >= n)) return;
     const uint8_t* __restrict__ color = fp.color[s];
-    DepthSource<true, true, Mth> src{fp.depth[s]};
+    DepthSource<DD, CD, Mth> src{fp.depth[s]};
     vox_table_init(T);
 
     for (int round = 0; round < rounds; round++) {
@@ -1550,6 +1567,9 @@ void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint
     vox_table_flush(T, vs, key_or, key_orn);
 }
 
+#endif  // PCS_TU_VOXEL
+
+#if !PCS_TU_VOXEL
 // ---- a2 twin -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_pack_dense_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp,
@@ -1687,6 +1707,8 @@ void pcs_verify_div_const_kernel(float c, float rc, int32_t dim, unsigned long l
     if (local) atomicAdd(bad, (unsigned long long)local);
 }
 
+#endif  // !PCS_TU_VOXEL
+
 inline dim3 tile_grid(uint32_t max_points, int n_launch)
 {
     return dim3((max_points + kTilePoints - 1) / kTilePoints, (unsigned)n_launch, 1);
@@ -1698,6 +1720,7 @@ inline dim3 tile_grid(uint32_t max_points, int n_launch)
 // Launchers
 // ------------------------------------------------------------------------------------------------
 
+#if !PCS_TU_VOXEL
 hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
                               bool any_ddist, bool any_cdist, MathSel math, const FramePtrs& fp, int16_t* d_payload,
                               hipStream_t st)
@@ -1826,9 +1849,12 @@ hipError_t launch_compact_batch(const StreamParams* d_params, int n_streams, int
     return hipGetLastError();
 }
 
+#endif  // !PCS_TU_VOXEL
+
+#if PCS_TU_VOXEL
 hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
-                                       uint32_t max_w, uint32_t max_h, bool patch_ok, uint32_t flags, MathSel math,
-                                       const FramePtrs& fp, const VoxelStage& vs, hipStream_t st)
+                                       uint32_t max_w, uint32_t max_h, bool patch_ok, bool any_dist, uint32_t flags,
+                                       MathSel math, const FramePtrs& fp, const VoxelStage& vs, hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
     static const int env_rounds = [] { const char* v = getenv("PCS_VOXEL_ROUNDS"); return v ? atoi(v) : 0; }();
@@ -1865,9 +1891,13 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
         grid = dim3((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
     }
-#define L(M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx, vs.leaf < 30u ? 1 : 0)
+    // no stream of the context has a distortion model (or the half-pixel texture convention): the instantiation without
+    // their (uniform, but not free in a VALU-bound kernel) tests
+#define L(D, M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<D, D, M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx, vs.leaf < 30u ? 1 : 0)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
-    if (math == MathSel::Ieee) L(IeeeMath); else if (ident) L(CertMath<true>); else L(CertMath<false>);
+    if (math == MathSel::Ieee) L(true, IeeeMath);
+    else if (any_dist) { if (ident) L(true, CertMath<true>); else L(true, CertMath<false>); }
+    else               { if (ident) L(false, CertMath<true>); else L(false, CertMath<false>); }
 #undef L
     return hipGetLastError();
 }
@@ -1892,6 +1922,9 @@ hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_po
     return hipGetLastError();
 }
 
+#endif  // PCS_TU_VOXEL
+
+#if !PCS_TU_VOXEL
 hipError_t launch_pack_batch(const StreamParams* d_params, const PackBatch& pb, int n, uint32_t max_points, bool aligned,
                              hipStream_t st)
 {
@@ -1972,5 +2005,7 @@ hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsamp
                        reinterpret_cast<const uint16_t*>(d_src), out_points, ds, reinterpret_cast<uint8_t*>(d_dst));
     return hipGetLastError();
 }
+
+#endif  // !PCS_TU_VOXEL
 
 }  // namespace pcs

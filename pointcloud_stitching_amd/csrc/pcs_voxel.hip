@@ -27,6 +27,7 @@
 // (Round 1 used rocPRIM's radix_sort_pairs + reduce_by_key for steps 2-3: 0.56 ms of library kernels per call at 50 mm,
 // plus a stream synchronisation in the middle of the call to learn m.)
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -810,32 +811,27 @@ struct Plan {
     bool track_bits;      // have the pre-aggregation record which key bits vary, so that the sort can skip passes
 };
 
-// floor(v / leaf) by multiply-shift for one leaf (verified over every int16 coordinate) + the bits one axis takes.
+// The constants of floor(v / leaf) + bias for one leaf (pcs_voxel_agg.h: VoxelDiv) + the bits one axis takes.
 hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
 {
     if (leaf_mm < 1 || leaf_mm > 32767) return hipErrorInvalidValue;
     bits = axis_bits(leaf_mm);
-    const unsigned int bias = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm;
-    dv = VoxelDiv{(unsigned)leaf_mm, bias * (unsigned)leaf_mm, 0u};
-    // floor(u / leaf) == umulhi(u, magic) for every biased coordinate u = v + bias*leaf, v in [-32768, 32767]:
-    // verified here over all 65 536 of them (once per leaf per host thread). leaf 1 has no 32-bit magic: magic = 0 makes
-    // the kernels pass u through. A failed check (impossible by the bound in pcs_voxel_agg.h) refuses the call.
+    const unsigned int bias_leaf = (32768u + (unsigned)leaf_mm - 1u) / (unsigned)leaf_mm * (unsigned)leaf_mm;
+    dv = VoxelDiv{(float)(1.0 / leaf_mm), (float)(((double)bias_leaf + 0.5) / leaf_mm)};
+    // (unsigned)fmaf(v, inv, c) == floor((v + bias * leaf) / leaf) for every int16 v: proven by the bound in pcs_voxel_agg.h,
+    // tested over all leaves (tests/test_voxel_grid.py), and re-checked here with the host's fmaf — the same single rounding
+    // as the device's v_fma_f32 — over the 65 536 values of the leaf in use (once per leaf per host thread). A failed check
+    // (impossible by the bound) refuses the call.
     thread_local int cached_leaf = 0;
-    thread_local unsigned int cached_magic = 0;
     thread_local bool cached_ok = false;
     if (cached_leaf != leaf_mm) {
-        const unsigned long long magic = leaf_mm == 1 ? 0ull : ((1ull << 32) + (unsigned)leaf_mm - 1) / (unsigned)leaf_mm;
-        bool ok = magic < (1ull << 32);
-        const unsigned int lo = dv.bias_leaf - 32768u, hi = dv.bias_leaf + 32767u;
-        for (unsigned int u = lo; ok && u <= hi; u++)
-            ok = (unsigned int)(((unsigned long long)u * magic) >> 32) + (magic ? 0u : u) == u / (unsigned)leaf_mm;
+        bool ok = true;
+        for (int v = -32768; ok && v <= 32767; v++)
+            ok = (unsigned int)std::fmaf((float)v, dv.inv, dv.c) == (unsigned int)(v + (int)bias_leaf) / (unsigned)leaf_mm;
         cached_leaf = leaf_mm;
-        cached_magic = (unsigned int)magic;
         cached_ok = ok;
     }
-    if (!cached_ok) return hipErrorInvalidValue;
-    dv.magic = cached_magic;
-    return hipSuccess;
+    return cached_ok ? hipSuccess : hipErrorInvalidValue;
 }
 
 // Carves the workspace and derives the key layout for a cloud of at most n_points points.
@@ -927,7 +923,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
         // 16-byte aligned payload: the reader that shares its table code with the raster reader (pcs_kernels.hip)
         VoxelStage vs{};
         vs.keys = w.keys_a; vs.idx = w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
-        vs.leaf = pl.dv.leaf; vs.bias_leaf = pl.dv.bias_leaf; vs.magic = pl.dv.magic; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
+        vs.leaf = (uint32_t)leaf_mm; vs.div_inv = pl.dv.inv; vs.div_c = pl.dv.c; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
         vs.track_bits = pl.track_bits ? 1u : 0u;
         e = launch_payload_voxel_partials(d_payload, n_points, d_n_points, vs, st);
         if (e != hipSuccess) return e;
@@ -954,7 +950,7 @@ hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t
     e = hipMemsetAsync(pl.w.ctl, 0, 64 * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
     stage->keys = pl.w.keys_a; stage->idx = pl.w.idx_a; stage->part = pl.w.part; stage->n_runs = pl.w.ctl;
-    stage->leaf = pl.dv.leaf; stage->bias_leaf = pl.dv.bias_leaf; stage->magic = pl.dv.magic;
+    stage->leaf = (uint32_t)leaf_mm; stage->div_inv = pl.dv.inv; stage->div_c = pl.dv.c;
     stage->bits = pl.bits; stage->idx_bits = pl.idx_bits;
     stage->track_bits = pl.track_bits ? 1u : 0u;
     return hipSuccess;
@@ -982,7 +978,7 @@ hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d
     e = hipMemsetAsync(d_ctl, 0, 64 * sizeof(unsigned int), st);
     if (e != hipSuccess) return e;
     stage->keys = d_keys; stage->idx = nullptr; stage->part = d_partials; stage->n_runs = d_ctl;
-    stage->leaf = dv.leaf; stage->bias_leaf = dv.bias_leaf; stage->magic = dv.magic;
+    stage->leaf = (uint32_t)leaf_mm; stage->div_inv = dv.inv; stage->div_c = dv.c;
     stage->bits = bits; stage->idx_bits = 0u; stage->track_bits = 0u;
     return hipSuccess;
 }

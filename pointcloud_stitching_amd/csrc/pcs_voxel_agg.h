@@ -19,25 +19,24 @@ inline unsigned int axis_bits(int leaf)
     return b;
 }
 
-// floor(v / leaf) + bias, bias = ceil(32768 / leaf): the biased numerator u = v + bias*leaf is in [0, 2^17), and
-// floor(u / leaf) == (u * magic) >> 32 with magic = ceil(2^32 / leaf): the error magic*leaf - 2^32 is below leaf <= 2^15,
-// so u * error < 2^32 for every u < 2^17 (the host still checks all 65 536 of them before the launch). leaf = 1 has no
-// 32-bit magic: magic = 0 and the quotient is u itself (`pass` = all ones). No branch: a (uniform) test per division put
-// three branches and a 13-instruction divide into every point of the unrolled loops.
+// floor(v / leaf) + bias, bias = ceil(32768 / leaf), in THREE full-rate instructions: convert, fused multiply-add, truncate —
+//     k = (unsigned)fmaf((float)v, inv, c),   inv = fl(1 / leaf),   c = fl((bias * leaf + 0.5) / leaf).
+// The exact value t = (v + 0.5) / leaf + bias is positive and never closer than 0.5 / leaf to an integer, while the
+// float result is off by less than 0.008 / leaf (|v| * ulp(inv)/2 + ulp(c)/2 + ulp(t)/2 with t < 2^17 / leaf), so the
+// truncation is floor(v / leaf) + bias for every int16 v and every leaf in 1 .. 32767 (tested exhaustively over all
+// 2^31 pairs; the host re-checks the 65 536 values of the leaf in use before a launch, pcs_voxel.hip: div_for).
+// (Rounds 1-3 used umulhi(v + bias * leaf, ceil(2^32 / leaf)): v_mul_hi_u32 issues at a quarter of the rate, and the
+// pre-aggregation is VALU-bound — three of them per point were 9 % of its cycles.)
 struct VoxelDiv {
-    unsigned int leaf, bias_leaf, magic;
-    __device__ __forceinline__ unsigned int operator()(int v) const
-    {
-        const unsigned int u = (unsigned int)(v + (int)bias_leaf);
-        const unsigned int pass = magic ? 0u : ~0u;          // uniform: an SGPR select, hoisted out of the loops
-        return __umulhi(u, magic) + (u & pass);
-    }
+    float inv, c;
+    __device__ __forceinline__ unsigned int operator()(int v) const { return (unsigned int)__builtin_fmaf((float)v, inv, c); }
 };
 
 __device__ __forceinline__ unsigned long long voxel_key(const VoxelDiv& dv, int x, int y, int z, unsigned int bits)
 {
-    const unsigned long long kx = dv(x), ky = dv(y), kz = dv(z);
-    return (kz << (2 * bits)) | (ky << bits) | kx;      // z major, x fastest: (z,y,x) voxel order
+    // z major, x fastest: (z,y,x) voxel order. bits <= 16, so the x and y fields share one 32-bit word.
+    const unsigned int xy = dv(x) | (dv(y) << bits);
+    return ((unsigned long long)dv(z) << (2u * bits)) | xy;
 }
 
 // LDS hash table of one pre-aggregation workgroup
@@ -47,16 +46,19 @@ constexpr int kSlots = 2048, kProbe = 12;
 constexpr unsigned int kVoxCtlOr = 32, kVoxCtlOrn = 34;
 constexpr unsigned long long kEmptyKey = ~0ull;
 
-// Probe sequence of a key: double hashing (start and an odd stride from two multiplicative hashes), so a crowded table
+// Probe sequence of a key: double hashing (start and an odd stride from one multiplicative hash), so a crowded table
 // costs 1/(1 - load) probes on average instead of linear probing's clusters — at 2/3 load a key fails to find a slot
-// within kProbe probes 1 time in 100, not 1 in 4.
+// within kProbe probes 1 time in 100, not 1 in 4. The hash multiplies the key's two 24-bit halves (3 * bits <= 48) by odd
+// 24-bit constants with v_mul_u32_u24 / v_mad_u32_u24 (full rate; the 64-bit multiply of rounds 1-3 was three
+// quarter-rate instructions per run) and takes the TOP bits of the low word, which depend on every input bit.
 struct VoxelProbe {
     unsigned int first, step;
     __device__ __forceinline__ explicit VoxelProbe(unsigned long long key)
     {
-        const unsigned long long m = key * 0x9E3779B97F4A7C15ull;
-        first = (unsigned int)(m >> 53);                                   // 11 bits
-        step = ((unsigned int)(m >> 42) & (unsigned)(kSlots - 1)) | 1u;    // odd: visits every slot of the 2^11 table
+        const unsigned int lo = (unsigned int)key, hi = (unsigned int)(key >> 32);
+        const unsigned int m = __umul24(lo, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbit(hi, lo, 24), 0x85EBCBu);
+        first = m >> 21;                                                   // 11 bits
+        step = ((m >> 10) & (unsigned)(kSlots - 1)) | 1u;                  // odd: visits every slot of the 2^11 table
     }
     __device__ __forceinline__ unsigned int next(unsigned int h) const { return (h + step) & (unsigned)(kSlots - 1); }
 };
