@@ -83,6 +83,7 @@ struct pcs_ctx {
     float*                          s_vertices = nullptr; size_t s_vertices_cap = 0;
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
     void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
+    VoxelWsState                    vox_state;          // which control block of s_voxel_ws the next voxel call uses
     unsigned int*                   d_vox_ctl = nullptr;       // 64 words: control block of pcs_process_frames_voxel_partials_device
     int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
     int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
@@ -1465,10 +1466,13 @@ static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_po
                     out_shorts, (size_t)n_points * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
     const size_t need = voxel_workspace_bytes((uint32_t)n_points);
-    if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
+    if (need > c->s_voxel_ws_cap) {                                               // the old workspace may be in use
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->vox_state.clean = false;                                               // (a new one may land on the same address)
+    }
     int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
     if (rc) return rc;
-    HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, d_n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out,
+    HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, d_n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out,
                                 d_out_points, c->stream));
     return PCS_OK;
 }
@@ -1521,7 +1525,10 @@ try {
         return voxel_grid_device_impl(c, c->s_payload, (int)cap, c->d_counts + S, leaf_mm, d_out, out_shorts, d_out_points);
     }
     const size_t need = voxel_workspace_bytes((uint32_t)cap);
-    if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
+    if (need > c->s_voxel_ws_cap) {                                               // the old workspace may be in use
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->vox_state.clean = false;                                               // (a new one may land on the same address)
+    }
     int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
     if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev{};
@@ -1531,7 +1538,7 @@ try {
         HIPCHK(c, hipEventRecord(ev.first, c->stream));
     }
     VoxelStage vs{};
-    HIPCHK(c, voxel_begin((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &vs, c->stream));
+    HIPCHK(c, voxel_begin((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, &vs, c->stream));
     for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
         const int nl = std::min(kLaunchStreams, S - s0);
         FramePtrs fp{};
@@ -1548,7 +1555,7 @@ try {
         const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
         HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
     }
-    HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out, d_out_points, c->stream));
+    HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
     if (c->kernel_timing) {
         HIPCHK(c, hipEventRecord(ev.second, c->stream));
         c->ev_pool.push_back(ev);
@@ -1632,11 +1639,14 @@ int pcs_voxel_grid_from_partials_device(pcs_ctx* c, const uint64_t* d_keys, cons
                     out_shorts, (size_t)n_partials * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
     const size_t need = voxel_workspace_bytes((uint32_t)n_partials);
-    if (need > c->s_voxel_ws_cap) HIPCHK(c, hipStreamSynchronize(c->stream));     // the old workspace may be in use
+    if (need > c->s_voxel_ws_cap) {                                               // the old workspace may be in use
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->vox_state.clean = false;                                               // (a new one may land on the same address)
+    }
     int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
     if (rc) return rc;
     HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,
-                                         d_n_partials, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, d_out, d_out_points, c->stream));
+                                         d_n_partials, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
     return PCS_OK;
 }
 

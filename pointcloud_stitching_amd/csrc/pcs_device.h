@@ -163,8 +163,15 @@ hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n
 
 // Voxel-grid downsample (pcs_voxel.hip).
 size_t     voxel_workspace_bytes(uint32_t n_points);
+// What the owner of a voxel workspace keeps between calls (pcs_voxel.hip: plan_for): which of the workspace's two control
+// blocks the next call uses, and whether both are known to be in the state that call expects.
+struct VoxelWsState {
+    const void* base = nullptr;
+    uint32_t    phase = 0;
+    bool        clean = false;
+};
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
-                             size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st);
+                             size_t ws_bytes, VoxelWsState* ws, int16_t* d_out, int32_t* d_out_points, hipStream_t st);
 
 // The same pipeline fed from the rasters (pcs_process_frames_voxel_device): voxel_begin carves the workspace and clears
 // the counters, launch_fused_voxel_partials (pcs_kernels.hip) appends the partials, voxel_finish sorts and reduces.
@@ -177,8 +184,9 @@ struct VoxelStage {
     float               div_inv, div_c;   // voxel index of a coordinate: (unsigned)fmaf(v, div_inv, div_c) (pcs_voxel_agg.h: VoxelDiv)
     uint32_t            track_bits;    // record which key bits vary (the sort may then skip a pass); 0: the host declared all of them varying
 };
-hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st);
-hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
+hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws, VoxelStage* stage,
+                       hipStream_t st);
+hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws, int16_t* d_out,
                         int32_t* d_out_points, hipStream_t st);
 // Partials as an exchange format (multi-GPU config 5): a stage that appends (raw voxel key, sums) to caller arrays
 // (d_ctl: 64 words, [0] = partials appended), and the sort + segmented mean over caller-held partials from any number of
@@ -186,8 +194,8 @@ hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_
 hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_ctl, VoxelStage* stage,
                                 hipStream_t st);
 hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const void* d_partials, uint32_t n_partials,
-                                      const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
-                                      int32_t* d_out_points, hipStream_t st);
+                                      const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws,
+                                      int16_t* d_out, int32_t* d_out_points, hipStream_t st);
 // the same table fed from a 16-byte aligned payload (pcs_kernels.hip; the unaligned forms stay in pcs_voxel.hip)
 hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points,
                                          const VoxelStage& vs, hipStream_t st);

@@ -444,6 +444,10 @@ void pcs_voxel_colscan_kernel(unsigned int* __restrict__ table, const unsigned i
 //               + this digit in earlier wavefronts of the chunk + in earlier rounds of this wavefront + in lower lanes.
 // The last three come from per-(wavefront, digit) LDS counters: counted first (LDS adds), turned into starting offsets,
 // then advanced round by round by the lowest lane of each group of equal digits (found with 11 ballots).
+// ONE trip to memory per chunk: a lane requests its (at most 16) elements, its four digit totals and its four entries of
+// the chunk's table row together and keeps all of them in registers — the elements are counted and later placed from
+// there. (Rounds 2-3 read the totals, the elements, the table row and the elements again one after the other: four
+// dependent round trips of ~2 us each in a workgroup that runs alone on its CU.)
 // PACKED: the element is (key << idx_bits) | partial index in ONE 64-bit word (possible when 3*bits + idx_bits <= 64, i.e.
 // for every leaf >= 8 mm on the 30 M-point cloud): one 8-byte scattered store per element instead of 8 + 4, and no
 // index arrays at all.
@@ -456,7 +460,6 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
                               const unsigned int* __restrict__ digit_total)
 {
     __shared__ unsigned int cnt[kSortWaves][kRadix];      // 64 KiB
-    __shared__ unsigned int dbase[kRadix];       //  8 KiB
     __shared__ unsigned int wsum[kSortWaves];
     const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
     if (sp.skip) return;
@@ -469,65 +472,69 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
     const unsigned int chunks = (m + csize - 1) / csize;
     if (blockIdx.x >= chunks) return;
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    constexpr unsigned int kPer = kRadix / kSortThreads;      // 4 consecutive digits per thread
+    constexpr unsigned int kPer = kRadix / kSortThreads;      // 4 consecutive digits per thread, the same four throughout
+    constexpr unsigned int kMaxRounds = kSortChunk / kSortWaves / 64;      // 16
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(kPer == 4, "a thread's digits travel as one 16-byte vector");
+    const unsigned int kRounds = csize / kSortWaves / 64;                  // 2 .. 16
 
-    {   // digit bases: exclusive scan of the 2048 digit totals
-        unsigned int v[kPer], s = 0;
-#pragma unroll
-        for (unsigned int j = 0; j < kPer; j++) { v[j] = digit_total[threadIdx.x * kPer + j]; s += v[j]; }
-        const unsigned int inc = wave_incl_scan(s);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned int run = inc - s;
-        for (unsigned int w = 0; w < wave; w++) run += wsum[w];
-#pragma unroll
-        for (unsigned int j = 0; j < kPer; j++) { dbase[threadIdx.x * kPer + j] = run; run += v[j]; }
-        __syncthreads();
-    }
+    const u32x4 tot4 = *reinterpret_cast<const u32x4*>(digit_total + threadIdx.x * kPer);
+    unsigned int dbase[kPer];
+    bool have_base = false;
 
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        for (unsigned int j = threadIdx.x; j < kSortWaves * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
-        __syncthreads();
         const unsigned int w0 = chunk * csize + wave * (csize / kSortWaves);
         const unsigned int w1 = min(w0 + csize / kSortWaves, m);               // this wavefront's elements: [w0, w1)
+        // everything this chunk needs from memory, requested at once
+        unsigned long long k[kMaxRounds];
+        unsigned int id[PACKED ? 1 : kMaxRounds];
+#pragma unroll
+        for (unsigned int r = 0; r < kMaxRounds; r++) {
+            const unsigned int e = w0 + r * 64 + lane;
+            k[r] = 0ull;
+            if (!PACKED) id[r] = 0u;
+            if (r < kRounds && e < w1) { k[r] = keys_in[e]; if (!PACKED) id[r] = idx_in[e]; }
+        }
+        const u32x4 row4 = *reinterpret_cast<const u32x4*>(table + (size_t)chunk * kRadix + threadIdx.x * kPer);
+        for (unsigned int j = threadIdx.x; j < kSortWaves * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
+        __syncthreads();
         // count: this wavefront's occurrences of every digit
-        const unsigned int kRounds = csize / kSortWaves / 64;                  // 2 .. 16
-        for (unsigned int r0 = 0; r0 < kRounds; r0 += kSortBatch) {
-            unsigned long long k[kSortBatch];
 #pragma unroll
-            for (unsigned int q = 0; q < kSortBatch; q++) {
-                const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                k[q] = e < w1 ? keys_in[e] : 0ull;
-            }
-#pragma unroll
-            for (unsigned int q = 0; q < kSortBatch; q++) {
-                const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                if (e < w1) atomicAdd(&cnt[wave][sp.digit(k[q])], 1u);
-            }
+        for (unsigned int r = 0; r < kMaxRounds; r++) {
+            const unsigned int e = w0 + r * 64 + lane;
+            if (r < kRounds && e < w1) atomicAdd(&cnt[wave][sp.digit(k[r])], 1u);
         }
-        __syncthreads();
+        if (!have_base) {   // digit bases: exclusive scan of the 2048 digit totals (once per workgroup)
+            const unsigned int s4 = tot4.x + tot4.y + tot4.z + tot4.w;
+            const unsigned int inc = wave_incl_scan(s4);
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            unsigned int run = inc - s4;
+            for (unsigned int w = 0; w < wave; w++) run += wsum[w];
+            dbase[0] = run; dbase[1] = run + tot4.x; dbase[2] = dbase[1] + tot4.y; dbase[3] = dbase[2] + tot4.z;
+            have_base = true;
+        } else {
+            __syncthreads();
+        }
         // starting offsets per (wavefront, digit)
-        for (unsigned int j = threadIdx.x; j < kRadix; j += kSortThreads) {
-            unsigned int start = dbase[j] + table[(size_t)chunk * kRadix + j];
+        {
+            const unsigned int row[kPer] = {row4.x, row4.y, row4.z, row4.w};
 #pragma unroll
-            for (unsigned int w = 0; w < kSortWaves; w++) { const unsigned int c = cnt[w][j]; cnt[w][j] = start; start += c; }
+            for (unsigned int j = 0; j < kPer; j++) {
+                const unsigned int d = threadIdx.x * kPer + j;
+                unsigned int start = dbase[j] + row[j];
+#pragma unroll
+                for (unsigned int w = 0; w < kSortWaves; w++) { const unsigned int c = cnt[w][d]; cnt[w][d] = start; start += c; }
+            }
         }
         __syncthreads();
-        // place: one round of 64 elements at a time, in order (the loads of a batch of rounds go out together)
-        for (unsigned int r0 = 0; r0 < kRounds; r0 += kSortBatch) {
-            unsigned long long k[kSortBatch];
-            unsigned int id[kSortBatch];
+        // place: one round of 64 elements at a time, in order, from the registers
 #pragma unroll
-            for (unsigned int q = 0; q < kSortBatch; q++) {
-                const unsigned int e = w0 + (r0 + q) * 64 + lane;
-                k[q] = 0ull; id[q] = 0u;
-                if (e < w1) { k[q] = keys_in[e]; if (!PACKED) id[q] = idx_in[e]; }
-            }
-#pragma unroll
-            for (unsigned int q = 0; q < kSortBatch; q++) {
-                const unsigned int e = w0 + (r0 + q) * 64 + lane;
+        for (unsigned int r = 0; r < kMaxRounds; r++) {
+            if (r < kRounds) {                                                  // uniform
+                const unsigned int e = w0 + r * 64 + lane;
                 const bool live = e < w1;
-                const unsigned int d = sp.digit(k[q]);
+                const unsigned int d = sp.digit(k[r]);
                 unsigned long long peers = __ballot(live);
 #pragma unroll
                 for (int b = 0; b < kRadixBits; b++) {
@@ -540,8 +547,8 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
                     const unsigned int start = cnt[wave][d];
                     if (below == 0) cnt[wave][d] = start + __popcll(peers);       // the group's lowest lane advances the counter
                     const unsigned int dst = start + below;
-                    keys_out[dst] = k[q];
-                    if (!PACKED) idx_out[dst] = id[q];
+                    keys_out[dst] = k[r];
+                    if (!PACKED) idx_out[dst] = id[r];
                 }
             }
         }
@@ -555,9 +562,12 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
 //    carries). A run that lies inside one block of 256 sorted elements — almost all of them — is finished there.
 //    Pieces of runs that cross block boundaries are left per block as {lead: the part of a run begun earlier, trail:
 //    the open run at the block's end}; a second, tiny kernel adds trail[b] + lead[b+1] + ... and writes those voxels.
+//    (Tried in round 3: the block a run STARTS in reading on past its end with all its lanes, so that the second kernel
+//    disappears — every third block then pays two more dependent round trips: reduce 18.6 -> 29 us for the 5 us saved.)
 //    No lane ever walks a run serially (the first version did: 231 us at 50 mm, most lanes idle, the rest latency-bound).
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned int kSegThreads = 256, kSegGrid = 4096;
+constexpr unsigned int kCtlWords = 64;                            // one call's control block
 
 // heads[b] = runs that START in block b (block = 256 consecutive sorted elements)
 __global__ __launch_bounds__(kSegThreads)
@@ -580,11 +590,17 @@ void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys_a, const
     }
 }
 
-// exclusive scan of heads[] (in place) by one workgroup, four entries per lane; the total is the number of voxels
+// exclusive scan of heads[] (in place) by one workgroup, four entries per lane; the total is the number of voxels.
+// zero_next: the control words of the NEXT call on this workspace (plan_for), cleared here so that no call needs a memset
+// launch of its own.
+// (Round 3 also tried heads + scan as ONE launch — fat workgroups, a release fence, a ticket, the last one scans: the fence
+// is an L2 write-back, and right after a scatter pass the L2s hold megabytes of dirty keys: 32 - 39 us instead of 5 + 5.)
 __global__ __launch_bounds__(1024)
 void pcs_voxel_blockscan_kernel(unsigned int* __restrict__ heads, const unsigned int* __restrict__ m_ptr,
-                                unsigned int* __restrict__ n_voxels, int32_t* __restrict__ out_points)
+                                unsigned int* __restrict__ n_voxels, int32_t* __restrict__ out_points,
+                                unsigned int* __restrict__ zero_next)
 {
+    if (zero_next && threadIdx.x < kCtlWords) zero_next[threadIdx.x] = 0u;
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int carry_s;
     const unsigned int m = *m_ptr;
@@ -615,8 +631,8 @@ void pcs_voxel_blockscan_kernel(unsigned int* __restrict__ heads, const unsigned
     }
 }
 
-// Sums of a piece of a run inside one block: 256 partials of <= 8192 points each -> the colour sums and the count fit
-// 32 bits, the coordinate sums need 64.
+// Sums of a piece of a run inside one block: 256 partials of <= 32 768 points each -> the colour sums (< 2^31) and the
+// count fit 32 bits, the coordinate sums need 64.
 struct SegSum {
     long long x, y, z;
     unsigned int r, g, b, n;
@@ -769,8 +785,10 @@ struct Workspace {
     unsigned long long *keys_a, *keys_b;
     unsigned int *idx_a, *idx_b;
     VoxelPartial* part;
-    unsigned int *table, *digit_total, *heads, *ctl;      // ctl[0] = m (partials), ctl[1] = voxels
+    unsigned int *table, *digit_total, *heads;
     BlockPiece *lead, *trail;
+    unsigned int *ctl, *ctl_next;       // this call's control words (ctl[0] = m partials, [1] = voxels, [32..35] key
+                                        // bits) and the block the NEXT call on this workspace will use: see plan_for
     size_t bytes;
 };
 
@@ -779,6 +797,8 @@ inline Workspace carve(uint8_t* base, size_t n)
     Workspace w{};
     uint8_t* p = base;
     auto take = [&](size_t bytes) { uint8_t* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    w.ctl = (unsigned int*)take(2 * kCtlWords * sizeof(unsigned int));      // first: where they are must not depend on n
+    w.ctl_next = w.ctl + kCtlWords;
     w.keys_a = (unsigned long long*)take(n * 8);
     w.keys_b = (unsigned long long*)take(n * 8);
     w.idx_a = (unsigned int*)take(n * 4);
@@ -792,7 +812,6 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.heads = (unsigned int*)take(((n + kSegThreads - 1) / kSegThreads) * 4);
     w.lead = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
     w.trail = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
-    w.ctl = (unsigned int*)take(256);
     w.bytes = (size_t)(p - base);
     return w;
 }
@@ -835,12 +854,24 @@ hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
 }
 
 // Carves the workspace and derives the key layout for a cloud of at most n_points points.
-hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes, Plan& pl)
+// The control words: a call needs 64 zeroed words (counters, tickets, key bits). Instead of a memset launch per call — 5 us
+// of dependent-dispatch floor — the workspace holds TWO blocks at its start; call k uses block k & 1 and its block-scan kernel
+// clears the other one for call k + 1 (nothing of call k touches that block; call k - 1, which used it, is behind on the
+// stream). `ws` remembers the parity; a workspace it has not seen, or one whose last call may not have been enqueued
+// completely (ws.clean == false), gets both blocks cleared by a memset first.
+hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState& ws, Plan& pl, hipStream_t st)
 {
     if (ws_bytes < voxel_workspace_bytes(n_points)) return hipErrorInvalidValue;
     uint8_t* base = static_cast<uint8_t*>(d_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
     pl.w = carve(base, n_points);
+    if (!ws.clean || ws.base != d_ws) {
+        ws.clean = false;
+        const hipError_t e = hipMemsetAsync(pl.w.ctl, 0, 2 * kCtlWords * sizeof(unsigned int), st);
+        if (e != hipSuccess) return e;
+        ws.base = d_ws; ws.phase = 0; ws.clean = true;
+    }
+    if (ws.phase & 1u) std::swap(pl.w.ctl, pl.w.ctl_next);
     {
         const hipError_t e = div_for(leaf_mm, pl.dv, pl.bits);
         if (e != hipSuccess) return e;
@@ -870,7 +901,6 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     const unsigned int idx_bits = pl.idx_bits;
     const unsigned int n_passes = (3u * pl.bits + kRadixBits - 1u) / kRadixBits;  // the device may skip the first few (SortPass)
     const unsigned int bits = pl.bits | (pl.track_bits ? kTrackFlag : 0u);         // what the kernels get: width + tracking flag
-    const unsigned int* m_ptr = w.ctl;
 
     // grids sized for what the launch can need at most, capped: the kernels loop over chunks / blocks
     const unsigned int max_chunks = std::max((n_points + kSortChunk - 1) / kSortChunk,
@@ -890,12 +920,21 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
     const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
     hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits, w.heads);
-    hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, m_ptr, w.ctl + 1, d_out_points);
+    hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, w.ctl, w.ctl + 1, d_out_points, w.ctl_next);
     hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.idx_a, w.keys_b, w.idx_b, w.part,
                        w.ctl, bits, idx_bits, w.heads, d_out, w.lead, w.trail);
     const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
-    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, m_ptr, w.lead, w.trail, d_out);
+    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, w.ctl, w.lead, w.trail, d_out);
     return hipGetLastError();
+}
+
+// A call that was enqueued completely hands the other control block to the next one; anything else leaves the workspace
+// to be cleared again.
+hipError_t finish_call(VoxelWsState& ws, hipError_t e)
+{
+    if (e == hipSuccess) ws.phase++;
+    else ws.clean = false;
+    return e;
 }
 
 }  // namespace
@@ -903,18 +942,16 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
 // d_n_points != nullptr: the number of points is read from device memory (<= n_points, which then is the capacity that
 // sizes the workspace and the grids)
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
-                             size_t ws_bytes, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
+                             size_t ws_bytes, VoxelWsState* ws, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
 {
     if (n_points == 0) {
         if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
         return hipSuccess;
     }
     Plan pl;
-    hipError_t e = plan_for(n_points, leaf_mm, d_ws, ws_bytes, pl);
+    hipError_t e = plan_for(n_points, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
     if (e != hipSuccess) return e;
     const Workspace& w = pl.w;
-    e = hipMemsetAsync(w.ctl, 0, 64 * sizeof(unsigned int), st);     // m, voxels, ...; second line: OR and OR-of-complements of the keys
-    if (e != hipSuccess) return e;
     const unsigned int per_block = (unsigned)kAggThreads * (unsigned)kAggPerLane;
     const dim3 agg_grid((n_points + per_block - 1) / per_block);
     static const int wide_ok = [] { const char* v = getenv("PCS_VOXEL_WIDE"); return v ? atoi(v) : 1; }();
@@ -926,7 +963,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
         vs.leaf = (uint32_t)leaf_mm; vs.div_inv = pl.dv.inv; vs.div_c = pl.dv.c; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
         vs.track_bits = pl.track_bits ? 1u : 0u;
         e = launch_payload_voxel_partials(d_payload, n_points, d_n_points, vs, st);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) return finish_call(*ws, e);
     } else {
         // the 1024-lane readers (payloads that are only 2- or 4-byte aligned) do not record which key bits vary: every bit
         // counts, no pass is skipped
@@ -938,17 +975,17 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
             hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv,
                                pl.bits, pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
     }
-    return sort_and_reduce(pl, n_points, d_out, d_out_points, st);
+    return finish_call(*ws, sort_and_reduce(pl, n_points, d_out, d_out_points, st));
 }
 
 // Raster source (pcs_kernels.hip: launch_fused_voxel_partials fills the stage between these two calls).
-hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelStage* stage, hipStream_t st)
+hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws, VoxelStage* stage,
+                       hipStream_t st)
 {
     Plan pl;
-    hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, pl);
+    hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(pl.w.ctl, 0, 64 * sizeof(unsigned int), st);
-    if (e != hipSuccess) return e;
+    ws->clean = false;                    // until voxel_finish has enqueued the kernel that clears the other block
     stage->keys = pl.w.keys_a; stage->idx = pl.w.idx_a; stage->part = pl.w.part; stage->n_runs = pl.w.ctl;
     stage->leaf = (uint32_t)leaf_mm; stage->div_inv = pl.dv.inv; stage->div_c = pl.dv.c;
     stage->bits = pl.bits; stage->idx_bits = pl.idx_bits;
@@ -956,13 +993,15 @@ hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t
     return hipSuccess;
 }
 
-hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out, int32_t* d_out_points,
-                        hipStream_t st)
+hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws, int16_t* d_out,
+                        int32_t* d_out_points, hipStream_t st)
 {
+    if (ws->base != d_ws) return hipErrorInvalidValue;          // not the workspace voxel_begin prepared
+    ws->clean = true;                                           // (voxel_begin's plan, again: same parity, no memset)
     Plan pl;
-    hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, pl);
-    if (e != hipSuccess) return e;
-    return sort_and_reduce(pl, capacity_points, d_out, d_out_points, st);
+    hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
+    if (e != hipSuccess) return finish_call(*ws, e);
+    return finish_call(*ws, sort_and_reduce(pl, capacity_points, d_out, d_out_points, st));
 }
 
 // ---- partials as an exchange format (multi-GPU config 5) -----------------------------------------------------------------
@@ -985,24 +1024,22 @@ hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d
 
 // Sort + segmented mean over n_partials (or *d_n_partials, at most n_partials) caller-held partials with raw keys.
 hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const void* d_partials, uint32_t n_partials,
-                                      const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, int16_t* d_out,
-                                      int32_t* d_out_points, hipStream_t st)
+                                      const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws,
+                                      int16_t* d_out, int32_t* d_out_points, hipStream_t st)
 {
     if (n_partials == 0) {
         if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
         return hipSuccess;
     }
     Plan pl;
-    hipError_t e = plan_for(n_partials, leaf_mm, d_ws, ws_bytes, pl);
+    hipError_t e = plan_for(n_partials, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
     if (e != hipSuccess) return e;
     pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
     pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place
-    e = hipMemsetAsync(pl.w.ctl, 0, 64 * sizeof(unsigned int), st);
-    if (e != hipSuccess) return e;
     const unsigned int grid = std::min<unsigned int>((n_partials + 255u) / 256u, 2048u);
     hipLaunchKernelGGL(pcs_voxel_import_kernel, dim3(grid), dim3(256), 0, st, d_keys, n_partials, d_n_partials, n_partials,
                        pl.idx_bits, pl.w.keys_a, pl.w.idx_a, pl.w.ctl);
-    return sort_and_reduce(pl, n_partials, d_out, d_out_points, st);
+    return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st));
 }
 
 }  // namespace pcs
