@@ -84,7 +84,6 @@ struct pcs_ctx {
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
     void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
     VoxelWsState                    vox_state;          // which control block of s_voxel_ws the next voxel call uses
-    unsigned int*                   d_vox_ctl = nullptr;       // 64 words: control block of pcs_process_frames_voxel_partials_device
     int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
     int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
     uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
@@ -773,7 +772,7 @@ void pcs_destroy(pcs_ctx* c)
     }
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     void* singles[] = {c->d_params, c->d_tile_counts, c->d_tile_prefix, c->d_stream_base, c->d_counts, c->s_payload,
-                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->d_batch_scratch, c->d_vox_ctl, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
+                       c->d_ticket, c->d_desc, c->d_stream_end, c->d_error, c->d_arrive, c->d_static_counts, c->d_batch_scratch, c->s_voxel_ws, c->s_voxel_in, c->s_voxel_out,
                        c->s_vertices, c->s_texcoords, c->s_pack_counts, c->s_pack_prefix};
     for (void* p : singles) if (p) (void)hipFree(p);
     for (auto& pr : c->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1585,10 +1584,11 @@ try {
         return fail(c, PCS_ERR_CAPACITY, "partial arrays hold %zu entries; the worst case (every kept point its own partial) needs %zu",
                     capacity, cap);
     DeviceGuard guard(c->device);
-    if (!c->d_vox_ctl) HIPCHK(c, hipMalloc((void**)&c->d_vox_ctl, 64 * sizeof(unsigned int)));
     static_assert(sizeof(pcs_voxel_partial) == 32, "pcs_voxel_partial is the kernels' 32-byte VoxelPartial");
+    // the caller's count word IS the append counter of the pre-aggregation (cleared here, complete when the kernels are)
     VoxelStage vs{};
-    HIPCHK(c, voxel_partials_stage(leaf_mm, reinterpret_cast<unsigned long long*>(d_keys), d_partials, c->d_vox_ctl, &vs, c->stream));
+    HIPCHK(c, voxel_partials_stage(leaf_mm, reinterpret_cast<unsigned long long*>(d_keys), d_partials,
+                                   reinterpret_cast<unsigned int*>(d_n_partials), &vs, c->stream));
     static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
     bool all_patch = true;
     for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
@@ -1618,7 +1618,6 @@ try {
             HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
         }
     }
-    HIPCHK(c, hipMemcpyAsync(d_n_partials, c->d_vox_ctl, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_partials_device: host allocation failed (%s)", ex.what());

@@ -189,9 +189,9 @@ hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t
 hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws, int16_t* d_out,
                         int32_t* d_out_points, hipStream_t st);
 // Partials as an exchange format (multi-GPU config 5): a stage that appends (raw voxel key, sums) to caller arrays
-// (d_ctl: 64 words, [0] = partials appended), and the sort + segmented mean over caller-held partials from any number of
+// (d_count: one word = partials appended), and the sort + segmented mean over caller-held partials from any number of
 // such stages (same leaf).
-hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_ctl, VoxelStage* stage,
+hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_count, VoxelStage* stage,
                                 hipStream_t st);
 hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const void* d_partials, uint32_t n_partials,
                                       const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws,

@@ -1007,16 +1007,16 @@ hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_
 // ---- partials as an exchange format (multi-GPU config 5) -----------------------------------------------------------------
 // A stage whose partials land in CALLER arrays as (raw key, sums): nothing of the sort's layout (index bits) leaks into them,
 // so partials of several pre-aggregations — other GPUs' — can be concatenated and handed to launch_voxel_from_partials.
-hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_ctl, VoxelStage* stage,
+hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d_partials, unsigned int* d_count, VoxelStage* stage,
                                 hipStream_t st)
 {
     VoxelDiv dv;
     unsigned int bits;
     hipError_t e = div_for(leaf_mm, dv, bits);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(d_ctl, 0, 64 * sizeof(unsigned int), st);
+    e = hipMemsetAsync(d_count, 0, sizeof(unsigned int), st);      // one word: without track_bits the readers touch nothing else
     if (e != hipSuccess) return e;
-    stage->keys = d_keys; stage->idx = nullptr; stage->part = d_partials; stage->n_runs = d_ctl;
+    stage->keys = d_keys; stage->idx = nullptr; stage->part = d_partials; stage->n_runs = d_count;
     stage->leaf = (uint32_t)leaf_mm; stage->div_inv = dv.inv; stage->div_c = dv.c;
     stage->bits = bits; stage->idx_bits = 0u; stage->track_bits = 0u;
     return hipSuccess;

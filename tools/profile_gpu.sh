@@ -41,8 +41,10 @@ for R in dense drop_invalid pack pack_batch batch batch_drop_invalid voxel confi
 done
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_dense_$N -- ${RUNS[dense]} > $OUT/pmc_dense_$N.log 2>&1
-  echo "pmc dense $N rc=$?"
+  for R in dense voxel; do      # the headline kernel (HBM-bound) and the voxel pre-aggregation (VALU-bound)
+    timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${R}_$N -- ${RUNS[$R]} > $OUT/pmc_${R}_$N.log 2>&1
+    echo "pmc $R $N rc=$?"
+  done
 done
 cd - > /dev/null
 python - <<PY
