@@ -260,7 +260,7 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
 //    pre-aggregation left 90 k or 17 M partials and needs no size from the host.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRadixBits = 11, kRadix = 1 << kRadixBits;
-constexpr unsigned int kSortChunk = 8192, kSortThreads = 512, kSortWaves = kSortThreads / 64, kSortGrid = 4096, kSortBatch = 8;
+constexpr unsigned int kSortChunk = 8192, kSortThreads = 512, kSortWaves = kSortThreads / 64, kSortGrid = 512, kSortBatch = 8;
 constexpr unsigned int kSortMinChunk = 1024, kSortMinRows = 256;
 
 // Elements per chunk (= per workgroup pass), chosen ON THE DEVICE from the number of partials so that a small sort still
@@ -459,7 +459,7 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
                               unsigned int n_passes, const unsigned int* __restrict__ table,
                               const unsigned int* __restrict__ digit_total)
 {
-    __shared__ unsigned int cnt[kSortWaves][kRadix];      // 64 KiB
+    __shared__ __attribute__((aligned(16))) unsigned int cnt[kSortWaves][kRadix];      // 64 KiB
     __shared__ unsigned int wsum[kSortWaves];
     const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
     if (sp.skip) return;
@@ -496,7 +496,11 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
             if (r < kRounds && e < w1) { k[r] = keys_in[e]; if (!PACKED) id[r] = idx_in[e]; }
         }
         const u32x4 row4 = *reinterpret_cast<const u32x4*>(table + (size_t)chunk * kRadix + threadIdx.x * kPer);
-        for (unsigned int j = threadIdx.x; j < kSortWaves * kRadix; j += kSortThreads) (&cnt[0][0])[j] = 0u;
+        {   // clear the counters: 16-byte LDS stores, lane-contiguous
+            u32x4* c4 = reinterpret_cast<u32x4*>(&cnt[0][0]);
+#pragma unroll
+            for (unsigned int j = 0; j < kSortWaves * kRadix / 4 / kSortThreads; j++) c4[j * kSortThreads + threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
+        }
         __syncthreads();
         // count: this wavefront's occurrences of every digit
 #pragma unroll
@@ -516,15 +520,15 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
         } else {
             __syncthreads();
         }
-        // starting offsets per (wavefront, digit)
+        // starting offsets per (wavefront, digit): a thread's four digits are one 16-byte LDS word per wavefront row
         {
-            const unsigned int row[kPer] = {row4.x, row4.y, row4.z, row4.w};
+            u32x4 start = u32x4{dbase[0], dbase[1], dbase[2], dbase[3]} + row4;
 #pragma unroll
-            for (unsigned int j = 0; j < kPer; j++) {
-                const unsigned int d = threadIdx.x * kPer + j;
-                unsigned int start = dbase[j] + row[j];
-#pragma unroll
-                for (unsigned int w = 0; w < kSortWaves; w++) { const unsigned int c = cnt[w][d]; cnt[w][d] = start; start += c; }
+            for (unsigned int w = 0; w < kSortWaves; w++) {
+                u32x4* slot = reinterpret_cast<u32x4*>(&cnt[w][threadIdx.x * kPer]);
+                const u32x4 c = *slot;
+                *slot = start;
+                start += c;
             }
         }
         __syncthreads();
@@ -670,16 +674,32 @@ struct BlockPiece {
     unsigned int pad;
 };
 
+// trunc(s / n) for a coordinate sum: |s| < 2^52 and n < 2^32 are exact doubles, the correctly rounded quotient is off by at
+// most 2^-38 (|s / n| <= 32 768) while a quotient that is not an integer is at least 1 / n > 2^-32 away from one, so truncating
+// the double quotient IS the integer division — in ~10 instructions instead of the ~100 of a 64-bit integer divide, six of
+// which per voxel made the reduce kernel VALU-bound (8.3 M wave-instructions: 13.5 of its 18.8 us). Sums that large cannot
+// come out of this library's own pre-aggregation (|s| < 2^44); caller-made partials that exceed the bound take the integer path.
+__device__ __forceinline__ long long div_sum(long long s, unsigned int n)
+{
+    if (__builtin_expect((unsigned long long)(s + (1ll << 52)) >> 53, 0)) return s / (long long)n;
+    return (long long)((double)s / (double)n);
+}
+__device__ __forceinline__ unsigned long long div_sum(unsigned long long s, unsigned int n)
+{
+    if (__builtin_expect(s >> 52, 0)) return s / n;
+    return (unsigned long long)((double)s / (double)n);
+}
+
 __device__ __forceinline__ void write_voxel(int16_t* __restrict__ out, unsigned int ordinal, long long sx, long long sy,
                                             long long sz, unsigned long long r, unsigned long long g, unsigned long long b,
                                             unsigned int n)
 {
     int16_t* o = out + (size_t)ordinal * PCS_POINT_SHORTS;
-    o[0] = (int16_t)(sx / (long long)n);
-    o[1] = (int16_t)(sy / (long long)n);
-    o[2] = (int16_t)(sz / (long long)n);
-    o[3] = (int16_t)(unsigned short)((r / n) | ((g / n) << 8));
-    o[4] = (int16_t)(b / n);
+    o[0] = (int16_t)div_sum(sx, n);
+    o[1] = (int16_t)div_sum(sy, n);
+    o[2] = (int16_t)div_sum(sz, n);
+    o[3] = (int16_t)(unsigned short)(div_sum(r, n) | (div_sum(g, n) << 8));
+    o[4] = (int16_t)div_sum(b, n);
 }
 
 __global__ __launch_bounds__(kSegThreads)

@@ -23,6 +23,8 @@ ctx = PcsContext(cfgs, flags=4)
 stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream); ctx.set_stream(stream.cuda_stream)
 n = W * H
 dep0 = [torch.from_numpy(Syn.synth_depth(W, H, s).reshape(-1).view(np.uint8)).to(dev) for s in range(S)]
+if os.environ.get("PROBE_EMPTY"):       # no valid depth at all: every launch after the readers runs on zero partials (its floor)
+    dep0 = [torch.zeros_like(d) for d in dep0]
 col0 = [torch.from_numpy(Syn.synth_color(W, H, s)).to(dev) for s in range(S)]
 sets = [(dep0, col0)] + [([d.clone() for d in dep0], [c.clone() for c in col0]) for _ in range(3)]
 vox = torch.empty(S * n * 5, dtype=torch.int16, device=dev)
