@@ -335,17 +335,40 @@ __device__ __forceinline__ bool sorted_in_a(const unsigned int* __restrict__ ctl
     return (real_passes(ctl, bits, w0, w1, w2) & 1u) == 0u;
 }
 
+// Partials that arrive from outside the pre-aggregation of this call (other GPUs' pre-aggregations, gathered to the root:
+// BASELINE configs[4]) bring RAW voxel keys; the sort wants (key << idx_bits) | index, or key and index side by side. The
+// first pass reads them as they are and forms its elements on the fly — keys == nullptr everywhere else. (Until round 3 a
+// separate import kernel rewrote them first: one more launch and 14 MB more traffic on the root.)
+struct RawKeys {
+    const unsigned long long* keys;      // nullptr: the elements are in the sort's own buffers
+    const int32_t*            m_dev;     // their number: read from the device if given (at most m_host), else m_host
+    unsigned int              m_host;
+    __device__ __forceinline__ unsigned int count() const
+    {
+        const unsigned int m = m_dev ? (unsigned int)max(*m_dev, 0) : m_host;
+        return min(m, m_host);
+    }
+    __device__ __forceinline__ unsigned long long element(unsigned int e, unsigned int idx_bits) const
+    {
+        const unsigned long long k = keys[e];
+        return idx_bits ? (k << idx_bits) | e : k;
+    }
+};
+
 // table[chunk][digit] = occurrences of the digit in the chunk
 __global__ __launch_bounds__(kSortThreads)
 void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys_a, const unsigned long long* __restrict__ keys_b,
-                           const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits, unsigned int pass,
-                           unsigned int n_passes, unsigned int* __restrict__ table)
+                           unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits, unsigned int pass,
+                           unsigned int n_passes, unsigned int* __restrict__ table, RawKeys raw)
 {
     __shared__ unsigned int hist[kRadix];
+    const bool from_raw = raw.keys != nullptr && pass == 0;        // (raw input never skips a pass: nobody tracked its key bits)
     const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
     if (sp.skip) return;
     const unsigned long long* __restrict__ keys = sp.in_a ? keys_a : keys_b;
-    const unsigned int m = ctl[0];
+    // raw input: this launch also publishes the element count for the device-driven kernels that follow
+    const unsigned int m = from_raw ? raw.count() : ctl[0];
+    if (from_raw && blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = m;
     const unsigned int csize = sort_chunk_of(m), per_thread = csize / kSortThreads;
     const unsigned int chunks = (m + csize - 1) / csize;
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -357,7 +380,7 @@ void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys_a, const 
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
                 const unsigned int e = c0 + (it0 + q) * kSortThreads + threadIdx.x;
-                k[q] = e < c1 ? keys[e] : 0ull;
+                k[q] = e < c1 ? (from_raw ? raw.element(e, idx_bits) : keys[e]) : 0ull;
             }
 #pragma unroll
             for (unsigned int q = 0; q < kSortBatch; q++) {
@@ -457,9 +480,10 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
                               unsigned long long* __restrict__ keys_b, unsigned int* __restrict__ idx_b,
                               const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits, unsigned int pass,
                               unsigned int n_passes, const unsigned int* __restrict__ table,
-                              const unsigned int* __restrict__ digit_total)
+                              const unsigned int* __restrict__ digit_total, RawKeys raw)
 {
     __shared__ __attribute__((aligned(16))) unsigned int cnt[kSortWaves][kRadix];      // 64 KiB
+    const bool from_raw = raw.keys != nullptr && pass == 0;
     __shared__ unsigned int wsum[kSortWaves];
     const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
     if (sp.skip) return;
@@ -493,7 +517,10 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
             const unsigned int e = w0 + r * 64 + lane;
             k[r] = 0ull;
             if (!PACKED) id[r] = 0u;
-            if (r < kRounds && e < w1) { k[r] = keys_in[e]; if (!PACKED) id[r] = idx_in[e]; }
+            if (r < kRounds && e < w1) {
+                if (from_raw) { k[r] = raw.element(e, idx_bits); if (!PACKED) id[r] = e; }
+                else { k[r] = keys_in[e]; if (!PACKED) id[r] = idx_in[e]; }
+            }
         }
         const u32x4 row4 = *reinterpret_cast<const u32x4*>(table + (size_t)chunk * kRadix + threadIdx.x * kPer);
         {   // clear the counters: 16-byte LDS stores, lane-contiguous
@@ -783,24 +810,6 @@ void pcs_voxel_fixup_kernel(const unsigned int* __restrict__ m_ptr, const BlockP
     }
 }
 
-// Partials that arrive from outside the pre-aggregation of this call (other GPUs' pre-aggregations, gathered to the root:
-// BASELINE configs[4]) enter the sort here: keys_in holds RAW voxel keys; the sort wants (key << idx_bits) | index, or key
-// and index side by side. Also publishes the element count for the device-driven kernels that follow.
-__global__ __launch_bounds__(256)
-void pcs_voxel_import_kernel(const unsigned long long* __restrict__ keys_in, unsigned int m_host, const int32_t* __restrict__ m_dev,
-                             unsigned int capacity, unsigned int idx_bits, unsigned long long* __restrict__ keys_a,
-                             unsigned int* __restrict__ idx_a, unsigned int* __restrict__ ctl)
-{
-    unsigned int m = m_dev ? (unsigned int)max(*m_dev, 0) : m_host;
-    m = min(m, capacity);
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = m;
-    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < m; i += gridDim.x * 256u) {
-        const unsigned long long k = keys_in[i];
-        if (idx_bits) keys_a[i] = (k << idx_bits) | i;
-        else { keys_a[i] = k; idx_a[i] = i; }
-    }
-}
-
 struct Workspace {
     unsigned long long *keys_a, *keys_b;
     unsigned int *idx_a, *idx_b;
@@ -848,6 +857,7 @@ struct Plan {
     VoxelDiv dv;
     unsigned int bits, idx_bits;
     bool track_bits;      // have the pre-aggregation record which key bits vary, so that the sort can skip passes
+    RawKeys raw{nullptr, nullptr, 0u};      // exchange format: the first pass reads caller-held raw keys
 };
 
 // The constants of floor(v / leaf) + bias for one leaf (pcs_voxel_agg.h: VoxelDiv) + the bits one axis takes.
@@ -928,14 +938,14 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
     for (unsigned int pass = 0; pass < n_passes; pass++) {
         hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits,
-                           pass, n_passes, w.table);
+                           pass, n_passes, w.table, pl.raw);
         hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, w.ctl, w.digit_total, bits, pass, n_passes);
         if (idx_bits)
             hipLaunchKernelGGL(pcs_voxel_scatter_kernel<true>, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.idx_a, w.keys_b,
-                               w.idx_b, w.ctl, bits, idx_bits, pass, n_passes, w.table, w.digit_total);
+                               w.idx_b, w.ctl, bits, idx_bits, pass, n_passes, w.table, w.digit_total, pl.raw);
         else
             hipLaunchKernelGGL(pcs_voxel_scatter_kernel<false>, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.idx_a, w.keys_b,
-                               w.idx_b, w.ctl, bits, idx_bits, pass, n_passes, w.table, w.digit_total);
+                               w.idx_b, w.ctl, bits, idx_bits, pass, n_passes, w.table, w.digit_total, pl.raw);
     }
     const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
     const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
@@ -1056,9 +1066,7 @@ hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const vo
     if (e != hipSuccess) return e;
     pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
     pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place
-    const unsigned int grid = std::min<unsigned int>((n_partials + 255u) / 256u, 2048u);
-    hipLaunchKernelGGL(pcs_voxel_import_kernel, dim3(grid), dim3(256), 0, st, d_keys, n_partials, d_n_partials, n_partials,
-                       pl.idx_bits, pl.w.keys_a, pl.w.idx_a, pl.w.ctl);
+    pl.raw = RawKeys{d_keys, d_n_partials, n_partials};
     return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st));
 }
 
