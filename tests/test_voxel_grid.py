@@ -446,3 +446,60 @@ def test_gpu_voxel_grid_counted_reads_the_count_from_the_device(oracle, n):
         if want.shape[0]:
             got = np.empty((int(nv[0]), 5), np.int16); ctx.memcpy_d2h(got, d_out)
             assert (got == want).all()
+
+
+@pytest.mark.gpu
+def test_voxel_entry_forms_interleaved_on_one_context_without_synchronising(oracle):
+    """Every voxel call hands the next one its control block (two blocks at the start of the workspace, cleared by the
+    previous call's block-scan kernel instead of a memset launch). One context, one stream, no host synchronisation between
+    calls: payloads of growing and shrinking sizes (the workspace is re-allocated in between), the raster form, the partials
+    exchange format, calls that fail their argument checks in the middle, and the host-pointer form — each against the oracle."""
+    rng = np.random.default_rng(77)
+    cfgs, depth, color = S.synth_frame_set(3, 320, 240)
+    n_max = sum(c.n_points for c in cfgs)
+    flags = FLAG_DROP_INVALID
+    stitched, _ = oracle.process_frames(cfgs, depth, color, flags)
+    with PcsContext(cfgs, flags=flags) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        sizes = [500, 70001, 3, 8192, 200000, 1, 4097, 150000]
+        clouds = [random_payload(n, 100 + i, span=int(rng.choice([60, 3000, 32767]))) for i, n in enumerate(sizes)]
+        big = max(max(sizes), n_max)
+        d_in = [ctx.device_malloc(c.nbytes + 64) for c in clouds]
+        for p, c in zip(d_in, clouds):
+            ctx.memcpy_h2d(p, c)
+        d_k = ctx.device_malloc(n_max * 8 + 64); d_p = ctx.device_malloc(n_max * 32 + 64); d_np = ctx.device_malloc(64)
+        jobs = []                                    # (what, leaf, device output, device count, expected)
+        def out_pair(n):
+            return ctx.device_malloc(max(n, 1) * 10 + 64), ctx.device_malloc(64)
+        for rep in range(3):
+            for i, (n, c) in enumerate(zip(sizes, clouds)):
+                leaf = int(rng.choice([1, 9, 37, 50, 250, 4000]))
+                d_o, d_n = out_pair(n)
+                ctx.voxel_grid_device(d_in[i], n, leaf, d_o, max(n, 1) * 5, d_n)
+                jobs.append((f"payload {n}", leaf, d_o, d_n, oracle.voxel_grid(c, leaf)))
+                if i % 3 == 0:                       # rasters -> voxels on the same workspace
+                    leaf = int(rng.choice([12, 36, 60, 500]))
+                    d_o, d_n = out_pair(n_max)
+                    ctx.process_frames_voxel_device(dd, dc, leaf, d_o, n_max * 5, d_n)
+                    jobs.append(("rasters", leaf, d_o, d_n, oracle.voxel_grid(stitched, leaf)))
+                if i % 3 == 1:                       # the exchange format: partials, then the grid from them (count on the device)
+                    leaf = int(rng.choice([7, 45, 300]))
+                    d_o, d_n = out_pair(n_max)
+                    ctx.process_frames_voxel_partials_device(dd, dc, leaf, d_k, d_p, n_max, d_np)
+                    ctx.voxel_grid_from_partials_device(d_k, d_p, n_max, leaf, d_o, n_max * 5, d_n, d_n_partials=d_np)
+                    jobs.append(("partials", leaf, d_o, d_n, oracle.voxel_grid(stitched, leaf)))
+                if i % 4 == 2:                       # refused before anything is enqueued: must not disturb the hand-over
+                    with pytest.raises(PcsError):
+                        ctx.voxel_grid_device(d_in[i], n, 0, d_o, max(n, 1) * 5, d_n)
+                    with pytest.raises(PcsError):
+                        ctx.voxel_grid_device(d_in[i], n, 50, d_o, 1, d_n)
+        ctx.synchronize()
+        for what, leaf, d_o, d_n, want in jobs:
+            nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_n)
+            got = np.empty(max(int(nv[0]), 1) * 5, np.int16); ctx.memcpy_d2h(got, d_o)
+            got = got[:int(nv[0]) * 5].reshape(-1, 5)
+            assert got.shape == want.shape and (got == want).all(), (what, leaf, got.shape, want.shape)
+        # the host-pointer form shares the workspace too
+        got = ctx.voxel_grid(clouds[1], 50)
+        want = oracle.voxel_grid(clouds[1], 50)
+        assert got.shape == want.shape and (got == want).all()
