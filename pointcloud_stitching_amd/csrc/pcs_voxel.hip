@@ -884,8 +884,8 @@ hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
 }
 
 // Carves the workspace and derives the key layout for a cloud of at most n_points points.
-// The control words: a call needs 64 zeroed words (counters, tickets, key bits). Instead of a memset launch per call — 5 us
-// of dependent-dispatch floor — the workspace holds TWO blocks at its start; call k uses block k & 1 and its block-scan kernel
+// The control words: a call needs 64 zeroed words (counters, key bits). Instead of a memset launch per call (one more
+// dependent dispatch) the workspace holds TWO blocks at its start; call k uses block k & 1 and its block-scan kernel
 // clears the other one for call k + 1 (nothing of call k touches that block; call k - 1, which used it, is behind on the
 // stream). `ws` remembers the parity; a workspace it has not seen, or one whose last call may not have been enqueued
 // completely (ws.clean == false), gets both blocks cleared by a memset first.
