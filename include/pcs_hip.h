@@ -309,13 +309,17 @@ typedef struct pcs_voxel_partial {          /* 32 bytes */
 
 /* Rasters -> partials of this context's streams under its flags (CUTOFF / DROP_INVALID / downsample honoured exactly as
  * pcs_process_frames_voxel_device does). d_keys / d_partials need room for `capacity` >= pcs_max_payload_shorts / 5 entries
- * (worst case: every kept point its own partial); *d_n_partials (device) receives how many were written. Asynchronous.    */
+ * (worst case: every kept point its own partial); *d_n_partials (device, 4-byte aligned) receives how many were written:
+ * it is the kernels' own append counter, cleared by the call — valid once the call's work on the stream is complete, not
+ * before. Asynchronous.                                                                                                   */
 int pcs_process_frames_voxel_partials_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                                              int leaf_mm, uint64_t* d_keys, pcs_voxel_partial* d_partials, size_t capacity,
                                              int32_t* d_n_partials);
 /* Partials (of any number of pcs_process_frames_voxel_partials_device calls with the SAME leaf_mm, concatenated in any
  * order) -> the voxel grid. n_partials entries are read, or *d_n_partials (device, <= n_partials, which then is the
- * capacity) when that pointer is given. The output needs room for n_partials points. Asynchronous.                       */
+ * capacity) when that pointer is given. The output needs room for n_partials points. The partials must be ones this library
+ * produced (or obey its bounds: n <= 32 768 points per partial, i.e. colour sums < 2^23): 256 of them are summed in 32 bits.
+ * Asynchronous.                                                                                                           */
 int pcs_voxel_grid_from_partials_device(pcs_ctx* ctx, const uint64_t* d_keys, const pcs_voxel_partial* d_partials,
                                         int n_partials, const int32_t* d_n_partials, int leaf_mm, int16_t* d_out,
                                         size_t out_shorts, int32_t* d_out_points);
