@@ -291,3 +291,62 @@ def test_aggregate_point_count_is_refused_before_any_device_is_touched():
         PcsContext(ok).close()
     except PcsError as ex:
         assert ex.status == -2                                                    # no device here: that, and only that
+
+
+_RCCL_WORLD1 = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pointcloud_stitching_amd import synthetic as S
+from pointcloud_stitching_amd.api import PcsContext
+from pointcloud_stitching_amd.stitch import RankStitcher, ShardedVoxelGrid
+from pointcloud_stitching_amd.types import FLAG_DROP_INVALID
+from oracle import pcs_oracle as O
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+cfgs, depth, color = S.synth_frame_set(3, 320, 240)
+stitched, counts = O.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+with PcsContext(cfgs, device=0, flags=FLAG_DROP_INVALID) as ctx:
+    ctx.set_stream(stream.cuda_stream)
+    dd = [torch.from_numpy(d.reshape(-1).view(np.uint8)).to(dev) for d in depth]
+    dc = [torch.from_numpy(c).to(dev) for c in color]
+    n_max = sum(c.n_points for c in cfgs)
+    pay = torch.zeros(n_max * 5, dtype=torch.int16, device=dev)
+    cnt = torch.zeros(len(cfgs) + 1, dtype=torch.int32, device=dev)
+    ctx.process_frames_device([t.data_ptr() for t in dd], [t.data_ptr() for t in dc], pay.data_ptr(), pay.numel(), cnt.data_ptr())
+    st = RankStitcher()
+    assert (st.rank, st.world, st.host_staged) == (0, 1, False)
+    # fixed-size gather through RCCL (asynchronous form, as bench.py drives it), variable gather, counts from a device word
+    out = torch.zeros_like(pay)
+    st.gather_fixed(pay, out, async_op=True).wait()
+    out2 = torch.zeros_like(pay)
+    got_counts = st.gather_variable(pay, cnt[len(cfgs)], out2)
+    torch.cuda.synchronize()
+    total = int(cnt[len(cfgs)].item())
+    assert got_counts == [total] and total * 5 == stitched.size
+    assert (out[:stitched.size].cpu().numpy() == stitched.reshape(-1)).all()
+    assert (out2[:stitched.size].cpu().numpy() == stitched.reshape(-1)).all()
+    # the config-5 pipeline object on the RCCL group
+    vox = torch.zeros(n_max * 5, dtype=torch.int16, device=dev)
+    sv = ShardedVoxelGrid(ctx, 50, dev)
+    sv.run([t.data_ptr() for t in dd], [t.data_ptr() for t in dc], vox.data_ptr(), vox.numel())
+    torch.cuda.synchronize()
+    nv = int(sv.n_vox[0].item())
+    want = O.voxel_grid(stitched, 50)
+    assert nv == want.shape[0] and (vox[:nv * 5].cpu().numpy().reshape(-1, 5) == want).all()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+'''
+
+
+@pytest.mark.gpu
+def test_exchange_classes_on_a_real_rccl_group_of_one():
+    """Everything at N > 1 is tested with gloo (host-staged). This is the part of the RCCL route one GPU can exercise: a real
+    "nccl" process group (world 1) under RankStitcher / ShardedVoxelGrid — the group comes up in this environment, the
+    collectives take the dtypes and views they are handed, and stream ordering between the library's kernels and torch's
+    collectives holds."""
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1, ROOT, "29611"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
