@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — Mpoints/s stitched for 8 x 1280x720 synthetic streams (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                       (any N; N > 1 = the one-process node route)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W         (the same: rank 0 drives the node, the others exit)
+    ... --route ranks                                                    (one process per GPU over torch.distributed / RCCL)
 
 A "step" = one pass of the fused deproject -> transform -> RGB attach -> pack kernel over one frame-set
 already resident in HBM. The frame-sets live in a ring whose INPUT rasters alone are more than twice the
@@ -15,6 +16,12 @@ Workload (the default, `--scaling strong`): 8 streams IN TOTAL, 8/N per GPU.
   N = 8  BASELINE.json configs[3]: one stream per GPU, the packed payloads gathered to rank 0 over RCCL/xGMI in
          camera order (what /root/reference's src/pcs-multicamera-client.cpp:373-409 does over TCP).
 `--scaling weak` keeps 8 streams PER GPU (64 streams at N = 8) — not a BASELINE configuration, kept as an option.
+Routes at N > 1. `node` (the default): ONE process drives the N GPUs through libpcs_node — the C++ host over
+the C ABI that `north_star` asks for: per-GPU contexts of libpcs_hip, ncclCommInitAll, one grouped ncclSend/ncclRecv to
+GPU 0 per frame-set, pipelined as submit(k+1); wait(k). It works however the script is launched: plain, or under
+torch.distributed.run (rank 0 does the work, the other ranks exit at once). `ranks`: one process per GPU, the exchange
+through torch.distributed (pointcloud_stitching_amd/stitch.py); needs torch.distributed.run — launched plain it re-executes
+itself under it.
 Rank 0 prints ONE JSON line. At N = 1 it also carries the other kernels' legs (ordered compaction, K frame-sets per
 launch, the batched a2 twin), each with its own algorithmic byte model, and the CPU baseline.
 """
@@ -81,6 +88,15 @@ def parse():
                          "configs[4] — 16 x 1920x1080 streams sharded 16/N per GPU, invalid-depth compaction, voxel grid of the "
                          "stitched cloud on rank 0 (per-rank voxel partials, one exchange, one sort + segmented mean)")
     ap.add_argument("--leaf", type=int, default=50, help="config5: voxel leaf in millimetres")
+    ap.add_argument("--route", choices=["auto", "node", "ranks"], default="auto",
+                    help="how N GPUs are driven. node: ONE process, libpcs_node (C++ host, ncclCommInitAll, one grouped "
+                         "ncclSend/ncclRecv to GPU 0 per frame-set, pipelined submit/wait). ranks: one process per GPU over "
+                         "torch.distributed (needs torch.distributed.run; launched plain it re-executes itself under it). "
+                         "auto (default): node for N > 1, the single-GPU legs for N = 1")
+    ap.add_argument("--node-devices", type=str, default="",
+                    help="node route: explicit device ids, one per peer (default 0..N-1). A repeated id makes virtual peers of "
+                         "one GPU whose transfers become RCCL self send/recv pairs: `--gpus 2 --node-devices 0,0` runs the N = 2 "
+                         "flow on a one-GPU box. For testing the flow — the numbers then say nothing about scaling")
     ap.add_argument("--batch-sets", type=int, default=4, help="frame-sets per launch of the batched-dense leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--preheat-ms", type=float, default=400.0,
@@ -237,8 +253,6 @@ def run_config5(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 through python -m torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
     debug_gloo = args.debug_backend == "gloo"
@@ -409,17 +423,290 @@ def run_config5(args):
         dist.destroy_process_group()
 
 
+def run_node(args):
+    """ONE process, N GPUs, libpcs_node (include/pcs_node.h) — the route `north_star` words: a C++ host over the C ABI,
+    cameras sharded over the GPUs in camera order, one grouped RCCL exchange to GPU 0 per frame-set
+    (src/pcs-multicamera-client.cpp:373-409's concatenation over xGMI instead of TCP). The loop is the pipelined one,
+        submit(k+1); wait(k)
+    so the kernels of frame-set k+1 overlap the exchange (and, for config5, the root's sort) of frame-set k.
+      --workload stitch   8 x 1280x720 in total, 8/N per GPU (BASELINE configs[2] at N = 1, configs[3] at N = 8)
+      --workload config5  16 x 1920x1080 in total, 16/N per GPU, invalid-depth compaction, voxel grid of the stitched cloud on
+                          GPU 0 through voxel partials (BASELINE configs[4] at N = 8)
+    Strong scaling: the work is fixed, the GPUs share it. Input rings are cold (per GPU, a slot is re-read after more than
+    2 x 256 MiB of other rasters). Before timing, the root's result for ring slots 0 and 1 is compared with the CPU oracle,
+    every stream of it (config5: the committed oracle digest)."""
+    import hashlib
+    import torch
+    from pointcloud_stitching_amd import synthetic as Syn
+    from pointcloud_stitching_amd import node as N
+    from pointcloud_stitching_amd.api import PcsError
+    from pointcloud_stitching_amd.types import POINT_SHORTS, FLAG_DROP_INVALID, FLAG_CUTOFF
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
+    config5 = args.workload == "config5"
+    devices = [int(x) for x in args.node_devices.split(",")] if args.node_devices else list(range(args.gpus))
+    P = len(devices)
+    if args.node_devices and P != args.gpus:
+        raise SystemExit(f"--node-devices names {P} peers but --gpus is {args.gpus}")
+    avail = torch.cuda.device_count()
+    note = None
+    if max(devices) >= avail:
+        # fewer GPUs than asked for: never a reason to print no line — fold the peers onto the GPUs that exist, and say so
+        note = f"{args.gpus} GPUs requested, {avail} visible: peers folded onto the visible GPUs (virtual peers)"
+        devices = [d % avail for d in devices]
+    virtual = len(set(devices)) < P
+    defaults = (args.streams, args.width, args.height) == (8, 1280, 720)
+    total_streams, W, H = (16, 1920, 1080) if (config5 and defaults) else (args.streams, args.width, args.height)
+    if total_streams % P:
+        raise SystemExit(f"{total_streams} streams do not divide over {P} peers")
+    S, npts = total_streams // P, W * H
+    LEAF = args.leaf
+    flags = FLAG_DROP_INVALID if config5 else {"drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}.get(args.mode, 0)
+    cfgs = [Syn.synth_stream_config(W, H, g) for g in range(total_streams)]
+
+    out = {}
+    node, node_error = None, None
+    try:
+        node = N.PcsNode(cfgs, devices=devices, flags=flags)
+    except PcsError as e:
+        # RCCL would not come up: measure what the kernels alone sustain, say so, and still print a line
+        node_error = f"{type(e).__name__}: {e}"[:300]
+        node = N.PcsNode(cfgs, devices=devices, flags=flags, node_flags=N.NO_EXCHANGE)
+    lib, h = node._lib, node._h
+    VP = C.c_void_p
+
+    def check(rc):
+        if rc:
+            raise RuntimeError((lib.pcs_node_last_error(h) or b"").decode())
+
+    # ---- rings of input rasters, each on its owning GPU ------------------------------------------------------------------------
+    in_bytes_gpu = S * npts * 5
+    R = max(args.ring, 2) if args.ring else max(4, -(-2 * INFINITY_CACHE_BYTES // in_bytes_gpu) + 2)
+    DISTINCT = 2
+    host = [([Syn.synth_depth(W, H, g, seed=Syn.SEED + 7919 * k) for g in range(total_streams)],
+             [Syn.synth_color(W, H, g, seed=Syn.SEED + 7919 * k) for g in range(total_streams)]) for k in range(DISTINCT)]
+    if config5:
+        host[1] = host[0]            # the digest is of frame 0: every slot holds it (distinct ADDRESSES are what keeps the ring cold)
+    ring = []                        # ring[slot] = (ctypes depth pointers, ctypes colour pointers), keeps: the tensors
+    keep = []
+    first = [None] * DISTINCT
+    for slot in range(R):
+        dps, cps = [], []
+        src = slot % DISTINCT
+        tens = []
+        for g in range(total_streams):
+            dev = torch.device("cuda", devices[g // S])
+            if slot < DISTINCT:
+                d = torch.from_numpy(host[src][0][g].reshape(-1).view(np.uint8)).to(dev)
+                c = torch.from_numpy(host[src][1][g]).to(dev)
+            else:
+                d, c = first[src][g][0].clone(), first[src][g][1].clone()
+            tens.append((d, c)); dps.append(d.data_ptr()); cps.append(c.data_ptr())
+        if slot < DISTINCT:
+            first[slot] = tens
+        keep.append(tens)
+        ring.append(((VP * total_streams)(*dps), (VP * total_streams)(*cps)))
+    root_dev = torch.device("cuda", devices[0])
+    cap = node.max_payload_shorts
+    outs = [torch.empty(cap + 32, dtype=torch.int16, device=root_dev) for _ in range(2)]
+    counter = [0]
+    tick = C.c_int(-1)
+    cnt_arr = (C.c_int * total_streams)()
+    tot = C.c_int(0)
+
+    def submit():
+        k = counter[0]; counter[0] = k + 1
+        dp, cp = ring[k % R]
+        if config5:
+            check(lib.pcs_node_submit_voxel_device(h, dp, cp, LEAF, VP(outs[k & 1].data_ptr()), cap, C.byref(tick)))
+        else:
+            check(lib.pcs_node_submit_device(h, dp, cp, VP(outs[k & 1].data_ptr()), cap, C.byref(tick)))
+        return tick.value
+
+    def wait(t):
+        if config5:
+            check(lib.pcs_node_wait_voxel(h, t, C.byref(tot)))
+        else:
+            check(lib.pcs_node_wait(h, t, cnt_arr, C.byref(tot)))
+        return tot.value
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    # ---- correctness before timing: slots 0 and 1 through the pipelined pair, every stream, against the oracle -------------------
+    from oracle import pcs_oracle as O
+    t_a = submit(); t_b = submit()
+    n_a = wait(t_a); got_a = outs[0][:n_a * POINT_SHORTS].cpu().numpy()
+    n_b = wait(t_b); got_b = outs[1][:n_b * POINT_SHORTS].cpu().numpy()
+    checked = {"slots": [0, 1], "streams": total_streams, "exchange": node_error is None}
+    if config5:
+        dig = [hashlib.sha256(g.tobytes()).hexdigest() for g in (got_a, got_b)]
+        checked.update({"voxels": n_a, "voxel_sha256": dig[0], "golden": None})
+        gpath = os.path.join(ROOT, "tests", "golden", "config5_digests.json")
+        gold = json.load(open(gpath))["voxel"].get(str(LEAF)) if ((total_streams, W, H) == (16, 1920, 1080) and os.path.exists(gpath)) else None
+        if gold and node_error is None:
+            checked["golden"] = bool(gold["voxels"] == n_a == n_b and gold["sha256"] == dig[0] == dig[1])
+            if not checked["golden"]:
+                raise SystemExit(f"bench aborted: the node's voxel cloud differs from the oracle digest (leaf {LEAF} mm)")
+        elif node_error is None:
+            want, _ = O.process_frames(cfgs, host[0][0], host[0][1], flags, 1)
+            wv = O.voxel_grid(want, LEAF)
+            if n_a != wv.shape[0] or (got_a.reshape(-1, 5) != wv).any():
+                raise SystemExit("bench aborted: the node's voxel cloud differs from the oracle")
+    else:
+        for slot, (n_got, got) in enumerate(((n_a, got_a), (n_b, got_b))):
+            want, _ = O.process_frames(cfgs, host[slot][0], host[slot][1], flags, 1)
+            if node_error is not None:                         # nothing was gathered: only the root's own slice is there
+                own = sum(cnt_arr[:S]); want, got, n_got = want[:own], got[:own * POINT_SHORTS], own
+            if n_got != want.shape[0] or (got.reshape(-1, 5) != want).any():
+                raise SystemExit(f"bench aborted: the stitched cloud of ring slot {slot} differs from the oracle")
+
+    # ---- settle clocks, warm up, time EXACTLY `steps` frame-sets: submit(k+1); wait(k) ----------------------------------------------
+    def run(k_steps):
+        t = submit()
+        for _ in range(k_steps - 1):
+            t2 = submit(); wait(t); t = t2
+        wait(t)
+
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+        run(20)
+    if args.warmup:
+        run(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    # ---- where a frame-set's time goes (HIP events on the root GPU; a separate loop: the events cost host time) ----------------------
+    node.set_timing(True)
+    ph = {"kernel": [], "exchange": [], "root": []}
+    xbytes = reduced = 0
+    n_ph = 30
+    t = submit()
+    for _ in range(n_ph):
+        t2 = submit(); wait(t); t = t2
+        st = node.last_stats()
+        ph["kernel"].append(st["kernels_ms"]); ph["exchange"].append(st["exchange_ms"]); ph["root"].append(st["root_ms"])
+        xbytes, reduced = st["exchanged_bytes"], st["reduced"]
+        counts = [int(x) for x in cnt_arr] if not config5 else None       # of the same frame-set as xbytes
+    wait(t)
+    node.set_timing(False)
+    kern_ms = float(np.median(ph["kernel"]))
+
+    pts_step = total_streams * npts
+    ms_per_step = elapsed * 1e3 / args.steps
+    kept_root = float(np.mean([(d != 0).mean() for d in host[0][0][:S]]))
+    if config5:
+        bytes_root = S * npts * 5             # + 40 B per partial (not known per peer here): a lower bound, stated
+        kern_name = "pcs_fused_voxel_partials_kernel"
+        bpp_note = "root GPU's pre-aggregation launch: 5 B per pixel in (+ 40 B per partial out, not counted): VALU / LDS bound, not HBM bound"
+    elif flags:
+        bytes_root = S * npts * (5 + 10 * kept_root)
+        kern_name = "pcs_fused_count_kernel + pcs_scan_kernel + pcs_fused_emit_kernel"
+        bpp_note = "root GPU's launches for its own cameras: (5 + 10 rho) B per pixel"
+    else:
+        bytes_root = S * npts * ALGO_BYTES_PER_POINT
+        kern_name = "pcs_fused_dense_kernel"
+        bpp_note = "root GPU's launch for its own cameras: 15 B per point"
+    ach = bytes_root / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    where = "one GPU" if P == 1 else f"{P} GPUs, {S} per GPU"
+    if config5:
+        cfg_name = "BASELINE.json configs[4]" if (total_streams, W, H, S) == (16, 1920, 1080, 2) else f"configs[4]'s pipeline, {S} cameras per GPU"
+        metric = "Mpoints/s in (16x1920x1080 streams: deproject+transform+RGB+pack, invalid-depth compaction, voxel grid of the stitched cloud)"
+        workload = (f"{cfg_name}: {total_streams} synthetic {W}x{H} Z16+RGB8 streams on {where}, PCS_FLAG_DROP_INVALID, voxel-grid downsample "
+                    f"(leaf {LEAF} mm) of the stitched cloud on GPU 0: per-GPU voxel partials, one grouped exchange, one sort + segmented mean")
+    else:
+        cfg_name = ("BASELINE.json configs[2]" if P == 1 and total_streams == 8 else
+                    "BASELINE.json configs[3]" if (S == 1 and total_streams == 8) else f"{total_streams} streams sharded {S}/GPU")
+        metric = "Mpoints/s stitched (8x1280x720 streams: deproject+transform+RGB+pack)"
+        workload = (f"{total_streams} synthetic {W}x{H} Z16+RGB8 streams on {where}, batched fused kernel, one extrinsic per stream ({cfg_name})"
+                    + (", payloads gathered to GPU 0 in camera order" if P > 1 and node_error is None else ""))
+    out.update({
+        "metric": metric, "value": round(pts_step * args.steps / elapsed / 1e6, 1), "unit": "Mpoints/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "route": "node: one process, libpcs_node (C++ host over the C ABI), pcs_node_submit*/pcs_node_wait* pipelined",
+                   "arithmetic": "f32 deprojection + affine (bit-exact vs the -m path), u16 depth in, u8 colour in, int16 records out",
+                   "streams_total": total_streams, "streams_per_gpu": S, "width": W, "height": H,
+                   "points_per_step": pts_step, "ring_frame_sets": R,
+                   "ring_inputs_between_rereads_mbytes_per_gpu": round((R - 1) * in_bytes_gpu / 1e6, 1),
+                   "ring_cold": bool((R - 1) * in_bytes_gpu >= 2 * INFINITY_CACHE_BYTES),
+                   "gather_to_rank0": bool(P > 1 and node_error is None), "devices": devices,
+                   "parallelism": f"streams sharded {S}/GPU x {P}"},
+        "rccl_ranks": node.rccl_ranks,
+        "check": checked,
+        "phases_ms": {"kernel": round(kern_ms, 5), "exchange": round(float(np.median(ph["exchange"])), 5),
+                      "root": round(float(np.median(ph["root"])), 5),
+                      "note": "medians of HIP-event brackets on GPU 0 over a separate loop of the same pipelined steps: kernel = the root's own "
+                              "launch(es); exchange = group enqueued (every peer's kernels done) -> every payload landed; root = config5's sort + "
+                              "segmented mean. They overlap across frame-sets: their sum is not ms_per_step"},
+        "bytes_into_root_per_step": int(xbytes),
+        "root_ingest_GBps": round(xbytes / (ms_per_step * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": kern_name, "avg_launch_ms": round(kern_ms, 5),
+                     "algorithmic_bytes_per_launch": int(bytes_root), "note": bpp_note,
+                     "timing": "hipEvent pair on GPU 0's kernel stream around its own launch(es), median over pipelined steps"},
+    })
+    if config5:
+        out["partials_reduced_per_step"] = int(reduced)
+        out["config"]["leaf_mm"] = LEAF
+    else:
+        out["per_stream_fps"] = round(args.steps / elapsed, 1)
+        out["points_per_stream"] = counts
+    if P > 1:
+        out["scaling_note"] = ("strong scaling with a gather: every peer's packed cloud crosses ONE xGMI link into GPU 0 each step, so the step "
+                               "is bound by bytes_into_root_per_step over the links (and by one host thread enqueueing for N GPUs), not by the "
+                               "kernels; see DESIGN.md §9")
+    if virtual:
+        out["debug"] = ("virtual peers: device ids repeat, the peers of one GPU share it and their transfers are RCCL self send/recv "
+                        "pairs. Exercises the N > 1 flow; says nothing about scaling")
+    if note:
+        out["note"] = note
+    if node_error:
+        out["node_error"] = node_error
+        out["config"]["gather_to_rank0"] = False
+    print(json.dumps(out), flush=True)
+    node.close()
+    return 0
+
+
+def _reexec_under_torchrun(args):
+    """--route ranks launched plain with N > 1: run the same command line under torch.distributed.run (one rank per GPU)
+    and hand its output and exit code through. Never a SystemExit for a launcher reason."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    route = args.route
+    if route == "auto":
+        # (--debug-backend gloo is the control-flow test of the ranks route)
+        route = "node" if ((args.gpus > 1 or args.node_devices) and args.debug_backend != "gloo") else "ranks"
+    if route == "node":
+        if int(os.environ.get("RANK", "0")) != 0:
+            return 0                     # under torch.distributed.run: rank 0's process drives every GPU of the node
+        return run_node(args)
+    if args.gpus > 1 and world == 1:
+        return _reexec_under_torchrun(args)
     if args.workload == "config5":
         return run_config5(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 through python -m torch.distributed.run (one rank per GPU)")
 
     import torch
     import torch.distributed as dist
@@ -1247,4 +1534,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

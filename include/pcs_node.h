@@ -8,12 +8,17 @@
  * payload, the root ncclRecv()s each straight into its slice of the stitched buffer (sendStitchToUnity's
  * camera-order concatenation, :385-395). The root's own slice is written in place by its kernel.
  *
- * This is the single-process form (ncclCommInitAll). The one-process-per-GPU form used by bench.py lives
- * in pointcloud_stitching_amd/stitch.py (torch.distributed / RCCL).
+ * This is the single-process form (ncclCommInitAll), the one `bench.py --gpus N` measures by default (--route node).
+ * The one-process-per-GPU form lives in pointcloud_stitching_amd/stitch.py (torch.distributed / RCCL; --route ranks).
  *
- * Status: the one-GPU paths (n_devices == 1) run in the test-suite on hardware. With n_devices > 1 the RCCL exchange has
- * not yet met a multi-GPU box (the development boxes have one GPU): treat the N > 1 paths, and in particular the
- * pipelined pcs_node_submit_device / pcs_node_wait pair, as EXPERIMENTAL until a hardware run is on record.
+ * Peers and GPUs. An entry of device_ids is a PEER: it owns streams_per_device cameras, a libpcs_hip context and two
+ * payload slots. Distinct device ids are the GPUs: each owns one RCCL communicator rank and one communication stream.
+ * A device id may REPEAT: the peers that share it are virtual peers of one GPU, and their transfers to the root become
+ * RCCL self send/recv pairs on that GPU's communicator. That is how a one-GPU box runs every N > 1 code path — offsets,
+ * slots, events, the grouped ncclSend/ncclRecv — on real RCCL (tests/test_node.py, bench.py --node-devices 0,0).
+ *
+ * Status: every path runs in the test-suite on ONE GPU (virtual peers, RCCL self exchange). A run over several physical
+ * GPUs is what bench.py --gpus N produces; none is on record yet (the development boxes have one GPU).
  */
 #ifndef PCS_NODE_H
 #define PCS_NODE_H
@@ -32,10 +37,17 @@ typedef struct pcs_node pcs_node;
  * would not fit the wire format's int32 byte count (more than 214 748 364 points in all). */
 int  pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
                      const pcs_stream_config* streams, uint32_t flags, int downsample);
+/* The same with node flags. PCS_NODE_NO_EXCHANGE: no communicator is created and nothing is gathered — every peer packs its
+ * own cameras and only the root's slice of the stitched buffer is written (the counts are still the whole node's). A
+ * diagnostic ("what do the kernels alone sustain") and bench.py's fall-back when RCCL refuses to come up.              */
+#define PCS_NODE_NO_EXCHANGE 0x1u
+int  pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
+                        const pcs_stream_config* streams, uint32_t flags, int downsample, uint32_t node_flags);
 void pcs_node_destroy(pcs_node* node);
 const char* pcs_node_last_error(const pcs_node* node);      /* NULL node: error of the last failed create */
 
-int  pcs_node_devices(const pcs_node* node);
+int  pcs_node_devices(const pcs_node* node);                 /* peers (entries of device_ids)                              */
+int  pcs_node_rccl_ranks(const pcs_node* node);              /* size of the RCCL communicator (distinct GPUs); 0 = none    */
 size_t pcs_node_max_payload_shorts(const pcs_node* node);
 
 /* Host rasters in (uploaded to the owning GPUs), stitched buffer out on the host, header like pcs_process_frames. */
@@ -53,15 +65,32 @@ int  pcs_node_process_device(pcs_node* node, const uint16_t* const* d_depth, con
  * every GPU's kernel stream and its exchange on per-GPU communication streams, then returns a ticket; pcs_node_wait
  * blocks until that frame-set's stitched payload is complete on the root. Writing the loop as  submit(k+1); wait(k);
  * overlaps the xGMI exchange of frame-set k with the kernels of k+1 (each GPU keeps two payload buffers). The two
- * frame-sets need different stitched buffers. Without CUTOFF / DROP_INVALID nothing is read back from the GPUs;
- * with a predicate submit reads every GPU's counts back (one asynchronous copy per GPU, all in flight together, then one
- * wait per GPU: the exchange is sized by the data dependent counts).
+ * frame-sets need different stitched buffers. Without CUTOFF / DROP_INVALID nothing is read back from the GPUs and the
+ * exchange is enqueued by submit itself. With a predicate the exchange is sized by data-dependent counts: submit enqueues
+ * the kernels and an asynchronous read-back of the counts and RETURNS; the exchange is enqueued by the next submit (after
+ * that frame-set's kernels are queued, when the counts have long landed) or by pcs_node_wait, whichever comes first — the
+ * host never waits for a kernel it has just enqueued.
  * PCS_ERR_CAPACITY from submit = two frame-sets already in flight. pcs_node_process_device = submit + wait.
+ * A submit that fails after some GPUs' kernels were enqueued leaves no ticket behind and the node usable: submit again.
  * An RCCL failure inside the exchange closes the group, aborts the communicators and leaves the node unusable
- * (every later call fails with PCS_ERR_HIP); pcs_node_wait never blocks on a failed submit.                      */
+ * (every later call fails with PCS_ERR_HIP); pcs_node_wait never blocks on a failed exchange.                    */
 int  pcs_node_submit_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                             int16_t* d_stitched_payload_root, size_t stitched_shorts, int* ticket);
 int  pcs_node_wait(pcs_node* node, int ticket, int* points_per_stream, int* total_points);
+
+/* Where a frame-set's time went, from HIP events on the ROOT GPU (pcs_node_set_timing(node, 1) before the submit; the
+ * events cost a few host microseconds per submit, hence opt-in). pcs_node_last_stats returns the figures of the ticket most
+ * recently waited for; exchanged_bytes / reduced are filled with or without timing.                                     */
+typedef struct pcs_node_stats {
+    int32_t  ticket;
+    float    kernels_ms;         /* root kernel stream: this submit's first enqueue -> the root's own kernels done            */
+    float    exchange_ms;        /* root communication stream: group enqueued (all its peers' kernels done) -> payloads landed */
+    float    root_ms;            /* voxel tickets: the root's sort + segmented mean                                            */
+    int64_t  exchanged_bytes;    /* bytes the peers sent to the root                                                           */
+    int64_t  reduced;            /* points in the stitched cloud (stitch tickets) / partials the root reduced (voxel tickets)  */
+} pcs_node_stats;
+int  pcs_node_set_timing(pcs_node* node, int enable);
+int  pcs_node_last_stats(const pcs_node* node, pcs_node_stats* out);
 
 /* ---- BASELINE configs[4]: voxel-grid downsample of the cloud the node's cameras stitch to ---------------------------- *
  * 16 x 1920x1080 streams, 2 per GPU, invalid-depth compaction, voxel grid of the stitched cloud on the root. Two routes, the
@@ -90,6 +119,14 @@ typedef struct pcs_node_voxel_stats {
 int  pcs_node_process_voxel_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                                    int leaf_mm, int route, int16_t* d_voxels_root, size_t voxels_shorts, int* n_voxels,
                                    pcs_node_voxel_stats* stats);
+/* Pipelined form of route PARTIALS, two frame-sets in flight like pcs_node_submit_device (the two kinds of ticket share the
+ * two slots): submit enqueues every GPU's pre-aggregation and the read-back of its partial count and returns; the exchange
+ * (sized by those counts) and, behind it on the root, the sort + segmented mean are enqueued by the next submit or by
+ * pcs_node_wait_voxel. Written as  submit(k+1); wait(k);  the pre-aggregation of k+1 overlaps the exchange and the root's
+ * sort of k. The two frame-sets need different d_voxels_root buffers. pcs_node_process_voxel_device(PARTIALS) = submit + wait. */
+int  pcs_node_submit_voxel_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
+                                  int16_t* d_voxels_root, size_t voxels_shorts, int* ticket);
+int  pcs_node_wait_voxel(pcs_node* node, int ticket, int* n_voxels);
 /* Host form: rasters uploaded to their owning GPUs, the voxel cloud downloaded into `out` with the wire header like
  * pcs_node_process ([int32 bytes][records] when write_header; records always start at out + 2 shorts).              */
 int  pcs_node_process_voxel(pcs_node* node, const uint16_t* const* depth, const uint8_t* const* color, int leaf_mm, int route,

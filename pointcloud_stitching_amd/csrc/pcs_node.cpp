@@ -1,8 +1,15 @@
-// pcs_node.cpp — libpcs_node.so: several GPUs, one process, one grouped RCCL exchange to the root.
+// pcs_node.cpp — libpcs_node.so: several GPUs, one process, one grouped RCCL exchange to the root per frame-set.
 // See include/pcs_node.h for what it replaces in the reference. Built on the public C ABI of libpcs_hip.so
 // (it uses nothing from it that an outside caller could not).
+//
+// Vocabulary: a PEER is one entry of device_ids (the node's "rank": it owns streams_per_device cameras, a context of
+// libpcs_hip with its kernel stream, two payload slots). A GPU is a distinct physical device: it owns the RCCL
+// communicator rank and the communication stream. Normally peers and GPUs are the same list; a device id that repeats
+// makes VIRTUAL peers that share a GPU (their transfers to the root become RCCL self send/recv pairs on that GPU's
+// communicator) — how the one-GPU development boxes run every N > 1 code path on real RCCL.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,38 +19,72 @@
 
 #include "../../include/pcs_node.h"
 
+namespace {
+
+struct Peer {
+    int dev = 0, gpu = 0;                 // HIP ordinal; index into pcs_node::gpus
+    pcs_ctx* ctx = nullptr;
+    size_t payload_shorts = 0;            // worst-case payload of this peer's cameras
+    size_t vcap = 0;                      // worst-case voxel partials of this peer's cameras
+    void* d_payload[2] = {nullptr, nullptr};      // peers > 0: the packed payload of slot 0 / 1 (the root packs into the stitched buffer)
+    void* d_counts = nullptr;             // streams_per_device + 1 int32 (pcs_process_frames_device's counts)
+    void* d_vkeys[2] = {nullptr, nullptr};        // voxel route: keys / partials / append counter per slot
+    void* d_vparts[2] = {nullptr, nullptr};       //   (the root's arrays take everybody's partials)
+    void* d_vcount[2] = {nullptr, nullptr};
+    hipEvent_t packed[2] = {nullptr, nullptr};    // kernel stream: this slot's kernels and its counts read-back are done
+    std::vector<void*> d_depth, d_color;  // host forms: raster staging
+};
+
+struct Gpu {
+    int dev = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;    // the exchange runs here, not on a kernel stream
+    hipEvent_t drained[2] = {nullptr, nullptr};   // comm stream: the exchange that read / filled this slot has completed
+};
+
+enum TicketKind { kStitch = 0, kVoxel = 1 };
+
+struct Ticket {
+    bool busy = false, exchanged = false;
+    int id = -1, kind = kStitch, rc = PCS_OK;
+    std::string err;
+    // stitch
+    int16_t* d_stitched = nullptr;
+    std::vector<int32_t> cnt;             // [peer * (S + 1) + k], k == S: the peer's total
+    size_t total = 0;                     // points (stitch) / partials (voxel) on the root
+    // voxel
+    int leaf = 0;
+    int16_t* d_voxels = nullptr;
+    size_t voxels_shorts = 0;
+    int64_t exchanged_bytes = 0;
+};
+
+}  // namespace
+
 struct pcs_node {
-    int n_dev = 0, per_dev = 0, n_streams = 0;
-    uint32_t flags = 0;
+    int n_peers = 0, per_dev = 0, n_streams = 0;
+    uint32_t flags = 0, node_flags = 0;
     int downsample = 1;
-    std::vector<int> dev;
-    std::vector<pcs_ctx*> ctx;
-    std::vector<ncclComm_t> comm;
-    bool broken = false;                     // an RCCL call failed: the communicators were aborted
-    // per device, two slots (index 0 unused: the root packs into the stitched buffer): the kernel of frame-set k+1
-    // fills one payload buffer while the exchange of frame-set k drains the other
-    std::vector<void*> d_payload[2];
-    std::vector<size_t> payload_shorts;      // per device capacity
-    std::vector<hipStream_t> comm_stream;    // per device: the exchange runs here, not on the kernel stream
-    std::vector<hipEvent_t> packed[2];       // per device and slot: payload packed (kernel stream -> comm stream)
-    std::vector<hipEvent_t> drained[2];      // per device and slot: exchange done (comm stream -> kernel stream / host)
-    struct Ticket { bool busy = false; int slot = 0; std::vector<std::vector<int32_t>> cnt; size_t total = 0; };
+    std::vector<Peer> peers;
+    std::vector<Gpu> gpus;
+    bool have_comm = false;
+    bool broken = false;                  // an RCCL call failed: the communicators were aborted
+    bool pred = false;                    // CUTOFF / DROP_INVALID: the exchange is sized by data-dependent counts
+    bool timing = false;
     Ticket inflight[2];
     int next_ticket = 0;
-    bool pred = false;
-    std::vector<void*> d_counts;             // per device: per_dev + 1 int32
-    int32_t* h_counts[2] = {nullptr, nullptr};   // page-locked: [slot][device * (per_dev + 1) + k]  (asynchronous read-back)
-    std::vector<std::vector<void*>> d_depth, d_color;   // staging for the host form, per global stream
+    int32_t* h_counts[2] = {nullptr, nullptr};    // page-locked: [slot][peer * (S + 1) + k]
+    int32_t* h_vcount[2] = {nullptr, nullptr};    // page-locked: [slot][peer] partial counts; [n_peers] = the root's voxel count
     std::vector<pcs_stream_config> cfg;
-    void* d_stitched = nullptr; size_t stitched_cap_shorts = 0;
-    // voxel route (config 5): per device key / partial arrays (the root's are the merged arrays, sized for all devices)
-    std::vector<void*> d_vkeys, d_vparts, d_vcount;
-    std::vector<size_t> vcap;                // per device: worst-case partials of its own cameras
+    void* d_stitched = nullptr; size_t stitched_cap_shorts = 0;      // host forms
+    void* d_vox_out = nullptr;
+    void* d_vox_n[2] = {nullptr, nullptr};        // root: voxel count per slot
+    bool voxel_ready = false;
     size_t vcap_total = 0;
-    int32_t* h_vcount = nullptr;             // page-locked, n_dev
-    void* d_vox_out = nullptr;               // root, host form: the voxel cloud
-    void* d_vox_n = nullptr;                 // root: voxel count
-    hipEvent_t ev_v[4] = {nullptr, nullptr, nullptr, nullptr};     // root: start, own kernel done, exchange done, voxels done
+    // root: kernel stream events (timing enabled): start of the submit, own kernels done, reduce start, reduce done
+    hipEvent_t ev_k0[2] = {nullptr, nullptr}, ev_k1[2] = {nullptr, nullptr}, ev_r0[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_x0[2] = {nullptr, nullptr};     // root: comm stream, the group is about to be enqueued
+    pcs_node_stats last{};
     std::string err;
 };
 
@@ -62,9 +103,9 @@ int nfail(pcs_node* n, int status, const char* fmt, ...)
 #define PCSCHK(n, c, expr) do { int rc_ = (expr); if (rc_ != PCS_OK) \
     return nfail((n), rc_, "%s: %s", #expr, pcs_last_error(c)); } while (0)
 
-hipStream_t kstream(pcs_node* n, int r) { return static_cast<hipStream_t>(pcs_get_stream(n->ctx[r])); }
+hipStream_t kstream(const Peer& p) { return static_cast<hipStream_t>(pcs_get_stream(p.ctx)); }
 
-// One transfer of a grouped exchange: `bytes` from src on device index `from` to dst on the root.
+// One transfer of a grouped exchange: `bytes` from src on peer `from` to dst on the root.
 struct Xfer { int from; const void* src; void* dst; size_t bytes; };
 
 // The grouped exchange. Whatever happens between ncclGroupStart and ncclGroupEnd, the group is CLOSED before this
@@ -72,21 +113,24 @@ struct Xfer { int from; const void* src; void* dst; size_t bytes; };
 // on the communication streams) and the node is marked unusable.
 int run_exchange(pcs_node* n, const std::vector<Xfer>& xs)
 {
-    if (n->n_dev < 2 || xs.empty()) return PCS_OK;
+    if (!n->have_comm || xs.empty()) return PCS_OK;
+    Gpu& root = n->gpus[n->peers[0].gpu];
     ncclResult_t first = ncclGroupStart();
     if (first == ncclSuccess) {
         for (const Xfer& x : xs) {
             if (!x.bytes) continue;
-            ncclResult_t r = ncclSend(x.src, x.bytes, ncclInt8, 0, n->comm[x.from], n->comm_stream[x.from]);
-            if (r == ncclSuccess) r = ncclRecv(x.dst, x.bytes, ncclInt8, x.from, n->comm[0], n->comm_stream[0]);
+            Gpu& g = n->gpus[n->peers[x.from].gpu];
+            // rank of a GPU in the communicator = its index in n->gpus; a virtual peer on the root's GPU sends to itself
+            ncclResult_t r = ncclSend(x.src, x.bytes, ncclInt8, n->peers[0].gpu, g.comm, g.comm_stream);
+            if (r == ncclSuccess) r = ncclRecv(x.dst, x.bytes, ncclInt8, n->peers[x.from].gpu, root.comm, root.comm_stream);
             if (r != ncclSuccess) { first = r; break; }
         }
         const ncclResult_t end = ncclGroupEnd();          // always: never leave a group open
         if (first == ncclSuccess) first = end;
     }
     if (first == ncclSuccess) return PCS_OK;
-    for (ncclComm_t& c : n->comm) if (c) { (void)ncclCommAbort(c); c = nullptr; }
-    n->broken = true;
+    for (Gpu& g : n->gpus) if (g.comm) { (void)ncclCommAbort(g.comm); g.comm = nullptr; }
+    n->broken = true; n->have_comm = false;
     return nfail(n, PCS_ERR_HIP, "RCCL exchange failed: %s (communicators aborted; destroy the node)", ncclGetErrorString(first));
 }
 
@@ -96,108 +140,231 @@ int upload_rasters(pcs_node* n, const uint16_t* const* depth, const uint8_t* con
 {
     const int S = n->per_dev;
     dd.assign(n->n_streams, nullptr); dc.assign(n->n_streams, nullptr);
-    for (int r = 0; r < n->n_dev; r++) {
-        HIPCHK(n, hipSetDevice(n->dev[r]));
+    for (int r = 0; r < n->n_peers; r++) {
+        Peer& p = n->peers[r];
+        HIPCHK(n, hipSetDevice(p.dev));
         for (int k = 0; k < S; k++) {
             const int g = r * S + k;
             const pcs_stream_config& sc = n->cfg[g];
             const size_t db = (size_t)sc.depth.width * sc.depth.height * sizeof(uint16_t);
             const size_t cb = (size_t)sc.color_stride * sc.color.height;
             if (!depth[g] || !color[g]) return nfail(n, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", g);
-            if (!n->d_depth[r][k]) PCSCHK(n, n->ctx[r], pcs_device_malloc(n->ctx[r], &n->d_depth[r][k], db + 16));
-            if (!n->d_color[r][k]) PCSCHK(n, n->ctx[r], pcs_device_malloc(n->ctx[r], &n->d_color[r][k], cb + 16));
-            PCSCHK(n, n->ctx[r], pcs_memcpy_h2d(n->ctx[r], n->d_depth[r][k], depth[g], db));
-            PCSCHK(n, n->ctx[r], pcs_memcpy_h2d(n->ctx[r], n->d_color[r][k], color[g], cb));
-            dd[g] = static_cast<const uint16_t*>(n->d_depth[r][k]);
-            dc[g] = static_cast<const uint8_t*>(n->d_color[r][k]);
+            if (!p.d_depth[k]) PCSCHK(n, p.ctx, pcs_device_malloc(p.ctx, &p.d_depth[k], db + 16));
+            if (!p.d_color[k]) PCSCHK(n, p.ctx, pcs_device_malloc(p.ctx, &p.d_color[k], cb + 16));
+            PCSCHK(n, p.ctx, pcs_memcpy_h2d(p.ctx, p.d_depth[k], depth[g], db));
+            PCSCHK(n, p.ctx, pcs_memcpy_h2d(p.ctx, p.d_color[k], color[g], cb));
+            dd[g] = static_cast<const uint16_t*>(p.d_depth[k]);
+            dc[g] = static_cast<const uint8_t*>(p.d_color[k]);
         }
     }
     return PCS_OK;
 }
 
+// Voxel route buffers, on first use: two slots of key / partial arrays per peer (the root's take everybody's partials).
 int ensure_voxel_buffers(pcs_node* n)
 {
-    if (!n->d_vkeys.empty()) return PCS_OK;
-    std::vector<void*> keys(n->n_dev, nullptr), parts(n->n_dev, nullptr), cnt(n->n_dev, nullptr);
-    auto undo = [&]() {
-        for (int r = 0; r < n->n_dev; r++) {
-            (void)hipSetDevice(n->dev[r]);
-            if (keys[r]) pcs_device_free(n->ctx[r], keys[r]);
-            if (parts[r]) pcs_device_free(n->ctx[r], parts[r]);
-            if (cnt[r]) pcs_device_free(n->ctx[r], cnt[r]);
-        }
-    };
-    for (int r = 0; r < n->n_dev; r++) {
-        HIPCHK(n, hipSetDevice(n->dev[r]));
-        const size_t cap = r == 0 ? n->vcap_total : n->vcap[r];        // the root's arrays take everybody's partials
-        if (pcs_device_malloc(n->ctx[r], &keys[r], cap * sizeof(uint64_t) + 64) != PCS_OK ||
-            pcs_device_malloc(n->ctx[r], &parts[r], cap * sizeof(pcs_voxel_partial) + 64) != PCS_OK ||
-            pcs_device_malloc(n->ctx[r], &cnt[r], 64) != PCS_OK) {
-            const int rc = nfail(n, PCS_ERR_NOMEM, "device %d: %s", n->dev[r], pcs_last_error(n->ctx[r]));
-            undo();
-            return rc;
+    if (n->voxel_ready) return PCS_OK;
+    for (int r = 0; r < n->n_peers; r++) {
+        Peer& p = n->peers[r];
+        HIPCHK(n, hipSetDevice(p.dev));
+        const size_t cap = r == 0 ? n->vcap_total : p.vcap;
+        for (int sl = 0; sl < 2; sl++) {
+            if ((!p.d_vkeys[sl] && pcs_device_malloc(p.ctx, &p.d_vkeys[sl], cap * sizeof(uint64_t) + 64) != PCS_OK) ||
+                (!p.d_vparts[sl] && pcs_device_malloc(p.ctx, &p.d_vparts[sl], cap * sizeof(pcs_voxel_partial) + 64) != PCS_OK) ||
+                (!p.d_vcount[sl] && pcs_device_malloc(p.ctx, &p.d_vcount[sl], 64) != PCS_OK))
+                return nfail(n, PCS_ERR_NOMEM, "device %d: %s", p.dev, pcs_last_error(p.ctx));     // (pcs_node_destroy frees what exists)
         }
     }
-    hipError_t e = hipSetDevice(n->dev[0]);
-    if (e == hipSuccess && !n->h_vcount) e = hipHostMalloc((void**)&n->h_vcount, sizeof(int32_t) * (size_t)n->n_dev, hipHostMallocPortable);
-    if (e == hipSuccess && !n->d_vox_n) e = pcs_device_malloc(n->ctx[0], &n->d_vox_n, 64) == PCS_OK ? hipSuccess : hipErrorOutOfMemory;
-    for (int k = 0; k < 4 && e == hipSuccess; k++) if (!n->ev_v[k]) e = hipEventCreate(&n->ev_v[k]);
-    if (e != hipSuccess) { undo(); return nfail(n, PCS_ERR_HIP, "voxel route set-up: %s", hipGetErrorString(e)); }
-    n->d_vkeys = keys; n->d_vparts = parts; n->d_vcount = cnt;
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
+    for (int sl = 0; sl < 2; sl++) {
+        if (!n->h_vcount[sl]) HIPCHK(n, hipHostMalloc((void**)&n->h_vcount[sl], sizeof(int32_t) * (size_t)(n->n_peers + 1), hipHostMallocPortable));
+        if (!n->d_vox_n[sl]) PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_vox_n[sl], 64));
+    }
+    n->voxel_ready = true;
     return PCS_OK;
+}
+
+// Everything the exchange of ticket `tk` needs from the host, then the exchange itself, then (voxel) the root's reduce.
+// Called from submit (no predicate: immediately), from the NEXT submit (after that frame-set's kernels are enqueued) or from
+// wait, whichever comes first. Always leaves drained[slot] recorded on every GPU's communication stream and tk.exchanged
+// set, so that neither a later submit's kernels nor a wait can block on this slot; a failure is parked in tk.rc.
+void issue_exchange(pcs_node* n, Ticket& tk)
+{
+    const int slot = tk.id & 1, S = n->per_dev, P = n->n_peers;
+    Peer& root = n->peers[0];
+    Gpu& rootg = n->gpus[root.gpu];
+    auto body = [&]() -> int {
+        const bool counts_on_device = tk.kind == kVoxel || n->pred;
+        if (counts_on_device) {
+            // the copies were enqueued behind the kernels in submit: by now (a whole submit later in a pipelined loop) they
+            // have usually landed and these waits return at once
+            for (int r = 0; r < P; r++) {
+                HIPCHK(n, hipSetDevice(n->peers[r].dev));
+                HIPCHK(n, hipEventSynchronize(n->peers[r].packed[slot]));
+            }
+        }
+        std::vector<Xfer> xs;
+        size_t off = 0;
+        if (tk.kind == kStitch) {
+            if (n->pred) for (int i = 0; i < P * (S + 1); i++) tk.cnt[i] = n->h_counts[slot][i];
+            for (int r = 0; r < P; r++) {
+                const int32_t c = tk.cnt[(size_t)r * (S + 1) + S];
+                if (c < 0 || (size_t)c * PCS_POINT_SHORTS > n->peers[r].payload_shorts)
+                    return nfail(n, PCS_ERR_HIP, "device %d reported %d points (capacity %zu)", n->peers[r].dev, c, n->peers[r].payload_shorts / PCS_POINT_SHORTS);
+                if (r > 0)
+                    xs.push_back(Xfer{r, n->peers[r].d_payload[slot], reinterpret_cast<int8_t*>(tk.d_stitched) + off * PCS_POINT_BYTES,
+                                      (size_t)c * PCS_POINT_BYTES});
+                off += (size_t)c;
+            }
+        } else {
+            for (int r = 0; r < P; r++) {
+                const int32_t m = n->h_vcount[slot][r];
+                if (m < 0 || (size_t)m > n->peers[r].vcap)
+                    return nfail(n, PCS_ERR_HIP, "device %d reported %d partials (capacity %zu)", n->peers[r].dev, m, n->peers[r].vcap);
+                if (r > 0) {
+                    xs.push_back(Xfer{r, n->peers[r].d_vkeys[slot], static_cast<uint64_t*>(root.d_vkeys[slot]) + off, (size_t)m * sizeof(uint64_t)});
+                    xs.push_back(Xfer{r, n->peers[r].d_vparts[slot], static_cast<pcs_voxel_partial*>(root.d_vparts[slot]) + off,
+                                      (size_t)m * sizeof(pcs_voxel_partial)});
+                    tk.exchanged_bytes += (int64_t)m * PCS_VOXEL_PARTIAL_WIRE_BYTES;
+                }
+                off += (size_t)m;
+            }
+        }
+        tk.total = off;
+        if (tk.kind == kStitch) for (const Xfer& x : xs) tk.exchanged_bytes += (int64_t)x.bytes;
+        // every GPU's communication stream runs behind the kernels of the peers it hosts
+        for (int r = 0; r < P; r++) {
+            Gpu& g = n->gpus[n->peers[r].gpu];
+            HIPCHK(n, hipSetDevice(g.dev));
+            HIPCHK(n, hipStreamWaitEvent(g.comm_stream, n->peers[r].packed[slot], 0));
+        }
+        if (n->timing) { HIPCHK(n, hipSetDevice(rootg.dev)); HIPCHK(n, hipEventRecord(n->ev_x0[slot], rootg.comm_stream)); }
+        if (!(n->node_flags & PCS_NODE_NO_EXCHANGE)) {
+            const int rc = run_exchange(n, xs);
+            if (rc != PCS_OK) return rc;
+        }
+        return PCS_OK;
+    };
+    int rc = body();
+    for (Gpu& g : n->gpus)
+        if (hipSetDevice(g.dev) == hipSuccess) (void)hipEventRecord(g.drained[slot], g.comm_stream);
+    tk.exchanged = true;
+    if (rc == PCS_OK && tk.kind == kVoxel) {
+        // the root reduces everybody's partials behind the exchange; its voxel count travels to page-locked memory
+        auto reduce = [&]() -> int {
+            HIPCHK(n, hipSetDevice(root.dev));
+            hipStream_t ks = kstream(root);
+            HIPCHK(n, hipStreamWaitEvent(ks, rootg.drained[slot], 0));
+            if (n->timing) HIPCHK(n, hipEventRecord(n->ev_r0[slot], ks));
+            PCSCHK(n, root.ctx, pcs_voxel_grid_from_partials_device(root.ctx, static_cast<const uint64_t*>(root.d_vkeys[slot]),
+                                                                    static_cast<const pcs_voxel_partial*>(root.d_vparts[slot]), (int)tk.total,
+                                                                    nullptr, tk.leaf, tk.d_voxels, tk.voxels_shorts,
+                                                                    static_cast<int32_t*>(n->d_vox_n[slot])));
+            HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, ks));
+            HIPCHK(n, hipEventRecord(n->ev_done[slot], ks));
+            return PCS_OK;
+        };
+        rc = reduce();
+    }
+    if (rc != PCS_OK) { tk.rc = rc; tk.err = n->err; }
+}
+
+// The other slot's exchange, if a submit left it pending (predicate / voxel: it waits for device counts).
+void flush_other(pcs_node* n, int slot)
+{
+    Ticket& o = n->inflight[slot ^ 1];
+    if (o.busy && !o.exchanged) issue_exchange(n, o);
+}
+
+int check_submit(pcs_node* n, Ticket*& tk, int& slot)
+{
+    if (n->broken) return nfail(n, PCS_ERR_HIP, "the node's communicators were aborted after an RCCL failure: destroy it");
+    slot = n->next_ticket & 1;
+    tk = &n->inflight[slot];
+    if (tk->busy) return nfail(n, PCS_ERR_CAPACITY, "two frame-sets are in flight: wait for the older one first");
+    return PCS_OK;
+}
+
+void fill_stats(pcs_node* n, const Ticket& tk)
+{
+    pcs_node_stats& st = n->last;
+    std::memset(&st, 0, sizeof st);
+    st.ticket = tk.id;
+    st.exchanged_bytes = tk.exchanged_bytes;
+    st.reduced = (int64_t)tk.total;
+    if (!n->timing) return;
+    const int slot = tk.id & 1;
+    Gpu& rootg = n->gpus[n->peers[0].gpu];
+    if (hipSetDevice(rootg.dev) != hipSuccess) return;
+    (void)hipEventElapsedTime(&st.kernels_ms, n->ev_k0[slot], n->ev_k1[slot]);
+    (void)hipEventElapsedTime(&st.exchange_ms, n->ev_x0[slot], rootg.drained[slot]);
+    if (tk.kind == kVoxel) (void)hipEventElapsedTime(&st.root_ms, n->ev_r0[slot], n->ev_done[slot]);
+    (void)hipGetLastError();
 }
 }  // namespace
 
 extern "C" {
 
 const char* pcs_node_last_error(const pcs_node* n) { return n ? n->err.c_str() : g_err.c_str(); }
-int pcs_node_devices(const pcs_node* n) { return n ? n->n_dev : 0; }
+int pcs_node_devices(const pcs_node* n) { return n ? n->n_peers : 0; }
+int pcs_node_rccl_ranks(const pcs_node* n) { return (n && n->have_comm) ? (int)n->gpus.size() : 0; }
 
 size_t pcs_node_max_payload_shorts(const pcs_node* n)
 {
     if (!n) return 0;
     size_t s = 0;
-    for (pcs_ctx* c : n->ctx) s += pcs_max_payload_shorts(c);
+    for (const Peer& p : n->peers) s += p.payload_shorts;
     return s;
 }
 
 void pcs_node_destroy(pcs_node* n)
 {
     if (!n) return;
-    for (size_t r = 0; r < n->ctx.size(); r++) {
-        if (!n->ctx[r]) continue;
-        (void)hipSetDevice(n->dev[r]);
-        if (r < n->comm_stream.size() && n->comm_stream[r]) (void)hipStreamSynchronize(n->comm_stream[r]);
+    for (Gpu& g : n->gpus) {
+        (void)hipSetDevice(g.dev);
+        if (g.comm_stream) (void)hipStreamSynchronize(g.comm_stream);
+    }
+    for (size_t r = 0; r < n->peers.size(); r++) {
+        Peer& p = n->peers[r];
+        if (!p.ctx) continue;
+        (void)hipSetDevice(p.dev);
+        (void)pcs_synchronize(p.ctx);
         for (int sl = 0; sl < 2; sl++) {
-            if (r < n->d_payload[sl].size() && n->d_payload[sl][r]) pcs_device_free(n->ctx[r], n->d_payload[sl][r]);
-            if (r < n->packed[sl].size() && n->packed[sl][r]) (void)hipEventDestroy(n->packed[sl][r]);
-            if (r < n->drained[sl].size() && n->drained[sl][r]) (void)hipEventDestroy(n->drained[sl][r]);
+            if (p.d_payload[sl]) pcs_device_free(p.ctx, p.d_payload[sl]);
+            if (p.d_vkeys[sl]) pcs_device_free(p.ctx, p.d_vkeys[sl]);
+            if (p.d_vparts[sl]) pcs_device_free(p.ctx, p.d_vparts[sl]);
+            if (p.d_vcount[sl]) pcs_device_free(p.ctx, p.d_vcount[sl]);
+            if (p.packed[sl]) (void)hipEventDestroy(p.packed[sl]);
         }
-        if (r < n->comm_stream.size() && n->comm_stream[r]) (void)hipStreamDestroy(n->comm_stream[r]);
-        if (r < n->d_counts.size() && n->d_counts[r]) pcs_device_free(n->ctx[r], n->d_counts[r]);
-        for (int k = 0; k < n->per_dev && r < n->d_depth.size(); k++) {
-            if (k < (int)n->d_depth[r].size() && n->d_depth[r][k]) pcs_device_free(n->ctx[r], n->d_depth[r][k]);
-            if (k < (int)n->d_color[r].size() && n->d_color[r][k]) pcs_device_free(n->ctx[r], n->d_color[r][k]);
-        }
-        if (r < n->d_vkeys.size() && n->d_vkeys[r]) pcs_device_free(n->ctx[r], n->d_vkeys[r]);
-        if (r < n->d_vparts.size() && n->d_vparts[r]) pcs_device_free(n->ctx[r], n->d_vparts[r]);
-        if (r < n->d_vcount.size() && n->d_vcount[r]) pcs_device_free(n->ctx[r], n->d_vcount[r]);
+        if (p.d_counts) pcs_device_free(p.ctx, p.d_counts);
+        for (void* q : p.d_depth) if (q) pcs_device_free(p.ctx, q);
+        for (void* q : p.d_color) if (q) pcs_device_free(p.ctx, q);
         if (r == 0) {
-            if (n->d_stitched) pcs_device_free(n->ctx[0], n->d_stitched);
-            if (n->d_vox_out) pcs_device_free(n->ctx[0], n->d_vox_out);
-            if (n->d_vox_n) pcs_device_free(n->ctx[0], n->d_vox_n);
-            for (hipEvent_t e : n->ev_v) if (e) (void)hipEventDestroy(e);
+            if (n->d_stitched) pcs_device_free(p.ctx, n->d_stitched);
+            if (n->d_vox_out) pcs_device_free(p.ctx, n->d_vox_out);
+            for (int sl = 0; sl < 2; sl++) {
+                if (n->d_vox_n[sl]) pcs_device_free(p.ctx, n->d_vox_n[sl]);
+                for (hipEvent_t e : {n->ev_k0[sl], n->ev_k1[sl], n->ev_r0[sl], n->ev_done[sl], n->ev_x0[sl]}) if (e) (void)hipEventDestroy(e);
+            }
         }
     }
-    for (int sl = 0; sl < 2; sl++) if (n->h_counts[sl]) (void)hipHostFree(n->h_counts[sl]);
-    if (n->h_vcount) (void)hipHostFree(n->h_vcount);
-    for (ncclComm_t c : n->comm) if (c) (void)ncclCommDestroy(c);
-    for (pcs_ctx* c : n->ctx) if (c) pcs_destroy(c);
+    for (Gpu& g : n->gpus) {
+        (void)hipSetDevice(g.dev);
+        for (int sl = 0; sl < 2; sl++) if (g.drained[sl]) (void)hipEventDestroy(g.drained[sl]);
+        if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
+        if (g.comm) (void)ncclCommDestroy(g.comm);
+    }
+    for (int sl = 0; sl < 2; sl++) {
+        if (n->h_counts[sl]) (void)hipHostFree(n->h_counts[sl]);
+        if (n->h_vcount[sl]) (void)hipHostFree(n->h_vcount[sl]);
+    }
+    for (Peer& p : n->peers) if (p.ctx) pcs_destroy(p.ctx);
     delete n;
 }
 
-int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
-                    const pcs_stream_config* streams, uint32_t flags, int downsample)
+int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
+                       const pcs_stream_config* streams, uint32_t flags, int downsample, uint32_t node_flags)
 {
     g_err.clear();
     if (!out) return nfail(nullptr, PCS_ERR_INVALID_ARG, "out is NULL");
@@ -223,152 +390,195 @@ int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int st
         if (device_ids[r] < 0 || device_ids[r] >= avail)
             return nfail(nullptr, PCS_ERR_NO_DEVICE, "device %d requested, %d available", device_ids[r], avail);
     pcs_node* n = new pcs_node;
-    n->n_dev = n_devices; n->per_dev = streams_per_device; n->n_streams = n_devices * streams_per_device;
-    n->flags = flags; n->downsample = downsample;
-    n->dev.assign(device_ids, device_ids + n_devices);
+    n->n_peers = n_devices; n->per_dev = streams_per_device; n->n_streams = n_devices * streams_per_device;
+    n->flags = flags; n->downsample = downsample; n->node_flags = node_flags;
     n->cfg.assign(streams, streams + n->n_streams);
-    n->ctx.assign(n_devices, nullptr);
-    n->payload_shorts.assign(n_devices, 0); n->d_counts.assign(n_devices, nullptr);
-    n->comm_stream.assign(n_devices, nullptr);
-    n->vcap.assign(n_devices, 0);
-    for (int sl = 0; sl < 2; sl++) {
-        n->d_payload[sl].assign(n_devices, nullptr);
-        n->packed[sl].assign(n_devices, nullptr); n->drained[sl].assign(n_devices, nullptr);
-    }
     n->pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
-    n->d_depth.assign(n_devices, std::vector<void*>(streams_per_device, nullptr));
-    n->d_color.assign(n_devices, std::vector<void*>(streams_per_device, nullptr));
+    n->peers.resize(n_devices);
     for (int r = 0; r < n_devices; r++) {
+        Peer& p = n->peers[r];
+        p.dev = device_ids[r];
+        p.gpu = -1;
+        for (size_t g = 0; g < n->gpus.size(); g++) if (n->gpus[g].dev == p.dev) p.gpu = (int)g;
+        if (p.gpu < 0) { p.gpu = (int)n->gpus.size(); Gpu g; g.dev = p.dev; n->gpus.push_back(g); }
+        p.d_depth.assign(streams_per_device, nullptr); p.d_color.assign(streams_per_device, nullptr);
+    }
+    auto bail = [&](int rc, const char* what, const char* detail) {
+        const int e = nfail(nullptr, rc, "%s: %s", what, detail);
+        pcs_node_destroy(n);
+        return e;
+    };
+    for (int r = 0; r < n_devices; r++) {
+        Peer& p = n->peers[r];
         pcs_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
-        cfg.device = device_ids[r]; cfg.n_streams = streams_per_device; cfg.streams = streams + (size_t)r * streams_per_device;
+        cfg.device = p.dev; cfg.n_streams = streams_per_device; cfg.streams = streams + (size_t)r * streams_per_device;
         cfg.flags = flags; cfg.downsample = downsample;
-        int rc = pcs_create(&n->ctx[r], &cfg);
-        if (rc != PCS_OK) { int e = nfail(nullptr, rc, "device %d: %s", device_ids[r], pcs_last_error(nullptr)); pcs_node_destroy(n); return e; }
-        n->payload_shorts[r] = pcs_max_payload_shorts(n->ctx[r]);
-        n->vcap[r] = n->payload_shorts[r] / PCS_POINT_SHORTS;
-        n->vcap_total += n->vcap[r];
-        if (pcs_device_malloc(n->ctx[r], &n->d_counts[r], sizeof(int32_t) * (streams_per_device + 1)) != PCS_OK ||
-            (r > 0 && (pcs_device_malloc(n->ctx[r], &n->d_payload[0][r], n->payload_shorts[r] * sizeof(int16_t) + 64) != PCS_OK ||
-                       pcs_device_malloc(n->ctx[r], &n->d_payload[1][r], n->payload_shorts[r] * sizeof(int16_t) + 64) != PCS_OK))) {
-            int e = nfail(nullptr, PCS_ERR_NOMEM, "device %d: %s", device_ids[r], pcs_last_error(n->ctx[r])); pcs_node_destroy(n); return e;
-        }
-        hipError_t he = hipSetDevice(device_ids[r]);
-        if (he == hipSuccess) he = hipStreamCreateWithFlags(&n->comm_stream[r], hipStreamNonBlocking);
+        const int rc = pcs_create(&p.ctx, &cfg);
+        if (rc != PCS_OK) return bail(rc, "pcs_create", pcs_last_error(nullptr));
+        p.payload_shorts = pcs_max_payload_shorts(p.ctx);
+        p.vcap = p.payload_shorts / PCS_POINT_SHORTS;
+        n->vcap_total += p.vcap;
+        if (pcs_device_malloc(p.ctx, &p.d_counts, sizeof(int32_t) * (streams_per_device + 1)) != PCS_OK ||
+            (r > 0 && (pcs_device_malloc(p.ctx, &p.d_payload[0], p.payload_shorts * sizeof(int16_t) + 64) != PCS_OK ||
+                       pcs_device_malloc(p.ctx, &p.d_payload[1], p.payload_shorts * sizeof(int16_t) + 64) != PCS_OK)))
+            return bail(PCS_ERR_NOMEM, "device memory", pcs_last_error(p.ctx));
+        hipError_t he = hipSetDevice(p.dev);
+        for (int sl = 0; sl < 2 && he == hipSuccess; sl++) he = hipEventCreateWithFlags(&p.packed[sl], hipEventDisableTiming);
+        if (he != hipSuccess) return bail(PCS_ERR_HIP, "event", hipGetErrorString(he));
+    }
+    for (Gpu& g : n->gpus) {
+        hipError_t he = hipSetDevice(g.dev);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking);
+        for (int sl = 0; sl < 2 && he == hipSuccess; sl++) he = hipEventCreate(&g.drained[sl]);
+        if (he != hipSuccess) return bail(PCS_ERR_HIP, "communication stream", hipGetErrorString(he));
+    }
+    {
+        hipError_t he = hipSetDevice(n->peers[0].dev);
         for (int sl = 0; sl < 2 && he == hipSuccess; sl++) {
-            he = hipEventCreateWithFlags(&n->packed[sl][r], hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&n->drained[sl][r], hipEventDisableTiming);
+            he = hipEventCreate(&n->ev_k0[sl]);
+            if (he == hipSuccess) he = hipEventCreate(&n->ev_k1[sl]);
+            if (he == hipSuccess) he = hipEventCreate(&n->ev_r0[sl]);
+            if (he == hipSuccess) he = hipEventCreate(&n->ev_done[sl]);
+            if (he == hipSuccess) he = hipEventCreate(&n->ev_x0[sl]);
+            if (he == hipSuccess) he = hipHostMalloc((void**)&n->h_counts[sl], sizeof(int32_t) * (size_t)n_devices * (streams_per_device + 1),
+                                                     hipHostMallocPortable);
         }
-        if (he != hipSuccess) { int e = nfail(nullptr, PCS_ERR_HIP, "device %d: %s", device_ids[r], hipGetErrorString(he)); pcs_node_destroy(n); return e; }
+        if (he != hipSuccess) return bail(PCS_ERR_HIP, "root events / page-locked counts", hipGetErrorString(he));
     }
-    for (int sl = 0; sl < 2; sl++) {
-        const hipError_t he = hipHostMalloc((void**)&n->h_counts[sl], sizeof(int32_t) * (size_t)n_devices * (streams_per_device + 1),
-                                            hipHostMallocPortable);
-        if (he != hipSuccess) { int e = nfail(nullptr, PCS_ERR_NOMEM, "hipHostMalloc: %s", hipGetErrorString(he)); pcs_node_destroy(n); return e; }
-    }
-    if (n_devices > 1) {       // one communicator per GPU, all in this process
-        n->comm.assign(n_devices, nullptr);
-        ncclResult_t r = ncclCommInitAll(n->comm.data(), n_devices, device_ids);
-        if (r != ncclSuccess) { int e = nfail(nullptr, PCS_ERR_HIP, "ncclCommInitAll: %s", ncclGetErrorString(r)); pcs_node_destroy(n); return e; }
+    if (n_devices > 1 && !(node_flags & PCS_NODE_NO_EXCHANGE)) {
+        // one communicator rank per GPU, all in this process; virtual peers share their GPU's rank
+        std::vector<int> ids;
+        std::vector<ncclComm_t> comms(n->gpus.size(), nullptr);
+        for (const Gpu& g : n->gpus) ids.push_back(g.dev);
+        const ncclResult_t r = ncclCommInitAll(comms.data(), (int)ids.size(), ids.data());
+        if (r != ncclSuccess) return bail(PCS_ERR_HIP, "ncclCommInitAll", ncclGetErrorString(r));
+        for (size_t g = 0; g < n->gpus.size(); g++) n->gpus[g].comm = comms[g];
+        n->have_comm = true;
     }
     *out = n;
     return PCS_OK;
 }
 
-// Pipelined device form. Per submit, in this order:
-//   1. every GPU r: kernel stream waits for drained[slot][r] (the exchange that last read this payload slot), then
-//      pcs_process_frames_device packs its cameras (the root straight into the head of the stitched buffer);
-//   2. counts: from the configuration, or — with a predicate — one hipMemcpyAsync per GPU into page-locked memory, all in
-//      flight together, then one hipStreamSynchronize per GPU;
-//   3. every GPU r: packed[slot][r] recorded on the kernel stream, its communication stream waits for it;
-//   4. ONE group: rank r ncclSend()s its payload, the root ncclRecv()s it at its camera-order offset, on the
-//      communication streams — so the kernels of the NEXT frame-set (other payload slot) overlap it; the group is closed
-//      on every path;
-//   5. drained[slot][r] recorded on every communication stream — also when step 4 failed, so pcs_node_wait never blocks.
+int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
+                    const pcs_stream_config* streams, uint32_t flags, int downsample)
+{
+    return pcs_node_create_ex(out, n_devices, device_ids, streams_per_device, streams, flags, downsample, 0u);
+}
+
+int pcs_node_set_timing(pcs_node* n, int enable)
+{
+    if (!n) return PCS_ERR_INVALID_ARG;
+    n->timing = enable != 0;
+    return PCS_OK;
+}
+
+int pcs_node_last_stats(const pcs_node* n, pcs_node_stats* out)
+{
+    if (!n || !out) return PCS_ERR_INVALID_ARG;
+    *out = n->last;
+    return PCS_OK;
+}
+
+// Pipelined device form. Per submit:
+//   1. every peer r: its kernel stream waits for drained[slot] of its GPU (the exchange that last read this payload slot),
+//      pcs_process_frames_device packs its cameras (the root straight into the head of the stitched buffer); with a
+//      predicate the counts follow on the same stream into page-locked memory; packed[slot][r] is recorded;
+//   2. the OTHER slot's exchange, if it was left pending, is issued now — its kernels were enqueued a whole submit ago, so
+//      the wait for its counts is (normally) over before it starts, and this frame-set's kernels are already queued behind;
+//   3. without a predicate the counts follow from the configuration and this slot's exchange is issued at once; with one it
+//      stays pending until the next submit or pcs_node_wait.
+// The exchange itself (issue_exchange): every GPU's communication stream waits for packed[slot] of its peers, ONE group —
+// peer r ncclSend()s its payload, the root ncclRecv()s it at its camera-order offset — and drained[slot] is recorded on
+// every communication stream on every path.
 int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                            int16_t* d_stitched, size_t stitched_shorts, int* ticket)
 {
     if (!n || !d_depth || !d_color || !d_stitched || !ticket) return nfail(n, PCS_ERR_INVALID_ARG, "NULL pointer");
-    if (n->broken) return nfail(n, PCS_ERR_HIP, "the node's communicators were aborted after an RCCL failure: destroy it");
     if (stitched_shorts < pcs_node_max_payload_shorts(n))
         return nfail(n, PCS_ERR_CAPACITY, "stitched payload holds %zu shorts, %zu needed", stitched_shorts, pcs_node_max_payload_shorts(n));
-    const int slot = n->next_ticket & 1;
-    pcs_node::Ticket& tk = n->inflight[slot];
-    if (tk.busy) return nfail(n, PCS_ERR_CAPACITY, "two frame-sets are in flight: pcs_node_wait() the older one first");
-    const int S = n->per_dev;
-    tk.cnt.assign(n->n_dev, std::vector<int32_t>(S + 1, 0));
-    // 1. every GPU packs its cameras (its payload slot was drained by the exchange two submits ago)
-    for (int r = 0; r < n->n_dev; r++) {
-        HIPCHK(n, hipSetDevice(n->dev[r]));
-        hipStream_t ks = kstream(n, r);
-        HIPCHK(n, hipStreamWaitEvent(ks, n->drained[slot][r], 0));
-        int16_t* dst = r == 0 ? d_stitched : static_cast<int16_t*>(n->d_payload[slot][r]);
-        PCSCHK(n, n->ctx[r], pcs_process_frames_device(n->ctx[r], d_depth + (size_t)r * S, d_color + (size_t)r * S, dst,
-                                                       r == 0 ? stitched_shorts : n->payload_shorts[r],
-                                                       n->pred ? static_cast<int32_t*>(n->d_counts[r]) : nullptr));
+    Ticket* tkp = nullptr; int slot = 0;
+    int rc = check_submit(n, tkp, slot);
+    if (rc != PCS_OK) return rc;
+    Ticket& tk = *tkp;
+    const int S = n->per_dev, P = n->n_peers;
+    tk = Ticket{};
+    tk.cnt.assign((size_t)P * (S + 1), 0);
+    tk.kind = kStitch; tk.d_stitched = d_stitched; tk.id = n->next_ticket;
+    // 1. kernels. A failure here leaves the ticket free and the slot's drained events as they were (complete): the kernels
+    //    already enqueued write payload slots nothing will read, and the next submit simply reuses the slot.
+    for (int r = 0; r < P; r++) {
+        Peer& p = n->peers[r];
+        HIPCHK(n, hipSetDevice(p.dev));
+        hipStream_t ks = kstream(p);
+        HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
+        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
+        int16_t* dst = r == 0 ? d_stitched : static_cast<int16_t*>(p.d_payload[slot]);
+        PCSCHK(n, p.ctx, pcs_process_frames_device(p.ctx, d_depth + (size_t)r * S, d_color + (size_t)r * S, dst,
+                                                   r == 0 ? stitched_shorts : p.payload_shorts,
+                                                   n->pred ? static_cast<int32_t*>(p.d_counts) : nullptr));
+        if (n->pred)
+            HIPCHK(n, hipMemcpyAsync(n->h_counts[slot] + (size_t)r * (S + 1), p.d_counts, sizeof(int32_t) * (S + 1), hipMemcpyDeviceToHost, ks));
+        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
+        HIPCHK(n, hipEventRecord(p.packed[slot], ks));
     }
-    // 2. counts: known from the configuration unless a predicate makes them data dependent
-    if (n->pred) {
-        int32_t* hc = n->h_counts[slot];
-        for (int r = 0; r < n->n_dev; r++) {
-            HIPCHK(n, hipSetDevice(n->dev[r]));
-            HIPCHK(n, hipMemcpyAsync(hc + (size_t)r * (S + 1), n->d_counts[r], sizeof(int32_t) * (S + 1), hipMemcpyDeviceToHost, kstream(n, r)));
-        }
-        for (int r = 0; r < n->n_dev; r++) {
-            HIPCHK(n, hipSetDevice(n->dev[r]));
-            HIPCHK(n, hipStreamSynchronize(kstream(n, r)));
-            for (int k = 0; k <= S; k++) tk.cnt[r][k] = hc[(size_t)r * (S + 1) + k];
-        }
-    } else {
-        for (int r = 0; r < n->n_dev; r++) {
+    tk.busy = true;
+    *ticket = n->next_ticket++;
+    // 2. the older frame-set's exchange, if it was waiting for its counts
+    flush_other(n, slot);
+    // 3. this frame-set's, when nothing on the device sizes it
+    if (!n->pred) {
+        for (int r = 0; r < P; r++) {
             int64_t tot = 0;
             for (int k = 0; k < S; k++) {
-                tk.cnt[r][k] = (pcs_stream_points(n->ctx[r], k) + n->downsample - 1) / n->downsample;
-                tot += tk.cnt[r][k];
+                const int32_t c = (pcs_stream_points(n->peers[r].ctx, k) + n->downsample - 1) / n->downsample;
+                tk.cnt[(size_t)r * (S + 1) + k] = c;
+                tot += c;
             }
-            tk.cnt[r][S] = (int32_t)tot;
+            tk.cnt[(size_t)r * (S + 1) + S] = (int32_t)tot;
+        }
+        issue_exchange(n, tk);
+        if (tk.rc != PCS_OK) {          // report it here; the ticket is gone (its drained events are recorded)
+            tk.busy = false;
+            n->err = tk.err;
+            return tk.rc;
         }
     }
-    // 3. the exchange runs on the communication streams, behind each GPU's kernel
-    for (int r = 0; r < n->n_dev; r++) {
-        HIPCHK(n, hipSetDevice(n->dev[r]));
-        HIPCHK(n, hipEventRecord(n->packed[slot][r], kstream(n, r)));
-        HIPCHK(n, hipStreamWaitEvent(n->comm_stream[r], n->packed[slot][r], 0));
+    return PCS_OK;
+}
+
+static int wait_common(pcs_node* n, int ticket, int kind, Ticket*& out)
+{
+    if (!n) return PCS_ERR_INVALID_ARG;
+    Ticket& tk = n->inflight[ticket & 1];
+    if (ticket < 0 || ticket >= n->next_ticket || !tk.busy || tk.id != ticket || tk.kind != kind)
+        return nfail(n, PCS_ERR_INVALID_ARG, "ticket %d is not in flight", ticket);
+    if (!tk.exchanged) issue_exchange(n, tk);
+    tk.busy = false;                                    // whatever happens below, the slot is free again
+    out = &tk;
+    const int slot = ticket & 1;
+    for (Gpu& g : n->gpus) {
+        HIPCHK(n, hipSetDevice(g.dev));
+        HIPCHK(n, hipEventSynchronize(g.drained[slot]));
     }
-    // 4. one group
-    size_t off = (size_t)tk.cnt[0][S];          // points
-    std::vector<Xfer> xs;
-    for (int r = 1; r < n->n_dev; r++) {
-        xs.push_back(Xfer{r, n->d_payload[slot][r], reinterpret_cast<int8_t*>(d_stitched) + off * PCS_POINT_BYTES,
-                          (size_t)tk.cnt[r][S] * PCS_POINT_BYTES});
-        off += (size_t)tk.cnt[r][S];
-    }
-    const int xrc = run_exchange(n, xs);
-    // 5. drained events: always, so that neither the next submit's kernels nor pcs_node_wait can block on this slot
-    for (int r = 0; r < n->n_dev; r++) {
-        if (hipSetDevice(n->dev[r]) == hipSuccess) (void)hipEventRecord(n->drained[slot][r], n->comm_stream[r]);
-    }
-    if (xrc != PCS_OK) return xrc;
-    tk.total = off; tk.slot = slot; tk.busy = true;
-    *ticket = n->next_ticket++;
+    if (tk.rc != PCS_OK) { n->err = tk.err; return tk.rc; }
     return PCS_OK;
 }
 
 int pcs_node_wait(pcs_node* n, int ticket, int* points_per_stream, int* total_points)
 {
-    if (!n) return PCS_ERR_INVALID_ARG;
-    pcs_node::Ticket& tk = n->inflight[ticket & 1];
-    if (ticket < 0 || ticket >= n->next_ticket || ticket < n->next_ticket - 2 || !tk.busy)
-        return nfail(n, PCS_ERR_INVALID_ARG, "ticket %d is not in flight", ticket);
+    Ticket* tk = nullptr;
+    const int rc = wait_common(n, ticket, kStitch, tk);
+    if (rc != PCS_OK) return rc;
     const int S = n->per_dev;
-    tk.busy = false;                                    // whatever happens below, the slot is free again
-    for (int r = 0; r < n->n_dev; r++) {
-        HIPCHK(n, hipSetDevice(n->dev[r]));
-        HIPCHK(n, hipEventSynchronize(n->drained[tk.slot][r]));
+    if (n->timing) {            // the root's own kernels may still be running when the peers' payloads have landed
+        HIPCHK(n, hipSetDevice(n->peers[0].dev));
+        HIPCHK(n, hipEventSynchronize(n->peers[0].packed[ticket & 1]));
     }
     if (points_per_stream)
-        for (int r = 0; r < n->n_dev; r++) for (int k = 0; k < S; k++) points_per_stream[r * S + k] = tk.cnt[r][k];
-    if (total_points) *total_points = (int)tk.total;
+        for (int r = 0; r < n->n_peers; r++) for (int k = 0; k < S; k++) points_per_stream[r * S + k] = tk->cnt[(size_t)r * (S + 1) + k];
+    if (total_points) *total_points = (int)tk->total;
+    fill_stats(n, *tk);
     return PCS_OK;
 }
 
@@ -392,127 +602,139 @@ int pcs_node_process(pcs_node* n, const uint16_t* const* depth, const uint8_t* c
     std::vector<const uint8_t*> dc;
     int rc = upload_rasters(n, depth, color, dd, dc);
     if (rc != PCS_OK) return rc;
-    HIPCHK(n, hipSetDevice(n->dev[0]));
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
     if (!n->d_stitched) {
-        PCSCHK(n, n->ctx[0], pcs_device_malloc(n->ctx[0], &n->d_stitched, max_sh * sizeof(int16_t) + 64));
+        PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_stitched, max_sh * sizeof(int16_t) + 64));
         n->stitched_cap_shorts = max_sh;
     }
     int total = 0;
     rc = pcs_node_process_device(n, dd.data(), dc.data(), static_cast<int16_t*>(n->d_stitched), n->stitched_cap_shorts,
                                  points_per_stream, &total);
     if (rc != PCS_OK) return rc;
-    HIPCHK(n, hipSetDevice(n->dev[0]));
+    HIPCHK(n, hipSetDevice(root.dev));
     const int32_t size = (int32_t)((size_t)total * PCS_POINT_BYTES);
-    if (size) PCSCHK(n, n->ctx[0], pcs_memcpy_d2h(n->ctx[0], stitched + PCS_HEADER_SHORTS, n->d_stitched, (size_t)size));
+    if (size) PCSCHK(n, root.ctx, pcs_memcpy_d2h(root.ctx, stitched + PCS_HEADER_SHORTS, n->d_stitched, (size_t)size));
     if (write_header) std::memcpy(stitched, &size, sizeof size);
     if (out_size_bytes) *out_size_bytes = size;
     return PCS_OK;
 }
 
 // ---- config 5: voxel grid of the node's stitched cloud -----------------------------------------------------------------
-// Route PARTIALS, per call:
-//   1. every GPU r: pcs_process_frames_voxel_partials_device on its kernel stream (the root appends to the head of the
-//      merged key / partial arrays), then one asynchronous 4-byte read-back of its partial count;
-//   2. one wait per GPU for the counts (they size the exchange), exclusive scan on the host;
-//   3. ONE group on the communication streams: rank r ncclSend()s m_r keys and m_r partials, the root ncclRecv()s them
-//      behind its own (and the earlier ranks') partials;
-//   4. the root's kernel stream waits for its communication stream, then pcs_voxel_grid_from_partials_device over all
-//      M = sum m_r partials; the voxel count is read back.
+// Route PARTIALS, pipelined. Per submit:
+//   1. every peer r: kernel stream waits for drained[slot] of its GPU, pcs_process_frames_voxel_partials_device into slot's
+//      key / partial arrays (the root appends to the head of its merged arrays), one asynchronous 4-byte read-back of the
+//      partial count into page-locked memory, packed[slot][r];
+//   2. the other slot's pending exchange + reduce are issued (its counts have landed by now);
+// and the exchange of THIS slot stays pending until the next submit or pcs_node_wait_voxel: ONE group on the communication
+// streams (peer r ncclSend()s m_r keys and m_r partials, the root ncclRecv()s them behind its own and the earlier peers'),
+// then, on the root's kernel stream behind it, pcs_voxel_grid_from_partials_device over all M = sum m_r partials and the
+// read-back of the voxel count. So the pre-aggregation of frame-set k+1 overlaps the exchange and the root's sort of k.
+int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
+                                 int16_t* d_voxels, size_t voxels_shorts, int* ticket)
+{
+    if (!n || !d_depth || !d_color || !d_voxels || !ticket) return nfail(n, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (leaf_mm < 1 || leaf_mm > 32767) return nfail(n, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
+    if (voxels_shorts < pcs_node_max_payload_shorts(n))
+        return nfail(n, PCS_ERR_CAPACITY, "voxel buffer holds %zu shorts; the worst case (every point its own voxel) needs %zu",
+                     voxels_shorts, pcs_node_max_payload_shorts(n));
+    Ticket* tkp = nullptr; int slot = 0;
+    int rc = check_submit(n, tkp, slot);
+    if (rc != PCS_OK) return rc;
+    rc = ensure_voxel_buffers(n);
+    if (rc != PCS_OK) return rc;
+    Ticket& tk = *tkp;
+    const int S = n->per_dev, P = n->n_peers;
+    tk = Ticket{};
+    tk.kind = kVoxel; tk.id = n->next_ticket; tk.leaf = leaf_mm; tk.d_voxels = d_voxels; tk.voxels_shorts = voxels_shorts;
+    for (int r = 0; r < P; r++) {
+        Peer& p = n->peers[r];
+        HIPCHK(n, hipSetDevice(p.dev));
+        hipStream_t ks = kstream(p);
+        HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
+        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
+        PCSCHK(n, p.ctx, pcs_process_frames_voxel_partials_device(p.ctx, d_depth + (size_t)r * S, d_color + (size_t)r * S, leaf_mm,
+                                                                  static_cast<uint64_t*>(p.d_vkeys[slot]),
+                                                                  static_cast<pcs_voxel_partial*>(p.d_vparts[slot]),
+                                                                  r == 0 ? n->vcap_total : p.vcap, static_cast<int32_t*>(p.d_vcount[slot])));
+        HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + r, p.d_vcount[slot], sizeof(int32_t), hipMemcpyDeviceToHost, ks));
+        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
+        HIPCHK(n, hipEventRecord(p.packed[slot], ks));
+    }
+    tk.busy = true;
+    *ticket = n->next_ticket++;
+    flush_other(n, slot);
+    return PCS_OK;
+}
+
+int pcs_node_wait_voxel(pcs_node* n, int ticket, int* n_voxels)
+{
+    Ticket* tk = nullptr;
+    const int rc = wait_common(n, ticket, kVoxel, tk);
+    if (rc != PCS_OK) return rc;
+    HIPCHK(n, hipSetDevice(n->peers[0].dev));
+    HIPCHK(n, hipEventSynchronize(n->ev_done[ticket & 1]));
+    if (n_voxels) *n_voxels = n->h_vcount[ticket & 1][n->n_peers];
+    fill_stats(n, *tk);
+    return PCS_OK;
+}
+
 int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int route, int16_t* d_voxels, size_t voxels_shorts, int* n_voxels, pcs_node_voxel_stats* stats)
 {
     if (!n || !d_depth || !d_color || !d_voxels || !n_voxels) return nfail(n, PCS_ERR_INVALID_ARG, "NULL pointer");
-    if (n->broken) return nfail(n, PCS_ERR_HIP, "the node's communicators were aborted after an RCCL failure: destroy it");
     if (leaf_mm < 1 || leaf_mm > 32767) return nfail(n, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
     if (route != PCS_NODE_VOXEL_PARTIALS && route != PCS_NODE_VOXEL_PAYLOADS) return nfail(n, PCS_ERR_INVALID_ARG, "unknown route %d", route);
     if (voxels_shorts < pcs_node_max_payload_shorts(n))
         return nfail(n, PCS_ERR_CAPACITY, "voxel buffer holds %zu shorts; the worst case (every point its own voxel) needs %zu",
                      voxels_shorts, pcs_node_max_payload_shorts(n));
     if (n->inflight[0].busy || n->inflight[1].busy)
-        return nfail(n, PCS_ERR_INVALID_ARG, "pcs_node_wait() the frame-sets in flight before a voxel call");
-    int rc = ensure_voxel_buffers(n);
-    if (rc != PCS_OK) return rc;
-    const int S = n->per_dev;
-    HIPCHK(n, hipSetDevice(n->dev[0]));
-    HIPCHK(n, hipEventRecord(n->ev_v[0], kstream(n, 0)));
-    int64_t reduced = 0, exchanged = 0;
-
-    if (route == PCS_NODE_VOXEL_PAYLOADS) {
+        return nfail(n, PCS_ERR_INVALID_ARG, "wait for the frame-sets in flight before a synchronous voxel call");
+    const bool was_timing = n->timing;
+    n->timing = n->timing || stats != nullptr;
+    struct Restore { pcs_node* n; bool t; ~Restore() { n->timing = t; } } restore{n, was_timing};
+    int rc, ticket = -1, nv = 0;
+    pcs_node_stats st{};
+    if (route == PCS_NODE_VOXEL_PARTIALS) {
+        rc = pcs_node_submit_voxel_device(n, d_depth, d_color, leaf_mm, d_voxels, voxels_shorts, &ticket);
+        if (rc != PCS_OK) return rc;
+        rc = pcs_node_wait_voxel(n, ticket, &nv);
+        if (rc != PCS_OK) return rc;
+        st = n->last;
+    } else {
         // the reference's shape: camera-order concatenation of the (compacted) payloads on the root, downsample there
+        rc = ensure_voxel_buffers(n);
+        if (rc != PCS_OK) return rc;
+        Peer& root = n->peers[0];
         const size_t max_sh = pcs_node_max_payload_shorts(n);
+        HIPCHK(n, hipSetDevice(root.dev));
         if (!n->d_stitched) {
-            PCSCHK(n, n->ctx[0], pcs_device_malloc(n->ctx[0], &n->d_stitched, max_sh * sizeof(int16_t) + 64));
+            PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_stitched, max_sh * sizeof(int16_t) + 64));
             n->stitched_cap_shorts = max_sh;
         }
-        int ticket = -1, total = 0;
+        int total = 0;
         rc = pcs_node_submit_device(n, d_depth, d_color, static_cast<int16_t*>(n->d_stitched), n->stitched_cap_shorts, &ticket);
         if (rc != PCS_OK) return rc;
-        HIPCHK(n, hipSetDevice(n->dev[0]));
-        HIPCHK(n, hipEventRecord(n->ev_v[1], kstream(n, 0)));
         rc = pcs_node_wait(n, ticket, nullptr, &total);
         if (rc != PCS_OK) return rc;
-        HIPCHK(n, hipSetDevice(n->dev[0]));
-        HIPCHK(n, hipEventRecord(n->ev_v[2], n->comm_stream[0]));
-        HIPCHK(n, hipStreamWaitEvent(kstream(n, 0), n->ev_v[2], 0));
-        PCSCHK(n, n->ctx[0], pcs_voxel_grid_device(n->ctx[0], static_cast<const int16_t*>(n->d_stitched), total, leaf_mm, d_voxels,
-                                                   voxels_shorts, static_cast<int32_t*>(n->d_vox_n)));
-        reduced = total;
-        exchanged = ((int64_t)total - (int64_t)n->inflight[ticket & 1].cnt[0][S]) * PCS_POINT_BYTES;
-    } else {
-        // 1. pre-aggregation on every GPU
-        for (int r = 0; r < n->n_dev; r++) {
-            HIPCHK(n, hipSetDevice(n->dev[r]));
-            PCSCHK(n, n->ctx[r], pcs_process_frames_voxel_partials_device(
-                                     n->ctx[r], d_depth + (size_t)r * S, d_color + (size_t)r * S, leaf_mm,
-                                     static_cast<uint64_t*>(n->d_vkeys[r]), static_cast<pcs_voxel_partial*>(n->d_vparts[r]),
-                                     r == 0 ? n->vcap_total : n->vcap[r], static_cast<int32_t*>(n->d_vcount[r])));
-            HIPCHK(n, hipMemcpyAsync(n->h_vcount + r, n->d_vcount[r], sizeof(int32_t), hipMemcpyDeviceToHost, kstream(n, r)));
-            if (r == 0) HIPCHK(n, hipEventRecord(n->ev_v[1], kstream(n, 0)));
-        }
-        // 2. counts (one wait per GPU; the copies were all in flight)
-        for (int r = 0; r < n->n_dev; r++) {
-            HIPCHK(n, hipSetDevice(n->dev[r]));
-            HIPCHK(n, hipStreamSynchronize(kstream(n, r)));
-            if (n->h_vcount[r] < 0 || (size_t)n->h_vcount[r] > n->vcap[r])
-                return nfail(n, PCS_ERR_HIP, "device %d reported %d partials (capacity %zu)", n->dev[r], n->h_vcount[r], n->vcap[r]);
-        }
-        // 3. one group: keys behind keys, partials behind partials
-        size_t off = (size_t)n->h_vcount[0];
-        std::vector<Xfer> xs;
-        for (int r = 1; r < n->n_dev; r++) {
-            const size_t m = (size_t)n->h_vcount[r];
-            xs.push_back(Xfer{r, n->d_vkeys[r], static_cast<uint64_t*>(n->d_vkeys[0]) + off, m * sizeof(uint64_t)});
-            xs.push_back(Xfer{r, n->d_vparts[r], static_cast<pcs_voxel_partial*>(n->d_vparts[0]) + off, m * sizeof(pcs_voxel_partial)});
-            off += m;
-            exchanged += (int64_t)m * PCS_VOXEL_PARTIAL_WIRE_BYTES;
-        }
-        rc = run_exchange(n, xs);           // (the kernel streams are idle: step 2 synchronised them)
-        if (rc != PCS_OK) return rc;
-        // 4. the root reduces everybody's partials
-        HIPCHK(n, hipSetDevice(n->dev[0]));
-        HIPCHK(n, hipEventRecord(n->ev_v[2], n->comm_stream[0]));
-        HIPCHK(n, hipStreamWaitEvent(kstream(n, 0), n->ev_v[2], 0));
-        PCSCHK(n, n->ctx[0], pcs_voxel_grid_from_partials_device(n->ctx[0], static_cast<const uint64_t*>(n->d_vkeys[0]),
-                                                                 static_cast<const pcs_voxel_partial*>(n->d_vparts[0]), (int)off, nullptr,
-                                                                 leaf_mm, d_voxels, voxels_shorts, static_cast<int32_t*>(n->d_vox_n)));
-        reduced = (int64_t)off;
+        st = n->last;
+        HIPCHK(n, hipSetDevice(root.dev));
+        hipStream_t ks = kstream(root);
+        HIPCHK(n, hipEventRecord(n->ev_r0[0], ks));
+        PCSCHK(n, root.ctx, pcs_voxel_grid_device(root.ctx, static_cast<const int16_t*>(n->d_stitched), total, leaf_mm, d_voxels,
+                                                  voxels_shorts, static_cast<int32_t*>(n->d_vox_n[0])));
+        HIPCHK(n, hipEventRecord(n->ev_done[0], ks));
+        int32_t v = 0;
+        PCSCHK(n, root.ctx, pcs_memcpy_d2h(root.ctx, &v, n->d_vox_n[0], sizeof v));        // synchronises the root's kernel stream
+        nv = v;
+        (void)hipEventElapsedTime(&st.root_ms, n->ev_r0[0], n->ev_done[0]);
+        st.reduced = total;
     }
-    HIPCHK(n, hipSetDevice(n->dev[0]));
-    HIPCHK(n, hipEventRecord(n->ev_v[3], kstream(n, 0)));
-    int32_t nv = 0;
-    PCSCHK(n, n->ctx[0], pcs_memcpy_d2h(n->ctx[0], &nv, n->d_vox_n, sizeof nv));         // synchronises the root's kernel stream
-    for (int r = 1; r < n->n_dev; r++) {                                                  // the peers' sends have completed too
-        HIPCHK(n, hipSetDevice(n->dev[r]));
-        HIPCHK(n, hipStreamSynchronize(n->comm_stream[r]));
-    }
-    HIPCHK(n, hipSetDevice(n->dev[0]));
     *n_voxels = nv;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        (void)hipEventElapsedTime(&stats->kernels_ms, n->ev_v[0], n->ev_v[1]);
-        (void)hipEventElapsedTime(&stats->exchange_ms, n->ev_v[1], n->ev_v[2]);
-        (void)hipEventElapsedTime(&stats->root_voxel_ms, n->ev_v[2], n->ev_v[3]);
-        stats->exchanged_bytes = exchanged; stats->partials = (int32_t)reduced; stats->voxels = nv;
+        stats->kernels_ms = st.kernels_ms; stats->exchange_ms = st.exchange_ms; stats->root_voxel_ms = st.root_ms;
+        stats->exchanged_bytes = st.exchanged_bytes; stats->partials = (int32_t)st.reduced; stats->voxels = nv;
     }
     return PCS_OK;
 }
@@ -525,17 +747,18 @@ int pcs_node_process_voxel(pcs_node* n, const uint16_t* const* depth, const uint
     std::vector<const uint8_t*> dc;
     int rc = upload_rasters(n, depth, color, dd, dc);
     if (rc != PCS_OK) return rc;
-    HIPCHK(n, hipSetDevice(n->dev[0]));
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
     const size_t max_sh = pcs_node_max_payload_shorts(n);
-    if (!n->d_vox_out) PCSCHK(n, n->ctx[0], pcs_device_malloc(n->ctx[0], &n->d_vox_out, max_sh * sizeof(int16_t) + 64));
+    if (!n->d_vox_out) PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_vox_out, max_sh * sizeof(int16_t) + 64));
     int nv = 0;
     rc = pcs_node_process_voxel_device(n, dd.data(), dc.data(), leaf_mm, route, static_cast<int16_t*>(n->d_vox_out), max_sh, &nv, stats);
     if (rc != PCS_OK) return rc;
     if (out_shorts < PCS_HEADER_SHORTS + (size_t)nv * PCS_POINT_SHORTS)
         return nfail(n, PCS_ERR_CAPACITY, "output holds %zu shorts, %zu needed", out_shorts, PCS_HEADER_SHORTS + (size_t)nv * PCS_POINT_SHORTS);
-    HIPCHK(n, hipSetDevice(n->dev[0]));
+    HIPCHK(n, hipSetDevice(root.dev));
     const int32_t size = (int32_t)((size_t)nv * PCS_POINT_BYTES);
-    if (size) PCSCHK(n, n->ctx[0], pcs_memcpy_d2h(n->ctx[0], out + PCS_HEADER_SHORTS, n->d_vox_out, (size_t)size));
+    if (size) PCSCHK(n, root.ctx, pcs_memcpy_d2h(root.ctx, out + PCS_HEADER_SHORTS, n->d_vox_out, (size_t)size));
     if (write_header) std::memcpy(out, &size, sizeof size);
     if (out_size_bytes) *out_size_bytes = size;
     return PCS_OK;

@@ -22,6 +22,14 @@ VOXEL_PARTIALS = 0      # PCS_NODE_VOXEL_PARTIALS: per-GPU pre-aggregation, part
 VOXEL_PAYLOADS = 1      # PCS_NODE_VOXEL_PAYLOADS: packed payloads gathered, voxel grid of the stitched cloud on the root
 
 
+NO_EXCHANGE = 1         # PCS_NODE_NO_EXCHANGE
+
+
+class NodeStats(C.Structure):
+    _fields_ = [("ticket", C.c_int32), ("kernels_ms", C.c_float), ("exchange_ms", C.c_float), ("root_ms", C.c_float),
+                ("exchanged_bytes", C.c_int64), ("reduced", C.c_int64)]
+
+
 class VoxelStats(C.Structure):
     _fields_ = [("kernels_ms", C.c_float), ("exchange_ms", C.c_float), ("root_voxel_ms", C.c_float),
                 ("exchanged_bytes", C.c_int64), ("partials", C.c_int32), ("voxels", C.c_int32)]
@@ -30,14 +38,20 @@ class VoxelStats(C.Structure):
 _P, _VP = C.POINTER, C.c_void_p
 SYMBOLS = [
     ("pcs_node_create", C.c_int, [_P(_VP), C.c_int, _P(C.c_int), C.c_int, _P(StreamConfig), C.c_uint32, C.c_int]),
+    ("pcs_node_create_ex", C.c_int, [_P(_VP), C.c_int, _P(C.c_int), C.c_int, _P(StreamConfig), C.c_uint32, C.c_int, C.c_uint32]),
     ("pcs_node_destroy", None, [_VP]),
     ("pcs_node_last_error", C.c_char_p, [_VP]),
     ("pcs_node_devices", C.c_int, [_VP]),
+    ("pcs_node_rccl_ranks", C.c_int, [_VP]),
     ("pcs_node_max_payload_shorts", C.c_size_t, [_VP]),
     ("pcs_node_process", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_node_process_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _P(C.c_int), _P(C.c_int)]),
     ("pcs_node_submit_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_node_wait", C.c_int, [_VP, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    ("pcs_node_set_timing", C.c_int, [_VP, C.c_int]),
+    ("pcs_node_last_stats", C.c_int, [_VP, _P(NodeStats)]),
+    ("pcs_node_submit_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
+    ("pcs_node_wait_voxel", C.c_int, [_VP, C.c_int, _P(C.c_int)]),
     ("pcs_node_process_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int), _P(VoxelStats)]),
     ("pcs_node_process_voxel", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(VoxelStats)]),
 ]
@@ -59,9 +73,11 @@ def load() -> C.CDLL:
 
 
 class PcsNode:
-    """streams: all cameras in global camera order; camera g belongs to devices[g // streams_per_device]."""
+    """streams: all cameras in global camera order; camera g belongs to devices[g // streams_per_device].
+    A device id may repeat (virtual peers of one GPU: their transfers become RCCL self send/recv pairs)."""
 
-    def __init__(self, streams: Sequence[StreamConfig], devices: Sequence[int] = (0,), flags: int = 0, downsample: int = 1):
+    def __init__(self, streams: Sequence[StreamConfig], devices: Sequence[int] = (0,), flags: int = 0, downsample: int = 1,
+                 node_flags: int = 0):
         self._lib = load()
         self._h = C.c_void_p()
         self.streams = list(streams)
@@ -71,8 +87,8 @@ class PcsNode:
         self.per_device = len(self.streams) // len(self.devices)
         self._arr = stream_array(self.streams)
         ids = (C.c_int * len(self.devices))(*self.devices)
-        rc = self._lib.pcs_node_create(C.byref(self._h), len(self.devices), ids, self.per_device,
-                                       C.cast(self._arr, C.POINTER(StreamConfig)), int(flags), int(downsample))
+        rc = self._lib.pcs_node_create_ex(C.byref(self._h), len(self.devices), ids, self.per_device,
+                                          C.cast(self._arr, C.POINTER(StreamConfig)), int(flags), int(downsample), int(node_flags))
         if rc != 0:
             d = self._lib.pcs_node_last_error(None)
             self._h = C.c_void_p()
@@ -103,6 +119,18 @@ class PcsNode:
     @property
     def max_payload_shorts(self) -> int:
         return int(self._lib.pcs_node_max_payload_shorts(self._h))
+
+    @property
+    def rccl_ranks(self) -> int:
+        return int(self._lib.pcs_node_rccl_ranks(self._h))
+
+    def set_timing(self, enable: bool) -> None:
+        self._check(self._lib.pcs_node_set_timing(self._h, int(bool(enable))))
+
+    def last_stats(self) -> dict:
+        st = NodeStats()
+        self._check(self._lib.pcs_node_last_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in NodeStats._fields_}
 
     def _raster_ptrs(self, depth, color):
         n = len(self.streams)
@@ -142,6 +170,18 @@ class PcsNode:
         total = C.c_int(0)
         self._check(self._lib.pcs_node_wait(self._h, int(ticket), counts, C.byref(total)))
         return [int(x) for x in counts], total.value
+
+    def submit_voxel_device(self, d_depth: Sequence[int], d_color: Sequence[int], leaf_mm: int, d_voxels: int, voxels_shorts: int) -> int:
+        n = len(self.streams)
+        t = C.c_int(-1)
+        self._check(self._lib.pcs_node_submit_voxel_device(self._h, (C.c_void_p * n)(*d_depth), (C.c_void_p * n)(*d_color), int(leaf_mm),
+                                                           d_voxels, voxels_shorts, C.byref(t)))
+        return t.value
+
+    def wait_voxel(self, ticket: int) -> int:
+        nv = C.c_int(0)
+        self._check(self._lib.pcs_node_wait_voxel(self._h, int(ticket), C.byref(nv)))
+        return nv.value
 
     def process_voxel(self, depth, color, leaf_mm: int, route: int = VOXEL_PARTIALS):
         """pcs_node_process_voxel: host rasters in -> (voxel records int16 [n,5], stats dict)."""

@@ -101,6 +101,71 @@ def test_two_ranks_shard_the_eight_streams():
     assert abs(d["value"] - 8 * 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
 
 
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+@pytest.mark.gpu
+def test_plain_launch_with_two_gpus_prints_a_line_from_the_node_route():
+    """`python3 bench.py --gpus 2 ...` launched PLAIN (no torch.distributed.run) on a box with one GPU: the default route at
+    N > 1 is the one-process libpcs_node route; the two peers are folded onto the visible GPU (virtual peers, RCCL self
+    send/recv) and the line says so. It must never exit for a launcher reason."""
+    d = _bench_line("--gpus", "2", "--steps", "6", "--warmup", "2", "--preheat-ms", "20")
+    for k in CONTRACT_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["route"].startswith("node")
+    assert d["config"]["streams_per_gpu"] == 4 and d["config"]["devices"] == [0, 0] and "virtual peers" in d["debug"] and "note" in d
+    assert d["rccl_ranks"] == 1 and d["config"]["gather_to_rank0"] is True and "node_error" not in d
+    assert d["check"] == {"slots": [0, 1], "streams": 8, "exchange": True}
+    assert d["bytes_into_root_per_step"] == 4 * 1280 * 720 * 10 and d["points_per_stream"] == [1280 * 720] * 8
+    ph = d["phases_ms"]
+    assert ph["kernel"] > 0 and ph["exchange"] > 0
+    assert abs(d["value"] - 8 * 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+@pytest.mark.gpu
+def test_node_route_under_torchrun_lets_rank_zero_drive_the_node():
+    """The driver's N > 1 command line: every rank is started, rank 0's process drives all GPUs, the others exit 0."""
+    d = _bench_line("--gpus", "2", "--node-devices", "0,0", "--steps", "4", "--warmup", "1", "--preheat-ms", "10", "--mode", "drop_invalid",
+                    launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", "29579"))
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 1 and d["check"]["exchange"] is True
+    kept = d["points_per_stream"]
+    assert len(kept) == 8 and all(0.85 * 1280 * 720 < c < 0.95 * 1280 * 720 for c in kept)
+    assert d["bytes_into_root_per_step"] == 10 * sum(kept[4:])
+
+
+@pytest.mark.gpu
+def test_node_route_on_one_gpu_agrees_with_the_headline():
+    """--route node --gpus 1 is the same kernel behind pcs_node_submit_device / pcs_node_wait: within a few per cent of the
+    headline's launch-stream figure (the node adds two event waits and a record per step)."""
+    quick = ("--steps", "300", "--warmup", "40")
+    a = _bench_line(*quick, "--no-extra-legs", "--no-cpu-baseline", "--no-host-api")
+    b = _bench_line(*quick, "--route", "node")
+    assert b["config"]["route"].startswith("node") and b["rccl_ranks"] == 0 and "configs[2]" in b["config"]["workload"]
+    assert abs(b["ms_per_step"] - a["ms_per_step"]) / a["ms_per_step"] < 0.06, (a["ms_per_step"], b["ms_per_step"])
+    assert b["roofline"]["kernel"] == "pcs_fused_dense_kernel" and b["roofline"]["frac"] > 0.45
+
+
+@pytest.mark.gpu
+def test_node_route_config5_pipelined_matches_the_digest():
+    """--workload config5 over 8 (virtual) peers = BASELINE configs[4]'s shape, 2 cameras per peer, through
+    pcs_node_submit_voxel_device / pcs_node_wait_voxel; bench.py aborts unless both pipelined slots equal the oracle digest."""
+    d = _bench_line("--workload", "config5", "--gpus", "8", "--node-devices", "0,0,0,0,0,0,0,0", "--steps", "4", "--warmup", "1",
+                    "--preheat-ms", "10", "--ring", "2")
+    assert d["n_gpus"] == 8 and "BASELINE.json configs[4]" in d["config"]["workload"] and d["config"]["streams_per_gpu"] == 2
+    assert d["check"]["golden"] is True and d["rccl_ranks"] == 1
+    assert d["bytes_into_root_per_step"] > 0 and d["bytes_into_root_per_step"] % 40 == 0
+    assert d["partials_reduced_per_step"] * 40 > d["bytes_into_root_per_step"]
+    assert d["phases_ms"]["root"] > 0
+
+
+@pytest.mark.gpu
+def test_ranks_route_launched_plain_reexecutes_itself_under_torchrun():
+    d = _bench_line("--gpus", "2", "--debug-backend", "gloo", "--steps", "4", "--warmup", "1", "--preheat-ms", "10")
+    assert d["n_gpus"] == 2 and d["config"]["gather_to_rank0"] is True and "gloo" in d["debug"]
+
+
 def _load_bench_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", BENCH)

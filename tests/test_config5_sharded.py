@@ -216,46 +216,6 @@ def test_node_voxel_routes_agree_with_the_oracle(oracle, flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
-def test_node_pipelined_submit_wait_keeps_two_frame_sets_in_flight(oracle, flags):
-    """submit(k+1); wait(k) over several frame-sets with alternating stitched buffers: every frame-set must equal what the
-    synchronous pcs_node_process_device gives (= the oracle), with and without data-dependent counts, and the slot
-    bookkeeping must refuse a third frame-set in flight and a stale ticket."""
-    from pointcloud_stitching_amd.node import PcsNode
-    n, w, h, frames = 3, 256, 144, 5
-    cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
-    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 31 * f) for s in range(n)],
-             [S.synth_color(w, h, s, seed=S.SEED + 31 * f) for s in range(n)]) for f in range(frames)]
-    want = [oracle.process_frames(cfgs, d, c, flags, 1) for d, c in sets]
-    with PcsNode(cfgs, devices=[0], flags=flags) as node, PcsContext(cfgs[:1]) as mem:
-        cap = node.max_payload_shorts
-        dev_sets = [_upload(mem, d, c) for d, c in sets]
-        stitched = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
-
-        def fetch(k, total):
-            got = np.empty(total * 5, np.int16)
-            if total:
-                mem.memcpy_d2h(got, stitched[k & 1])
-            return got.reshape(-1, 5)
-        tickets = [node.submit_device(*dev_sets[0], stitched[0], cap)]
-        for k in range(1, frames + 1):
-            if k < frames:
-                tickets.append(node.submit_device(*dev_sets[k], stitched[k & 1], cap))
-                if k == 1:
-                    with pytest.raises(PcsError) as e:                       # both slots are busy now
-                        node.submit_device(*dev_sets[k], stitched[k & 1], cap)
-                    assert e.value.status == -5
-            counts, total = node.wait(tickets[k - 1])
-            w_pts, w_counts = want[k - 1]
-            assert counts == w_counts and total == w_pts.shape[0]
-            assert (fetch(k - 1, total) == w_pts).all(), k - 1
-        with pytest.raises(PcsError):
-            node.wait(tickets[0])                                             # long gone
-        counts, total = node.process_device(*dev_sets[2], stitched[0], cap)  # the synchronous form agrees
-        assert counts == want[2][1] and (fetch(0, total) == want[2][0]).all()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("leaf", [50, 200])
 def test_central_cli_shards_config5_over_one_gpu_and_matches_the_digests(leaf):
     """`pcs-multicamera-optimized -i synth:1920x1080 -N 16 -Z -G 1 -V <leaf>`: the node library's voxel route through the CLI

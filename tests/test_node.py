@@ -1,0 +1,211 @@
+"""libpcs_node (include/pcs_node.h): ONE process, several peers, one grouped RCCL exchange to the root per frame-set — the
+star of src/pcs-camera-optimized.cpp:715-720 -> src/pcs-multicamera-client.cpp:363-409 on a node of GPUs.
+
+The development box has ONE GPU. A device id that repeats makes virtual peers of that GPU: every N > 1 code path — camera
+order offsets, the two payload slots, packed / drained events, the deferred exchange under a predicate, the voxel-partials
+route — then runs on REAL RCCL (ncclCommInitAll of one rank, grouped self ncclSend / ncclRecv pairs), and the result must be
+the oracle's bytes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pointcloud_stitching_amd import synthetic as S
+from pointcloud_stitching_amd.api import PcsContext, PcsError
+from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config5_digests.json")))
+
+
+def _upload(ctx, depth, color):
+    dd = [ctx.device_malloc(max(d.nbytes, 16)) for d in depth]
+    dc = [ctx.device_malloc(max(c.nbytes, 16)) for c in color]
+    for ptr, a in zip(dd + dc, list(depth) + list(color)):
+        ctx.memcpy_h2d(ptr, a)
+    return dd, dc
+
+
+def _fetch(mem, ptr, n_points):
+    got = np.empty(max(n_points, 1) * 5, np.int16)
+    if n_points:
+        mem.memcpy_d2h(got[:n_points * 5], ptr)
+    return got[:n_points * 5].reshape(-1, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0], [0] * 8])
+@pytest.mark.parametrize("flags,downsample", [(0, 1), (FLAG_DROP_INVALID, 1), (FLAG_CUTOFF | FLAG_CUTOFF_COMPAT, 1), (0, 3),
+                                              (FLAG_DROP_INVALID, 2)])
+def test_virtual_peers_stitch_over_a_real_rccl_exchange(oracle, devices, flags, downsample):
+    """Host form: every peer's payload must land at its camera-order offset of the root's stitched buffer (a7)."""
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs, depth, color = S.synth_frame_set(8, 208, 120)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags, downsample)
+    with PcsNode(cfgs, devices=devices, flags=flags, downsample=downsample) as node:
+        assert node.rccl_ranks == 1                      # one physical GPU: a communicator of one rank, self send/recv pairs
+        for _ in range(2):
+            buf, counts, size = node.process(depth, color)
+            assert counts == wcounts and size == want.nbytes
+            assert int(np.frombuffer(buf[:2].tobytes(), np.int32)[0]) == size
+            assert (buf[2:2 + want.size].reshape(-1, 5) == want).all()
+        st = node.last_stats()
+        per = 8 // len(devices)
+        assert st["exchanged_bytes"] == 10 * sum(wcounts[per:]) and st["reduced"] == want.shape[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_pipelined_submit_wait_with_two_frame_sets_in_flight(oracle, flags, devices):
+    """submit(k+1); wait(k) with alternating stitched buffers: every frame-set equals the oracle, with and without
+    data-dependent counts (then the exchange of k is enqueued by submit(k+1), not by a host wait inside submit(k)); the slot
+    bookkeeping refuses a third frame-set in flight, a stale ticket and a ticket of the wrong kind."""
+    from pointcloud_stitching_amd.node import PcsNode
+    n, w, h, frames = 3, 256, 144, 6
+    cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
+    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 31 * f) for s in range(n)],
+             [S.synth_color(w, h, s, seed=S.SEED + 31 * f) for s in range(n)]) for f in range(frames)]
+    want = [oracle.process_frames(cfgs, d, c, flags, 1) for d, c in sets]
+    with PcsNode(cfgs, devices=devices, flags=flags) as node, PcsContext(cfgs[:1]) as mem:
+        node.set_timing(True)
+        cap = node.max_payload_shorts
+        dev_sets = [_upload(mem, d, c) for d, c in sets]
+        stitched = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        tickets = [node.submit_device(*dev_sets[0], stitched[0], cap)]
+        for k in range(1, frames + 1):
+            if k < frames:
+                tickets.append(node.submit_device(*dev_sets[k], stitched[k & 1], cap))
+                if k == 1:
+                    with pytest.raises(PcsError) as e:                       # both slots are busy now
+                        node.submit_device(*dev_sets[k], stitched[k & 1], cap)
+                    assert e.value.status == -5
+                    with pytest.raises(PcsError):
+                        node.wait_voxel(tickets[0])                           # a stitch ticket
+            counts, total = node.wait(tickets[k - 1])
+            w_pts, w_counts = want[k - 1]
+            assert counts == w_counts and total == w_pts.shape[0]
+            assert (_fetch(mem, stitched[(k - 1) & 1], total) == w_pts).all(), k - 1
+            st = node.last_stats()
+            assert st["ticket"] == tickets[k - 1] and st["kernels_ms"] > 0 and st["exchange_ms"] >= 0
+        with pytest.raises(PcsError):
+            node.wait(tickets[0])                                             # long gone
+        counts, total = node.process_device(*dev_sets[2], stitched[0], cap)  # the synchronous form agrees
+        assert counts == want[2][1] and (_fetch(mem, stitched[0], total) == want[2][0]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
+def test_a_failed_submit_leaves_the_node_usable(oracle, flags):
+    """Fault injection: peer 0's kernel is enqueued, peer 1 is handed a NULL raster pointer -> the submit fails after work was
+    queued. No ticket may be left behind and the next submit / wait on the same slot must complete and be correct — twice, so
+    that both slots see a failure followed by a success."""
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs, depth, color = S.synth_frame_set(2, 320, 240)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags, 1)
+    with PcsNode(cfgs, devices=[0, 0], flags=flags) as node, PcsContext(cfgs[:1]) as mem:
+        cap = node.max_payload_shorts
+        dd, dc = _upload(mem, depth, color)
+        out = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        for rnd in range(3):
+            with pytest.raises(PcsError) as e:
+                node.submit_device([dd[0], 0], dc, out[0], cap)
+            assert e.value.status == -1
+            t0 = node.submit_device(dd, dc, out[0], cap)
+            t1 = node.submit_device(dd, dc, out[1], cap)
+            for t, o in ((t0, out[0]), (t1, out[1])):
+                counts, total = node.wait(t)
+                assert counts == wcounts and (_fetch(mem, o, total) == want).all(), rnd
+        # the voxel kind too
+        with pytest.raises(PcsError):
+            node.submit_voxel_device([dd[0], 0], dc, 50, out[0], cap)
+        t = node.submit_voxel_device(dd, dc, 50, out[0], cap)
+        nv = node.wait_voxel(t)
+        wv = oracle.voxel_grid(want, 50)
+        assert nv == wv.shape[0] and (_fetch(mem, out[0], nv) == wv).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0]])
+def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, devices):
+    """pcs_node_submit_voxel_device / pcs_node_wait_voxel: partials pre-aggregated per peer, ONE grouped exchange of keys +
+    partials, sort + segmented mean on the root — byte-identical to the voxel grid of the stitched cloud, frame after frame,
+    with the pre-aggregation of k+1 queued before the exchange of k."""
+    from pointcloud_stitching_amd.node import PcsNode, VOXEL_PARTIALS, VOXEL_PAYLOADS
+    n, w, h, frames, leaf = 4, 320, 240, 5, 40
+    cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
+    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 17 * f) for s in range(n)],
+             [S.synth_color(w, h, s, seed=S.SEED + 17 * f) for s in range(n)]) for f in range(frames)]
+    want = [oracle.voxel_grid(oracle.process_frames(cfgs, d, c, flags, 1)[0], leaf) for d, c in sets]
+    with PcsNode(cfgs, devices=devices, flags=flags) as node, PcsContext(cfgs[:1]) as mem:
+        node.set_timing(True)
+        cap = node.max_payload_shorts
+        dev_sets = [_upload(mem, d, c) for d, c in sets]
+        vox = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        tickets = [node.submit_voxel_device(*dev_sets[0], leaf, vox[0], cap)]
+        for k in range(1, frames + 1):
+            if k < frames:
+                tickets.append(node.submit_voxel_device(*dev_sets[k], leaf, vox[k & 1], cap))
+            nv = node.wait_voxel(tickets[k - 1])
+            assert nv == want[k - 1].shape[0]
+            assert (_fetch(mem, vox[(k - 1) & 1], nv) == want[k - 1]).all(), k - 1
+            st = node.last_stats()
+            assert st["reduced"] >= nv and st["root_ms"] > 0
+            assert (st["exchanged_bytes"] > 0) == (len(devices) > 1) and st["exchanged_bytes"] % 40 == 0
+        # the synchronous forms (both routes) on the same node afterwards
+        for route in (VOXEL_PARTIALS, VOXEL_PAYLOADS):
+            nv, stats = node.process_voxel_device(*dev_sets[1], leaf, vox[0], cap, route)
+            assert nv == want[1].shape[0] and (_fetch(mem, vox[0], nv) == want[1]).all(), route
+            assert stats["voxels"] == nv and stats["root_voxel_ms"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0] * 8])
+def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices):
+    """BASELINE configs[4] at full size — 16 x 1920x1080, invalid-depth compaction, 50 mm voxel grid — through the pipelined node
+    call with two frame-sets in flight; [0]*8 is the configuration's own shape (2 cameras per peer, 8 peers) with the
+    exchange on RCCL. Both frame-sets are the digest's frame."""
+    from pointcloud_stitching_amd.node import PcsNode
+    W, H, N, leaf = 1920, 1080, 16, 50
+    cfgs = [S.synth_stream_config(W, H, s) for s in range(N)]
+    depth = [S.synth_depth(W, H, s) for s in range(N)]
+    color = [S.synth_color(W, H, s) for s in range(N)]
+    gold = GOLD["voxel"][str(leaf)]
+    with PcsNode(cfgs, devices=devices, flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
+        cap = node.max_payload_shorts
+        dd, dc = _upload(mem, depth, color)
+        vox = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        t = [node.submit_voxel_device(dd, dc, leaf, vox[0], cap), node.submit_voxel_device(dd, dc, leaf, vox[1], cap)]
+        for k in range(2, 5):
+            nv = node.wait_voxel(t[k - 2])
+            assert nv == gold["voxels"]
+            assert hashlib.sha256(_fetch(mem, vox[k & 1], nv).tobytes()).hexdigest() == gold["sha256"], k
+            t.append(node.submit_voxel_device(dd, dc, leaf, vox[k & 1], cap))
+        for k in (3, 4):
+            assert node.wait_voxel(t[k]) == gold["voxels"]
+
+
+@pytest.mark.gpu
+def test_no_exchange_flag_packs_every_peer_but_gathers_nothing(oracle):
+    from pointcloud_stitching_amd.node import PcsNode, NO_EXCHANGE
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, 0, 1)
+    with PcsNode(cfgs, devices=[0, 0], node_flags=NO_EXCHANGE) as node:
+        assert node.rccl_ranks == 0
+        buf, counts, size = node.process(depth, color)
+        own = sum(wcounts[:2])
+        assert counts == wcounts and size == want.nbytes
+        assert (buf[2:2 + own * 5].reshape(-1, 5) == want[:own]).all()       # the root's slice only
+
+
+# ---- no GPU needed ------------------------------------------------------------------------------------------------------------
+def test_node_refuses_bad_arguments_without_a_device():
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs = [S.synth_stream_config(64, 48, s) for s in range(4)]
+    with pytest.raises(ValueError):
+        PcsNode(cfgs, devices=[0, 0, 0])               # 4 cameras do not divide over 3 peers
+    with pytest.raises(PcsError) as e:
+        PcsNode(cfgs, devices=[0, 0], downsample=0)
+    assert e.value.status == -1
