@@ -318,7 +318,8 @@ int pcs_process_frames_voxel_partials_device(pcs_ctx* ctx, const uint16_t* const
 /* Partials (of any number of pcs_process_frames_voxel_partials_device calls with the SAME leaf_mm, concatenated in any
  * order) -> the voxel grid. n_partials entries are read, or *d_n_partials (device, <= n_partials, which then is the
  * capacity) when that pointer is given. The output needs room for n_partials points. The partials must be ones this library
- * produced (or obey its bounds: n <= 32 768 points per partial, i.e. colour sums < 2^23): 256 of them are summed in 32 bits.
+ * produced (or obey its bounds: 1 <= n <= 32 768 points per partial, i.e. colour sums < 2^23): 256 of them are summed in 32
+ * bits; a voxel whose partials have n == 0 throughout is written with its sums undivided.
  * Asynchronous.                                                                                                           */
 int pcs_voxel_grid_from_partials_device(pcs_ctx* ctx, const uint64_t* d_keys, const pcs_voxel_partial* d_partials,
                                         int n_partials, const int32_t* d_n_partials, int leaf_mm, int16_t* d_out,

@@ -920,16 +920,28 @@ int pcs_copy_pointclouds_xyzrgb_to_buffer_device(pcs_ctx* c, int n_clouds, const
 //  -1  page-locked, but the allocation ends before h + bytes (a buffer registered in part, an interior pointer too close to
 //      the end of a registration): neither route can take it — a kernel would run off the end of the mapping and fault on
 //      the GPU, and the HIP runtime refuses copies that straddle the edge of a registration — so the call is refused
-// The verdict is cached per (pointer, bytes): a frame loop that hands the same buffers over every frame does no driver
-// look-ups after the first; pcs_host_free / pcs_host_unregister drop the cache.
+// The verdict is cached per (pointer, bytes): a frame loop that hands the same buffers over every frame does one attribute
+// query per buffer (the re-validation below) instead of the range look-ups; pcs_host_free / pcs_host_unregister /
+// pcs_host_register drop the cache.
 static int host_device_view(pcs_ctx* c, const void* h, size_t bytes, void** d)
 {
-    for (const auto& e : c->zc_cache)
-        if (e.host == h && e.bytes == bytes) { *d = e.dev; return e.verdict; }
+    // A cached verdict is re-validated with ONE attribute query: the buffer may have been released (or registered) behind this
+    // context's back — hipHostFree / hipHostUnregister / another context — and its address handed out again; a stale "zero
+    // copy" verdict would let a kernel dereference a dead mapping. Only an unchanged answer (still page-locked with the same
+    // device view, or still pageable) is a hit; anything else is looked up afresh (the range queries below).
+    hipPointerAttribute_t a{};
+    const bool locked = hipPointerGetAttributes(&a, h) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer;
+    (void)hipGetLastError();
+    for (size_t i = 0; i < c->zc_cache.size(); i++) {
+        const auto& e = c->zc_cache[i];
+        if (e.host != h || e.bytes != bytes) continue;
+        if ((e.verdict == 1 && locked && a.devicePointer == e.dev) || (e.verdict == 0 && !locked)) { *d = e.dev; return e.verdict; }
+        c->zc_cache.erase(c->zc_cache.begin() + (ptrdiff_t)i);
+        break;
+    }
     void* dev = nullptr;
     int verdict = 0;
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, h) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer) {
+    if (locked) {
         verdict = -1;
         hipDeviceptr_t base = nullptr;
         size_t size = 0;
@@ -1626,9 +1638,11 @@ try {
 int pcs_voxel_grid_from_partials_device(pcs_ctx* c, const uint64_t* d_keys, const pcs_voxel_partial* d_partials, int n_partials,
                                         const int32_t* d_n_partials, int leaf_mm, int16_t* d_out, size_t out_shorts,
                                         int32_t* d_out_points)
-{
+try {
     if (!c) return PCS_ERR_INVALID_ARG;
     if (n_partials < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_partials %d < 0", n_partials);
+    if (((uintptr_t)d_n_partials & 3u) || ((uintptr_t)d_out_points & 3u))
+        return fail(c, PCS_ERR_INVALID_ARG, "d_n_partials / d_out_points must be 4-byte aligned");
     if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
     if (n_partials > 0 && (!d_keys || !d_partials || !d_out)) return fail(c, PCS_ERR_INVALID_ARG, "NULL device pointer");
     if (((uintptr_t)d_keys & 7u) || ((uintptr_t)d_partials & 31u))
@@ -1647,6 +1661,8 @@ int pcs_voxel_grid_from_partials_device(pcs_ctx* c, const uint64_t* d_keys, cons
     HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,
                                          d_n_partials, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
     return PCS_OK;
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_voxel_grid_from_partials_device: host allocation failed (%s)", ex.what());
 }
 
 int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,
@@ -1780,6 +1796,7 @@ int pcs_host_register(pcs_ctx* c, void* h_ptr, size_t bytes)
         (void)hipGetLastError();
         return fail(c, PCS_ERR_HIP, "hipHostRegister(%p, %zu) failed: %s", h_ptr, bytes, hipGetErrorString(e));
     }
+    c->zc_cache.clear();       // verdicts about this range ("pageable", "locked in part") are out of date
     return PCS_OK;
 }
 

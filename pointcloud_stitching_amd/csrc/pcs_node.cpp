@@ -81,6 +81,10 @@ struct pcs_node {
     void* d_vox_n[2] = {nullptr, nullptr};        // root: voxel count per slot
     bool voxel_ready = false;
     size_t vcap_total = 0;
+    // root: a second context of libpcs_hip (own stream, own sort workspace) that runs the sort + segmented mean of frame-set k
+    // while the root's kernel stream pre-aggregates frame-set k+1: the tail is a dozen latency-bound launches that leave the GPU
+    // almost empty, the pre-aggregation is VALU-bound — side by side they cost what the longer one costs
+    pcs_ctx* reduce_ctx = nullptr;
     // root: kernel stream events (timing enabled): start of the submit, own kernels done, reduce start, reduce done
     hipEvent_t ev_k0[2] = {nullptr, nullptr}, ev_k1[2] = {nullptr, nullptr}, ev_r0[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     hipEvent_t ev_x0[2] = {nullptr, nullptr};     // root: comm stream, the group is about to be enqueued
@@ -177,6 +181,15 @@ int ensure_voxel_buffers(pcs_node* n)
     }
     Peer& root = n->peers[0];
     HIPCHK(n, hipSetDevice(root.dev));
+    if (!n->reduce_ctx) {
+        pcs_config cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.device = root.dev; cfg.n_streams = n->per_dev; cfg.streams = n->cfg.data(); cfg.flags = n->flags; cfg.downsample = n->downsample;
+        const int rc = pcs_create(&n->reduce_ctx, &cfg);
+        if (rc != PCS_OK) return nfail(n, rc, "second root context: %s", pcs_last_error(nullptr));
+        // (its own default-priority stream. A high-priority stream was tried: 0.330 instead of 0.198 ms per 16 x 1080p frame-set —
+        // every short launch then pre-empts the pre-aggregation's workgroups)
+    }
     for (int sl = 0; sl < 2; sl++) {
         if (!n->h_vcount[sl]) HIPCHK(n, hipHostMalloc((void**)&n->h_vcount[sl], sizeof(int32_t) * (size_t)(n->n_peers + 1), hipHostMallocPortable));
         if (!n->d_vox_n[sl]) PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_vox_n[sl], 64));
@@ -232,6 +245,13 @@ void issue_exchange(pcs_node* n, Ticket& tk)
             }
         }
         tk.total = off;
+        if (!n->have_comm) {
+            // one peer, or PCS_NODE_NO_EXCHANGE: nothing travels and nothing but the kernels themselves has to finish — no hop
+            // through the communication streams (two barrier packets per frame-set that the single-GPU loop does not need)
+            tk.exchanged_bytes = 0;
+            if (tk.kind == kVoxel) tk.total = (size_t)n->h_vcount[slot][0];      // only the root's own partials are on the root
+            return PCS_OK;
+        }
         if (tk.kind == kStitch) for (const Xfer& x : xs) tk.exchanged_bytes += (int64_t)x.bytes;
         // every GPU's communication stream runs behind the kernels of the peers it hosts
         for (int r = 0; r < P; r++) {
@@ -247,17 +267,19 @@ void issue_exchange(pcs_node* n, Ticket& tk)
         return PCS_OK;
     };
     int rc = body();
-    for (Gpu& g : n->gpus)
-        if (hipSetDevice(g.dev) == hipSuccess) (void)hipEventRecord(g.drained[slot], g.comm_stream);
+    if (n->have_comm || n->broken)
+        for (Gpu& g : n->gpus)
+            if (hipSetDevice(g.dev) == hipSuccess) (void)hipEventRecord(g.drained[slot], g.comm_stream);
     tk.exchanged = true;
     if (rc == PCS_OK && tk.kind == kVoxel) {
         // the root reduces everybody's partials behind the exchange; its voxel count travels to page-locked memory
         auto reduce = [&]() -> int {
             HIPCHK(n, hipSetDevice(root.dev));
-            hipStream_t ks = kstream(root);
-            HIPCHK(n, hipStreamWaitEvent(ks, rootg.drained[slot], 0));
+            hipStream_t ks = static_cast<hipStream_t>(pcs_get_stream(n->reduce_ctx));      // not the root's kernel stream: see reduce_ctx
+            HIPCHK(n, hipStreamWaitEvent(ks, root.packed[slot], 0));                        // the root's own partials
+            if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, rootg.drained[slot], 0));    // everybody else's
             if (n->timing) HIPCHK(n, hipEventRecord(n->ev_r0[slot], ks));
-            PCSCHK(n, root.ctx, pcs_voxel_grid_from_partials_device(root.ctx, static_cast<const uint64_t*>(root.d_vkeys[slot]),
+            PCSCHK(n, n->reduce_ctx, pcs_voxel_grid_from_partials_device(n->reduce_ctx, static_cast<const uint64_t*>(root.d_vkeys[slot]),
                                                                     static_cast<const pcs_voxel_partial*>(root.d_vparts[slot]), (int)tk.total,
                                                                     nullptr, tk.leaf, tk.d_voxels, tk.voxels_shorts,
                                                                     static_cast<int32_t*>(n->d_vox_n[slot])));
@@ -298,7 +320,7 @@ void fill_stats(pcs_node* n, const Ticket& tk)
     Gpu& rootg = n->gpus[n->peers[0].gpu];
     if (hipSetDevice(rootg.dev) != hipSuccess) return;
     (void)hipEventElapsedTime(&st.kernels_ms, n->ev_k0[slot], n->ev_k1[slot]);
-    (void)hipEventElapsedTime(&st.exchange_ms, n->ev_x0[slot], rootg.drained[slot]);
+    if (n->have_comm) (void)hipEventElapsedTime(&st.exchange_ms, n->ev_x0[slot], rootg.drained[slot]);
     if (tk.kind == kVoxel) (void)hipEventElapsedTime(&st.root_ms, n->ev_r0[slot], n->ev_done[slot]);
     (void)hipGetLastError();
 }
@@ -325,6 +347,7 @@ void pcs_node_destroy(pcs_node* n)
         (void)hipSetDevice(g.dev);
         if (g.comm_stream) (void)hipStreamSynchronize(g.comm_stream);
     }
+    if (n->reduce_ctx && !n->peers.empty()) { (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); }
     for (size_t r = 0; r < n->peers.size(); r++) {
         Peer& p = n->peers[r];
         if (!p.ctx) continue;
@@ -359,6 +382,7 @@ void pcs_node_destroy(pcs_node* n)
         if (n->h_counts[sl]) (void)hipHostFree(n->h_counts[sl]);
         if (n->h_vcount[sl]) (void)hipHostFree(n->h_vcount[sl]);
     }
+    if (n->reduce_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); pcs_destroy(n->reduce_ctx); }
     for (Peer& p : n->peers) if (p.ctx) pcs_destroy(p.ctx);
     delete n;
 }
@@ -511,7 +535,7 @@ int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const ui
         Peer& p = n->peers[r];
         HIPCHK(n, hipSetDevice(p.dev));
         hipStream_t ks = kstream(p);
-        HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
+        if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
         if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
         int16_t* dst = r == 0 ? d_stitched : static_cast<int16_t*>(p.d_payload[slot]);
         PCSCHK(n, p.ctx, pcs_process_frames_device(p.ctx, d_depth + (size_t)r * S, d_color + (size_t)r * S, dst,
@@ -557,9 +581,16 @@ static int wait_common(pcs_node* n, int ticket, int kind, Ticket*& out)
     tk.busy = false;                                    // whatever happens below, the slot is free again
     out = &tk;
     const int slot = ticket & 1;
-    for (Gpu& g : n->gpus) {
-        HIPCHK(n, hipSetDevice(g.dev));
-        HIPCHK(n, hipEventSynchronize(g.drained[slot]));
+    if (n->have_comm || n->broken) {
+        for (Gpu& g : n->gpus) {
+            HIPCHK(n, hipSetDevice(g.dev));
+            HIPCHK(n, hipEventSynchronize(g.drained[slot]));
+        }
+    } else {
+        for (Peer& p : n->peers) {                      // no exchange: the frame-set is complete when every peer's kernels are
+            HIPCHK(n, hipSetDevice(p.dev));
+            HIPCHK(n, hipEventSynchronize(p.packed[slot]));
+        }
     }
     if (tk.rc != PCS_OK) { n->err = tk.err; return tk.rc; }
     return PCS_OK;
@@ -651,7 +682,7 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
         Peer& p = n->peers[r];
         HIPCHK(n, hipSetDevice(p.dev));
         hipStream_t ks = kstream(p);
-        HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
+        if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
         if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
         PCSCHK(n, p.ctx, pcs_process_frames_voxel_partials_device(p.ctx, d_depth + (size_t)r * S, d_color + (size_t)r * S, leaf_mm,
                                                                   static_cast<uint64_t*>(p.d_vkeys[slot]),

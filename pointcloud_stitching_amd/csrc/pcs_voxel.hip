@@ -262,6 +262,7 @@ void pcs_voxel_partials_kernel(const int16_t* __restrict__ payload, unsigned int
 constexpr int kRadixBits = 11, kRadix = 1 << kRadixBits;
 constexpr unsigned int kSortChunk = 8192, kSortThreads = 512, kSortWaves = kSortThreads / 64, kSortGrid = 512, kSortBatch = 8;
 constexpr unsigned int kSortMinChunk = 1024, kSortMinRows = 256;
+constexpr unsigned int kSuperShift = 6, kSuperStride = 32;      // voxel ordinals: groups of 64 blocks, one counter per 128-byte line
 
 // Elements per chunk (= per workgroup pass), chosen ON THE DEVICE from the number of partials so that a small sort still
 // spreads over 128 - 256 workgroups: 8192 from 1 M elements up, halving down to 1024 below 256 k (the 125 k partials
@@ -359,16 +360,22 @@ struct RawKeys {
 __global__ __launch_bounds__(kSortThreads)
 void pcs_voxel_hist_kernel(const unsigned long long* __restrict__ keys_a, const unsigned long long* __restrict__ keys_b,
                            unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits, unsigned int pass,
-                           unsigned int n_passes, unsigned int* __restrict__ table, RawKeys raw)
+                           unsigned int n_passes, unsigned int* __restrict__ table, unsigned int* __restrict__ super, RawKeys raw)
 {
     __shared__ unsigned int hist[kRadix];
     const bool from_raw = raw.keys != nullptr && pass == 0;        // (raw input never skips a pass: nobody tracked its key bits)
     const SortPass sp = sort_pass(ctl, bits, idx_bits, pass, n_passes);
-    if (sp.skip) return;
-    const unsigned long long* __restrict__ keys = sp.in_a ? keys_a : keys_b;
     // raw input: this launch also publishes the element count for the device-driven kernels that follow
     const unsigned int m = from_raw ? raw.count() : ctl[0];
     if (from_raw && blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = m;
+    // the launch of the LAST pass (which is never skipped while there is anything to sort) clears the group counters the heads
+    // kernel adds to: one per 128-byte line, as many as m needs
+    if (pass + 1u == n_passes && blockIdx.x == 0) {
+        const unsigned int groups = ((((m + 255u) >> 8) + (1u << kSuperShift) - 1u) >> kSuperShift) + 1u;
+        for (unsigned int j = threadIdx.x; j < groups; j += kSortThreads) super[(size_t)j * kSuperStride] = 0u;
+    }
+    if (sp.skip) return;
+    const unsigned long long* __restrict__ keys = sp.in_a ? keys_a : keys_b;
     const unsigned int csize = sort_chunk_of(m), per_thread = csize / kSortThreads;
     const unsigned int chunks = (m + csize - 1) / csize;
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -600,11 +607,15 @@ void pcs_voxel_scatter_kernel(unsigned long long* __restrict__ keys_a, unsigned 
 constexpr unsigned int kSegThreads = 256, kSegGrid = 4096;
 constexpr unsigned int kCtlWords = 64;                            // one call's control block
 
-// heads[b] = runs that START in block b (block = 256 consecutive sorted elements)
+// heads[b] = runs that START in block b (block = 256 consecutive sorted elements); super[g] = the same for the group of 64
+// blocks g — added with non-returning atomics, one counter per 128-byte line (64 adds to a line serialise at ~12 ns each; all
+// 3 500 of them on two lines took 23 us), cleared by the last pass's histogram launch. A block's first voxel ordinal is then
+// the sum of the groups before its own + the blocks before it in its group: <= 2 loads per lane in the reduce kernel. (Until
+// round 4 a separate single-workgroup launch scanned heads[] in place: one more dependent dispatch.)
 __global__ __launch_bounds__(kSegThreads)
 void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys_a, const unsigned long long* __restrict__ keys_b,
                             const unsigned int* __restrict__ ctl, unsigned int bits, unsigned int idx_bits,
-                            unsigned int* __restrict__ heads)
+                            unsigned int* __restrict__ heads, unsigned int* __restrict__ super)
 {
     __shared__ unsigned int wsum[4];
     const unsigned long long* __restrict__ keys = sorted_in_a(ctl, bits) ? keys_a : keys_b;
@@ -616,49 +627,12 @@ void pcs_voxel_heads_kernel(const unsigned long long* __restrict__ keys_a, const
         const unsigned int c = __popcll(__ballot(head));
         if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = c;
         __syncthreads();
-        if (threadIdx.x == 0) heads[b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (threadIdx.x == 0) {
+            const unsigned int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            heads[b] = t;
+            if (t) atomicAdd(&super[(size_t)(b >> kSuperShift) * kSuperStride], t);
+        }
         __syncthreads();
-    }
-}
-
-// exclusive scan of heads[] (in place) by one workgroup, four entries per lane; the total is the number of voxels.
-// zero_next: the control words of the NEXT call on this workspace (plan_for), cleared here so that no call needs a memset
-// launch of its own.
-// (Round 3 also tried heads + scan as ONE launch — fat workgroups, a release fence, a ticket, the last one scans: the fence
-// is an L2 write-back, and right after a scatter pass the L2s hold megabytes of dirty keys: 32 - 39 us instead of 5 + 5.)
-__global__ __launch_bounds__(1024)
-void pcs_voxel_blockscan_kernel(unsigned int* __restrict__ heads, const unsigned int* __restrict__ m_ptr,
-                                unsigned int* __restrict__ n_voxels, int32_t* __restrict__ out_points,
-                                unsigned int* __restrict__ zero_next)
-{
-    if (zero_next && threadIdx.x < kCtlWords) zero_next[threadIdx.x] = 0u;
-    __shared__ unsigned int wsum[16];
-    __shared__ unsigned int carry_s;
-    const unsigned int m = *m_ptr;
-    const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
-    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (unsigned int b0 = 0; b0 < blocks; b0 += 4096) {
-        const unsigned int b = b0 + threadIdx.x * 4u;
-        unsigned int v[4];
-#pragma unroll
-        for (unsigned int q = 0; q < 4; q++) v[q] = b + q < blocks ? heads[b + q] : 0u;
-        const unsigned int s = v[0] + v[1] + v[2] + v[3];
-        const unsigned int inc = wave_incl_scan(s);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned int run = carry_s + inc - s;
-        for (unsigned int w = 0; w < wave; w++) run += wsum[w];
-#pragma unroll
-        for (unsigned int q = 0; q < 4; q++) { if (b + q < blocks) heads[b + q] = run; run += v[q]; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *n_voxels = carry_s;
-        if (out_points) *out_points = (int32_t)carry_s;
     }
 }
 
@@ -722,6 +696,9 @@ __device__ __forceinline__ void write_voxel(int16_t* __restrict__ out, unsigned 
                                             unsigned int n)
 {
     int16_t* o = out + (size_t)ordinal * PCS_POINT_SHORTS;
+    // (n == 0 cannot come out of this library's pre-aggregation; caller-made partials that sum to no points at all get their
+    // sums written undivided instead of a division by zero)
+    n = n ? n : 1u;
     o[0] = (int16_t)div_sum(sx, n);
     o[1] = (int16_t)div_sum(sy, n);
     o[2] = (int16_t)div_sum(sz, n);
@@ -733,11 +710,12 @@ __global__ __launch_bounds__(kSegThreads)
 void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys_a, const unsigned int* __restrict__ idx_a,
                              const unsigned long long* __restrict__ keys_b, const unsigned int* __restrict__ idx_b,
                              const VoxelPartial* __restrict__ part, const unsigned int* __restrict__ ctl, unsigned int bits,
-                             unsigned int idx_bits, const unsigned int* __restrict__ block_base, int16_t* __restrict__ out,
+                             unsigned int idx_bits, const unsigned int* __restrict__ heads,
+                             const unsigned int* __restrict__ super, int16_t* __restrict__ out,
                              BlockPiece* __restrict__ lead, BlockPiece* __restrict__ trail)
 {
     __shared__ SegSum wv[4];
-    __shared__ unsigned int wheads[4];
+    __shared__ unsigned int wheads[4], wbase[4];
     const bool in_a = sorted_in_a(ctl, bits);
     const unsigned long long* __restrict__ keys = in_a ? keys_a : keys_b;
     const unsigned int* __restrict__ idx = in_a ? idx_a : idx_b;
@@ -747,6 +725,10 @@ void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys_a, cons
     for (unsigned int b = blockIdx.x; b < blocks; b += gridDim.x) {
         const unsigned int g = b * kSegThreads + threadIdx.x;
         const bool live = g < m;
+        // the block's first voxel ordinal: runs begun in the groups before this block's + in the blocks before it in its group
+        unsigned int obase = 0;
+        for (unsigned int j = threadIdx.x; j < (b >> kSuperShift); j += kSegThreads) obase += super[(size_t)j * kSuperStride];
+        if (threadIdx.x < (b & ((1u << kSuperShift) - 1u))) obase += heads[(b >> kSuperShift << kSuperShift) + threadIdx.x];
         unsigned long long key = 0, kprev = 0, knext = 0;
         VoxelPartial q{0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
@@ -766,7 +748,8 @@ void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys_a, cons
         seg_step64<0x142, 0xa>(a);                        // row_bcast:15 -> rows 1, 3
         seg_step64<0x143, 0xc>(a);                        // row_bcast:31 -> rows 2, 3
         const unsigned long long hb = __ballot(head && live);
-        if (lane == 63) wv[wave] = a;
+        obase = wave_incl_scan(obase);
+        if (lane == 63) { wv[wave] = a; wbase[wave] = obase; }
         if (lane == 0) wheads[wave] = __popcll(hb);
         __syncthreads();
         // carry from the earlier wavefronts of the block: back to (and including) the nearest one that holds a head
@@ -778,7 +761,7 @@ void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys_a, cons
         }
         if (!a.head) { seg_add(a, c); a.head = c.head; }
         // a.head now says: my run's head lies inside this block
-        const unsigned int ordinal = block_base[b] + heads_before - 1u;
+        const unsigned int ordinal = wbase[0] + wbase[1] + wbase[2] + wbase[3] + heads_before - 1u;
         const unsigned int last = (m - b * kSegThreads < kSegThreads ? m - b * kSegThreads : kSegThreads) - 1u;   // last live lane
         if (tail && a.head) write_voxel(out, ordinal, a.x, a.y, a.z, a.r, a.g, a.b, a.n);
         if (live && !a.head && (tail || threadIdx.x == last))       // the run begun in an earlier block: its piece in here
@@ -791,13 +774,30 @@ void pcs_voxel_reduce_kernel(const unsigned long long* __restrict__ keys_a, cons
     }
 }
 
-// one lane per block with an open trailing run: add the pieces the following blocks hold of it
+// one lane per block with an open trailing run: add the pieces the following blocks hold of it. Its first wavefront also
+// totals the voxels (the sum of the group counters) and clears the control words of the NEXT call on this workspace
+// (plan_for), so that no call needs a memset launch of its own.
 __global__ __launch_bounds__(256)
-void pcs_voxel_fixup_kernel(const unsigned int* __restrict__ m_ptr, const BlockPiece* __restrict__ lead,
-                            const BlockPiece* __restrict__ trail, int16_t* __restrict__ out)
+void pcs_voxel_fixup_kernel(unsigned int* __restrict__ ctl, const BlockPiece* __restrict__ lead,
+                            const BlockPiece* __restrict__ trail, int16_t* __restrict__ out, const unsigned int* __restrict__ super,
+                            int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next)
 {
-    const unsigned int m = *m_ptr;
+    const unsigned int m = ctl[0];
     const unsigned int blocks = (m + kSegThreads - 1) / kSegThreads;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 64) {
+            const unsigned int groups = (blocks + (1u << kSuperShift) - 1u) >> kSuperShift;
+            unsigned int t = 0;
+            for (unsigned int j = threadIdx.x; j < groups; j += 64) t += super[(size_t)j * kSuperStride];
+            t = wave_incl_scan(t);
+            if (threadIdx.x == 63) {
+                ctl[1] = t;
+                if (out_points) *out_points = (int32_t)t;
+            }
+        } else if (threadIdx.x < 64 + kCtlWords) {
+            if (zero_next) zero_next[threadIdx.x - 64] = 0u;
+        }
+    }
     for (unsigned int b = blockIdx.x * blockDim.x + threadIdx.x; b < blocks; b += gridDim.x * blockDim.x) {
         BlockPiece t = trail[b];
         if (!t.flag) continue;
@@ -814,7 +814,7 @@ struct Workspace {
     unsigned long long *keys_a, *keys_b;
     unsigned int *idx_a, *idx_b;
     VoxelPartial* part;
-    unsigned int *table, *digit_total, *heads;
+    unsigned int *table, *digit_total, *heads, *super;
     BlockPiece *lead, *trail;
     unsigned int *ctl, *ctl_next;       // this call's control words (ctl[0] = m partials, [1] = voxels, [32..35] key
                                         // bits) and the block the NEXT call on this workspace will use: see plan_for
@@ -839,6 +839,7 @@ inline Workspace carve(uint8_t* base, size_t n)
     }
     w.digit_total = (unsigned int*)take((size_t)kRadix * 4);
     w.heads = (unsigned int*)take(((n + kSegThreads - 1) / kSegThreads) * 4);
+    w.super = (unsigned int*)take(((((n + kSegThreads - 1) / kSegThreads) >> kSuperShift) + 2) * (size_t)kSuperStride * 4);
     w.lead = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
     w.trail = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
     w.bytes = (size_t)(p - base);
@@ -938,7 +939,7 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     const unsigned int sort_grid = max_chunks < kSortGrid ? max_chunks : kSortGrid;
     for (unsigned int pass = 0; pass < n_passes; pass++) {
         hipLaunchKernelGGL(pcs_voxel_hist_kernel, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits,
-                           pass, n_passes, w.table, pl.raw);
+                           pass, n_passes, w.table, w.super, pl.raw);
         hipLaunchKernelGGL(pcs_voxel_colscan_kernel, dim3(kRadix / 4), dim3(256), 0, st, w.table, w.ctl, w.digit_total, bits, pass, n_passes);
         if (idx_bits)
             hipLaunchKernelGGL(pcs_voxel_scatter_kernel<true>, dim3(sort_grid), dim3(kSortThreads), 0, st, w.keys_a, w.idx_a, w.keys_b,
@@ -949,12 +950,13 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     }
     const unsigned int max_blocks = (n_points + kSegThreads - 1) / kSegThreads;
     const unsigned int seg_grid = max_blocks < kSegGrid ? max_blocks : kSegGrid;
-    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits, w.heads);
-    hipLaunchKernelGGL(pcs_voxel_blockscan_kernel, dim3(1), dim3(1024), 0, st, w.heads, w.ctl, w.ctl + 1, d_out_points, w.ctl_next);
+    hipLaunchKernelGGL(pcs_voxel_heads_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.keys_b, w.ctl, bits, idx_bits, w.heads,
+                       w.super);
     hipLaunchKernelGGL(pcs_voxel_reduce_kernel, dim3(seg_grid), dim3(kSegThreads), 0, st, w.keys_a, w.idx_a, w.keys_b, w.idx_b, w.part,
-                       w.ctl, bits, idx_bits, w.heads, d_out, w.lead, w.trail);
+                       w.ctl, bits, idx_bits, w.heads, w.super, d_out, w.lead, w.trail);
     const unsigned int fix_grid = (max_blocks + 255) / 256 < 64 ? (max_blocks + 255) / 256 : 64;
-    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, w.ctl, w.lead, w.trail, d_out);
+    hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, w.ctl, w.lead, w.trail, d_out, w.super, d_out_points,
+                       w.ctl_next);
     return hipGetLastError();
 }
 

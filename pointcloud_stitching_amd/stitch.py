@@ -37,6 +37,16 @@ def _as_bytes(t: torch.Tensor) -> torch.Tensor:
     return t.view(torch.uint8)
 
 
+class _Completed:
+    """What an exchange that needed no communication returns in place of a work handle."""
+
+    def wait(self):
+        return True
+
+    def is_completed(self):
+        return True
+
+
 class RankStitcher:
     def __init__(self, group=None, root: int = 0):
         self.group = group
@@ -56,6 +66,12 @@ class RankStitcher:
         """local_payload: int16 [points*5]; stitched (root only): int16 [world*points*5]."""
         n = local_payload.numel()
         src = _as_bytes(local_payload)
+        if self.world == 1:                     # no process group needed: the gather of one rank is a copy (or nothing at all)
+            if stitched is None or stitched.numel() < n:
+                raise ValueError("root needs a stitched buffer of world * local size")
+            if stitched.data_ptr() != local_payload.data_ptr():
+                _as_bytes(stitched[:n]).copy_(src)
+            return _Completed()
         if self.rank == self.root:
             if stitched is None or stitched.numel() < n * self.world:
                 raise ValueError("root needs a stitched buffer of world * local size")
@@ -103,7 +119,14 @@ class RankStitcher:
                         dst = merged[a][off:off + sz[r]]
                         if r == self.root:
                             if dst.data_ptr() != src.data_ptr():
-                                own.append((dst, src[:sz[r]]))
+                                mine = src[:sz[r]]
+                                # root != 0: the root's own bytes sit at the head of the merged array and move up by `off`;
+                                # when the two ranges overlap copy_ is not a memmove, and the ranks below the root are about
+                                # to land in [0, off) — go through a temporary
+                                lo, hi = sorted((dst.data_ptr(), mine.data_ptr()))
+                                if dst.untyped_storage().data_ptr() == mine.untyped_storage().data_ptr() and hi - lo < sz[r]:
+                                    mine = mine.clone()
+                                own.append((dst, mine))
                         elif stage and dst.is_cuda:
                             tmp = torch.empty(sz[r], dtype=torch.uint8)
                             landed.append((dst, tmp))
@@ -152,6 +175,27 @@ class ShardedVoxelGrid:
         self.total_cap = total
         self.counts: List[int] = []
 
+    # The context's kernels run on the CONTEXT's HIP stream (its own non-blocking stream unless pcs_set_stream adopted one);
+    # the count read-back, the collectives and their copies run on torch's current stream. Unless the two are the same
+    # stream, each side waits for the other through events — a caller that never called ctx.set_stream gets the same bytes.
+    def _ctx_stream(self):
+        if self.device.type != "cuda":
+            return None
+        h = self.ctx.get_stream()
+        if not h or h == torch.cuda.current_stream(self.device).cuda_stream:
+            return None
+        return torch.cuda.ExternalStream(h, device=self.device)
+
+    def _torch_waits_for_ctx(self):
+        ext = self._ctx_stream()
+        if ext is not None:
+            torch.cuda.current_stream(self.device).wait_stream(ext)
+
+    def _ctx_waits_for_torch(self):
+        ext = self._ctx_stream()
+        if ext is not None:
+            ext.wait_stream(torch.cuda.current_stream(self.device))
+
     def pre_aggregate(self, d_depth: Sequence[int], d_color: Sequence[int]) -> None:
         """Step 1 (asynchronous on the context's stream)."""
         self.ctx.process_frames_voxel_partials_device(d_depth, d_color, self.leaf, self.keys.data_ptr(), self.parts.data_ptr(),
@@ -159,6 +203,7 @@ class ShardedVoxelGrid:
 
     def exchange(self) -> List[int]:
         """Steps 2 + 3. Returns every rank's partial count."""
+        self._torch_waits_for_ctx()                   # the pre-aggregation wrote n_local / keys / parts on the context's stream
         self.counts = self.st.gather_counts(self.n_local[0], self.device)
         if max(self.counts) > self.cap:
             raise RuntimeError(f"a rank reported {max(self.counts)} partials (capacity {self.cap})")
@@ -171,6 +216,7 @@ class ShardedVoxelGrid:
         """Step 4, root only (asynchronous; the voxel count lands in self.n_vox[0])."""
         if self.st.rank != self.st.root:
             return
+        self._ctx_waits_for_torch()                   # the received partials landed behind torch's current stream
         self.ctx.voxel_grid_from_partials_device(self.keys.data_ptr(), self.parts.data_ptr(), sum(self.counts), self.leaf,
                                                  d_out, out_shorts, self.n_vox.data_ptr())
 

@@ -137,13 +137,15 @@ def test_node_route_under_torchrun_lets_rank_zero_drive_the_node():
 
 @pytest.mark.gpu
 def test_node_route_on_one_gpu_agrees_with_the_headline():
-    """--route node --gpus 1 is the same kernel behind pcs_node_submit_device / pcs_node_wait: within a few per cent of the
-    headline's launch-stream figure (the node adds two event waits and a record per step)."""
+    """--route node --gpus 1 is the same kernel behind pcs_node_submit_device / pcs_node_wait. Per frame-set the node records ONE
+    event on the kernel stream (what pcs_node_wait waits for): a marker packet between two 23 us kernels costs ~3 us of
+    command-processor time that the headline loop, which records nothing between its launches, does not pay (measured 25.8
+    vs 22.8 us). Without a communicator nothing else is queued (no hop through the communication stream)."""
     quick = ("--steps", "300", "--warmup", "40")
     a = _bench_line(*quick, "--no-extra-legs", "--no-cpu-baseline", "--no-host-api")
     b = _bench_line(*quick, "--route", "node")
     assert b["config"]["route"].startswith("node") and b["rccl_ranks"] == 0 and "configs[2]" in b["config"]["workload"]
-    assert abs(b["ms_per_step"] - a["ms_per_step"]) / a["ms_per_step"] < 0.06, (a["ms_per_step"], b["ms_per_step"])
+    assert -0.03 < (b["ms_per_step"] - a["ms_per_step"]) / a["ms_per_step"] < 0.18, (a["ms_per_step"], b["ms_per_step"])
     assert b["roofline"]["kernel"] == "pcs_fused_dense_kernel" and b["roofline"]["frac"] > 0.45
 
 

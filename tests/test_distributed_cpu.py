@@ -74,7 +74,7 @@ def test_two_rank_gather_reproduces_camera_order_concat(oracle, flags):
     assert all(ok for _, ok in res), res
 
 
-def _partials_worker(rank, world, port, q):
+def _partials_worker(rank, world, port, q, root=0):
     """The config-5 exchange step on its own: every rank holds m_r (key, partial) pairs; ONE grouped exchange lands
     keys behind keys and partials behind partials on the root, in rank order; the counts come from a tensor (as they do on
     the device: a view of the word the pre-aggregation kernel wrote), not from a host int."""
@@ -84,20 +84,20 @@ def _partials_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pointcloud_stitching_amd.stitch import RankStitcher, KEY_BYTES, PARTIAL_BYTES
-        st = RankStitcher()
-        m = [1234, 0, 777][rank]
+        st = RankStitcher(root=root)
+        m = [1234, 1500, 777][rank] if root else [1234, 0, 777][rank]
         rng = np.random.default_rng(100 + rank)
         cap = 2000
-        keys = torch.zeros((cap * world if rank == 0 else cap) * KEY_BYTES, dtype=torch.uint8)
-        parts = torch.zeros((cap * world if rank == 0 else cap) * PARTIAL_BYTES, dtype=torch.uint8)
+        keys = torch.zeros((cap * world if rank == root else cap) * KEY_BYTES, dtype=torch.uint8)
+        parts = torch.zeros((cap * world if rank == root else cap) * PARTIAL_BYTES, dtype=torch.uint8)
         mine_k = rng.integers(0, 256, m * KEY_BYTES, dtype=np.uint8)
         mine_p = rng.integers(0, 256, m * PARTIAL_BYTES, dtype=np.uint8)
         keys[:mine_k.size] = torch.from_numpy(mine_k); parts[:mine_p.size] = torch.from_numpy(mine_p)
         counts = st.gather_counts(torch.tensor([m, 99], dtype=torch.int32)[0], "cpu")
         st.gather_bytes([keys, parts], [[c * KEY_BYTES for c in counts], [c * PARTIAL_BYTES for c in counts]],
-                        [keys, parts] if rank == 0 else None)
-        ok = counts == [1234, 0, 777]
-        if rank == 0:
+                        [keys, parts] if rank == root else None)
+        ok = counts == ([1234, 1500, 777] if root else [1234, 0, 777])
+        if rank == root:
             want_k = np.concatenate([np.random.default_rng(100 + r).integers(0, 256, c * KEY_BYTES, dtype=np.uint8) for r, c in enumerate(counts)])
             # (each rank drew its keys first, then its partials, from its own generator: replay that order)
             want_k, want_p = [], []
@@ -112,11 +112,14 @@ def _partials_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_three_rank_partials_exchange_lands_in_rank_order():
+@pytest.mark.parametrize("root", [0, 1])
+def test_three_rank_partials_exchange_lands_in_rank_order(root):
+    """root = 1: the root's own 1 500 entries sit at the head of its merged arrays and must move up behind rank 0's 1 234 —
+    overlapping ranges of one storage (copy_ is not a memmove), with rank 0's bytes about to land where they were."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_partials_worker, args=(r, 3, port, q)) for r in range(3)]
+    procs = [ctx.Process(target=_partials_worker, args=(r, 3, port, q, root)) for r in range(3)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -124,3 +127,18 @@ def test_three_rank_partials_exchange_lands_in_rank_order():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_rank_stitcher_without_a_process_group_is_the_identity():
+    """world = 1, torch.distributed not initialised: every exchange is a copy (or nothing), never a collective."""
+    from pointcloud_stitching_amd.stitch import RankStitcher
+    assert not dist.is_initialized()
+    st = RankStitcher()
+    assert (st.rank, st.world) == (0, 1)
+    pay = torch.arange(50, dtype=torch.int16)
+    out = torch.zeros(60, dtype=torch.int16)
+    assert st.gather_fixed(pay, out, async_op=True).wait()
+    assert (out[:50] == pay).all() and (out[50:] == 0).all()
+    assert st.gather_fixed(pay, pay).wait()                         # already in place
+    out2 = torch.zeros(60, dtype=torch.int16)
+    assert st.gather_variable(pay, 7, out2) == [7] and (out2[:35] == pay[:35]).all() and (out2[35:] == 0).all()

@@ -829,6 +829,35 @@ def test_host_api_partially_registered_buffers_are_refused_not_faulted(oracle):
         assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
 
 
+def test_zero_copy_verdicts_survive_registration_changes_made_through_another_context(oracle):
+    """A context caches per buffer whether it is page-locked (zero copy) or pageable (staged). The buffers can change state
+    behind its back — registered, then unregistered, through ANOTHER context (or plain HIP): a stale "zero copy" verdict would
+    let the kernels dereference a dead device mapping (a GPU fault), a stale "pageable" one only costs speed. Every call
+    re-validates with one attribute query, so the same bytes come out in every state."""
+    shapes = [(320, 240)] * 2
+    cfgs = [S.synth_stream_config(w, h, s) for s, (w, h) in enumerate(shapes)]
+    depth = [S.synth_depth(w, h, s) for s, (w, h) in enumerate(shapes)]
+    color = [S.synth_color(w, h, s) for s, (w, h) in enumerate(shapes)]
+    want, wcounts = oracle.process_frames(cfgs, depth, color)
+    with PcsContext(cfgs) as ctx, PcsContext(cfgs[:1]) as other:
+        rd = [np.array(d) for d in depth]; rc = [np.array(c) for c in color]
+        rout = np.zeros(2 + ctx.max_payload_shorts, np.int16)
+
+        def run():
+            rout[:] = 0x5555
+            buf, counts, size = ctx.process_frames(rd, rc, out=rout)
+            assert counts == wcounts and size == want.size * 2
+            assert_same(buf[2:2 + want.size].reshape(-1, 5), want)
+        run()                                                    # pageable: verdicts "staged" cached
+        for a in rd + rc + [rout]:
+            other.host_register(a)
+        run()                                                    # now page-locked: zero copy
+        for a in rd + rc + [rout]:
+            other.host_unregister(a)
+        run()                                                    # the cached device views are dead: must stage again, not fault
+        run()
+
+
 @pytest.mark.parametrize("flags", [0, FLAG_CUTOFF, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT])
 @pytest.mark.parametrize("n", [1, 7, 2048, 70001])
 def test_a2_twin_zero_copy_with_pinned_arrays(oracle, flags, n):

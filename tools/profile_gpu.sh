@@ -26,7 +26,10 @@ RUNS[batch]="$BENCH --mode batch"
 RUNS[batch_drop_invalid]="$BENCH --mode batch_drop_invalid"
 RUNS[voxel]="python $PWD/tools/voxel_bench.py 16 1920 1080 50,200"
 RUNS[config5]="python $PWD/bench.py --workload config5 --steps 60 --warmup 5 --no-cpu-baseline"
-ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch batch_drop_invalid voxel config5"
+# the one-process node route (libpcs_node) on this box's one GPU: 8 virtual peers, the exchange = RCCL self send/recv pairs
+RUNS[node_stitch]="python $PWD/bench.py --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps $STEPS --warmup 20"
+RUNS[node_config5]="python $PWD/bench.py --workload config5 --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps 60 --warmup 5"
+ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch batch_drop_invalid voxel config5 node_stitch node_config5"
 cd /tmp
 for R in $ORDER; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -- ${RUNS[$R]} > $OUT/stats_$R.log 2>&1
@@ -63,7 +66,7 @@ for d in sorted(glob.glob(out + "/stats_*")):
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             name = short(r["Name"])
-            if not ("pcs" in name or "rocprim" in name):
+            if not ("pcs" in name or "rocprim" in name or "ccl" in name.lower()):
                 continue
             rows.append({"run": run, "kernel": name, "calls": r["Calls"], "avg_ns": r["AverageNs"], "min_ns": r["MinNs"],
                          "max_ns": r["MaxNs"], "total_ns": r["TotalDurationNs"], "pct_of_run": r["Percentage"]})
