@@ -767,7 +767,7 @@ def main():
     slab = torch.empty(R * (S * (depth_b + color_b) + out_b) + 256, dtype=torch.uint8, device=dev)
     base = slab.data_ptr()
     off = (-base) % 256
-    d_depth, d_color, d_out, host0 = [], [], [], None
+    d_depth, d_color, d_out, host0, host1 = [], [], [], None, None
     DISTINCT = 4          # frame-sets generated on the host; further ring slots are device copies of these (distinct
     for slot in range(R):  # ADDRESSES are what defeats the caches; generating 16 sets in numpy would only cost start-up time)
         if slot < DISTINCT:
@@ -775,6 +775,8 @@ def main():
             col = [Syn.synth_color(W, H, rank * S + s, seed=Syn.SEED + 7919 * slot) for s in range(S)]
         if slot == 0:
             host0 = (dep, col)
+        if slot == 1:
+            host1 = (dep, col)
         dd, dc = [], []
         for s in range(S):
             v = slab[off:off + npts * 2]
@@ -964,15 +966,23 @@ def main():
         c.timer_end()
         return c.timer_elapsed_ms() / n
 
-    # parity spot-check of slot 0 against the oracle before timing (bench must not time a wrong kernel)
+    # parity check against the oracle before timing (bench must not time a wrong kernel): EVERY stream of ring slots 0 and 1
+    # (distinct frames), on the very buffers the timed region uses
     counter[0] = 0
     launch(); torch.cuda.synchronize(dev)
-    if rank == 0:
-        from oracle import pcs_oracle as O
-        want, _ = O.process_frames(cfgs[:1], host0[0][:1], host0[1][:1], mode_flags, 1)
-        got = d_out[0][:want.size].cpu().numpy().reshape(-1, 5)
-        if (got != want).any():
-            raise SystemExit("bench aborted: HIP output differs from the oracle")
+    if sets_per_launch == 1 and R > 1:
+        launch(); torch.cuda.synchronize(dev)          # slot 1 (the batched modes covered it with the first launch)
+    checked_slots = [0, 1] if (R > 1 and (sets_per_launch == 1 or KB >= 2)) else [0]
+    from oracle import pcs_oracle as O
+    for slot in checked_slots:
+        hd, hc = (host0, host1)[slot]
+        if args.mode in ("pack", "pack_batch"):
+            hd = host0[0]                              # the a2 twin's ring holds slot 0's vertices beside every slot's colour raster
+        want, _ = O.process_frames(cfgs, hd, hc, mode_flags, 1)
+        got = d_out[slot][:want.size].cpu().numpy().reshape(-1, 5)
+        if got.shape != want.shape or (got != want).any():
+            raise SystemExit(f"bench aborted: HIP output of ring slot {slot} differs from the oracle "
+                             f"({int((got != want).any(axis=1).sum())} of {want.shape[0]} records)")
 
     preheat(launch, args.preheat_ms)
     gather_error = None
@@ -1081,6 +1091,7 @@ def main():
                        "ring_inputs_between_rereads_mbytes": round((R - 1) * in_bytes_per_set / 1e6, 1),
                        "ring_cold": bool(ring_cold),
                        "gather_to_rank0": bool(gather), "parallelism": f"streams sharded {S}/GPU x {world}"},
+            "check": {"oracle_compared": {"slots": checked_slots, "streams": S, "records": "all"}},
             "per_stream_fps": round(args.steps * sets_per_launch / elapsed, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -1430,8 +1441,20 @@ def main():
                 preheat(launch_k, args.preheat_ms / 2)
                 ms_k = timed(launch_k, max(300, args.steps), ctx_k)
                 ach_k = set_points * ALGO_BYTES_PER_POINT / (ms_k * 1e-3) / 1e9
+                # the same launch priced by the colour bytes it must TOUCH: every 128-byte line of the larger raster that holds
+                # some pixel's texel (camera 0's map, from the oracle's texture coordinates), instead of 3 B per point
+                _, tex = O.deproject(cfgs_c[0], host0[0][0])
+                tx = np.clip((tex[:, 0] * np.float32(CW) + np.float32(0.5)).astype(np.int64), 0, CW - 1)
+                ty = np.clip((tex[:, 1] * np.float32(CH) + np.float32(0.5)).astype(np.int64), 0, CH - 1)
+                ok_px = host0[0][0].reshape(-1) != 0
+                off_b = (ty * cfgs_c[0].color_stride + tx * 3)[ok_px]
+                lines = np.union1d(off_b // 128, (off_b + 2) // 128).size
+                touched_pp = lines * 128.0 / npts
+                ach_t = set_points * (2 + 10 + touched_pp) / (ms_k * 1e-3) / 1e9
                 out["color_1080p"] = {"ms_per_step": round(ms_k, 5), "value": round(set_points / ms_k / 1e3, 1),
                                       "achieved": round(ach_k, 1), "frac": round(ach_k / HBM_PEAK_GBS, 4),
+                                      "touched_colour_bytes_per_point": round(touched_pp, 3),
+                                      "frac_touched_bytes": round(ach_t / HBM_PEAK_GBS, 4),
                                       "arithmetic": POLICY[min(ctx_k.stream_math(s) for s in range(S))],
                                       "workload": f"{S} x (Z16 {W}x{H} + RGB8 {CW}x{CH}), 1-degree depth->colour rotation, inverse "
                                                   f"Brown-Conrady colour coefficients (0.12, -0.28, 0.0008, -0.0005, 0.09)",
@@ -1519,6 +1542,19 @@ def main():
                                    "ZERO COPY, the kernels read the rasters and write the payload over PCIe themselves, both directions at once. "
                                    "pipelined_*: pcs_submit_frames / pcs_collect_frames (staged, upload of k+1 overlaps download of k). All bounded "
                                    "by the host link, not by the kernel"}
+        if extra:
+            with Leg(out, "per_kernel_unprofiled_us"):
+                # what one launch of each short kernel takes in a back-to-back loop bracketed by ONE hipEvent pair — no
+                # per-launch events, no profiler (rocprofv3 --kernel-trace adds ~1.5 us to every short kernel: profiles/README.md)
+                pk = {"pcs_fused_dense_kernel (8 x 720p)": round(kern_ms * 1e3, 2)}
+                if "pack_twin" in out:
+                    pk["pcs_pack_dense_kernel (1 x 720p)"] = round(out["pack_twin"]["per_stream_launches_ms_per_frame_set"] / S * 1e3, 2)
+                    pk["pcs_pack_batch_kernel (8 x 720p)"] = round(out["pack_twin"]["batched_ms_per_frame_set"] * 1e3, 2)
+                if "compaction" in out:
+                    pk["count + scan + emit (8 x 720p, drop-invalid)"] = round(out["compaction"]["ms_per_step"] * 1e3, 2)
+                    if "caller_counts" in out["compaction"]:
+                        pk["scan + emit (caller counts)"] = round(out["compaction"]["caller_counts"]["ms_per_step"] * 1e3, 2)
+                out["per_kernel_unprofiled_us"] = pk
         if world == 1 and not args.no_cpu_baseline:
             with Leg(out, "cpu_baseline"):
                 out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
