@@ -16,6 +16,8 @@
 //     and -n belong to the PCL viewer, which this build does not have: refused with a reason.
 //   additions: -i <src>  -c <list>  -N <streams>  -g <gpu>  -p <serve port>  -r <frame-sets>  -o <file>  -q (no server)
 //              -G <n>  shard the cameras of -i over n GPUs: libpcs_node (ncclCommInitAll + one grouped send/recv to GPU 0)
+//              -G <id,id,...>  the same with explicit device ids, one per peer; an id that repeats makes virtual peers of one GPU
+//                      (their transfers are RCCL self send/recv pairs): `-G 0,0,0,0` runs the 4-GPU flow on a one-GPU box
 //              -V <mm> serve the voxel-grid downsample (leaf in mm, BASELINE config 5) of the stitched cloud instead of the
 //                      cloud itself: with -i one device call from the rasters (pcs_process_frames_voxel_device), with -c the
 //                      voxel grid of the concatenated payloads;  -Z  drop invalid-depth pixels (PCS_FLAG_DROP_INVALID, -i only)
@@ -44,6 +46,7 @@ typedef std::chrono::duration<double, std::milli> timeMilli;
 static bool timer = false, serve = true;
 static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30, n_gpus = 0, voxel_leaf = 0;
 static bool drop_invalid = false;
+static std::vector<int> gpu_ids;
 static int voxel_route = PCS_NODE_VOXEL_PARTIALS;
 static const char* source = nullptr;
 static const char* cameras = nullptr;
@@ -60,6 +63,7 @@ static void usage()
               << " -c <list>        edge servers host:port,... (pull 'Z' protocol)\n"
               << " -N <n> streams   -g <gpu>   -p <port> (default 9000)   -r <frame-sets>   -o <file>   -q no server\n"
               << " -G <n>           shard the -i cameras over n GPUs of this node (one process, RCCL gather to GPU 0)\n"
+              << " -G <id,id,...>   the same with explicit device ids per peer (a repeated id = virtual peers of one GPU)\n"
               << " -V <mm>          serve the voxel-grid downsample (leaf in millimetres) of the stitched cloud;  -Z drop invalid depth\n"
               << "                  with -G: every GPU pre-aggregates its cameras, ONE exchange of the voxel partials, reduced on GPU 0\n"
               << "                  (-R payloads: gather the packed payloads instead and downsample the stitched cloud on GPU 0)\n"
@@ -85,7 +89,14 @@ int main(int argc, char** argv)
             case 'r': max_sets = atoi(optarg); break;
             case 'o': dump_path = optarg; break;
             case 'q': serve = false; break;
-            case 'G': n_gpus = atoi(optarg); break;
+            case 'G':
+                if (strchr(optarg, ',')) {
+                    for (const char* q = optarg; *q;) { gpu_ids.push_back(atoi(q)); q = strchr(q, ','); if (!q) break; q++; }
+                    n_gpus = (int)gpu_ids.size();
+                } else {
+                    n_gpus = atoi(optarg);
+                }
+                break;
             case 'V': voxel_leaf = atoi(optarg); break;
             case 'R': voxel_route = (optarg[0] == 'p' && optarg[1] == 'a' && optarg[2] == 'y') ? PCS_NODE_VOXEL_PAYLOADS : PCS_NODE_VOXEL_PARTIALS; break;
             case 'Z': drop_invalid = true; break;
@@ -157,10 +168,11 @@ int main(int argc, char** argv)
         if (!source) { std::cerr << "-G applies to cameras on this node (-i)" << std::endl; return 2; }
         if (n_streams % n_gpus) { std::cerr << "-N " << n_streams << " streams do not divide over -G " << n_gpus << " GPUs" << std::endl; return 2; }
         std::vector<int> ids(n_gpus);
-        for (int g = 0; g < n_gpus; g++) ids[g] = device + g;
+        for (int g = 0; g < n_gpus; g++) ids[g] = gpu_ids.empty() ? device + g : gpu_ids[g];
         rc = pcs_node_create(&node, n_gpus, ids.data(), n_streams / n_gpus, cfgs.data(), cfg.flags, downsample);
         if (rc != PCS_OK) { std::cerr << "pcs_node_create: " << pcs_strerror(rc) << ": " << pcs_node_last_error(nullptr) << std::endl; return 1; }
-        std::cout << "Sharding " << n_streams << " cameras over " << n_gpus << " GPU(s), RCCL gather to GPU " << device << std::endl;
+        std::cout << "Sharding " << n_streams << " cameras over " << n_gpus << " GPU(s), RCCL gather to GPU " << ids[0]
+                  << " (communicator of " << pcs_node_rccl_ranks(node) << " rank(s))" << std::endl;
     }
 
     // ---- buffers -------------------------------------------------------------------------------

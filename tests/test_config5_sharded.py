@@ -234,6 +234,25 @@ def test_central_cli_shards_config5_over_one_gpu_and_matches_the_digests(leaf):
     assert hashlib.sha256(raw[4:]).hexdigest() == want["sha256"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-Z"], ["-Z", "-V", "50"], ["-d", "3"]])
+def test_central_cli_over_virtual_peers_writes_the_same_bytes_as_one_gpu(extra):
+    """`pcs-multicamera-optimized -G 0,0,0,0`: four peers on GPU 0, the gather (or the voxel-partials exchange) on real RCCL as
+    self send/recv pairs — byte-identical to the same cameras on one context (no -G) and on a one-peer node (-G 1)."""
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, g in (("plain", []), ("one", ["-G", "1"]), ("four", ["-G", "0,0,0,0"])):
+            dump = os.path.join(tmp, tag + ".bin")
+            r = subprocess.run([CENTRAL, "-i", "synth:320x240", "-N", "8", "-q", "-r", "2", "-t", "-o", dump, *g, *extra],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert r.returncode == 0, (tag, r.stderr[-2000:])
+            if tag == "four":
+                assert "communicator of 1 rank(s)" in r.stdout
+            outs.append(open(dump, "rb").read())
+    assert len(outs[0]) > 4 and outs[0] == outs[1] == outs[2]
+
+
 # ---- no GPU needed ------------------------------------------------------------------------------------------------------------
 def test_aggregate_point_count_is_refused_before_any_device_is_touched():
     """64 streams of 4096 x 4096 would stitch to 1.07 G points: the int32 byte-count header (and the 32-bit per-stream
