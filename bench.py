@@ -258,6 +258,7 @@ def run_config5(args):
     debug_gloo = args.debug_backend == "gloo"
     if debug_gloo:
         local_rank = 0
+    local_rank %= max(torch.cuda.device_count(), 1)      # (a launcher that shows every rank only its own GPU: index 0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -473,12 +474,13 @@ def run_node(args):
         # RCCL would not come up: measure what the kernels alone sustain, say so, and still print a line
         node_error = f"{type(e).__name__}: {e}"[:300]
         node = N.PcsNode(cfgs, devices=devices, flags=flags, node_flags=N.NO_EXCHANGE)
-    lib, h = node._lib, node._h
+    lib = node._lib
+    cur = [node]                     # the node the loops below drive (the direct-store leg swaps in a second one)
     VP = C.c_void_p
 
     def check(rc):
         if rc:
-            raise RuntimeError((lib.pcs_node_last_error(h) or b"").decode())
+            raise RuntimeError((lib.pcs_node_last_error(cur[0]._h) or b"").decode())
 
     # ---- rings of input rasters, each on its owning GPU ------------------------------------------------------------------------
     in_bytes_gpu = S * npts * 5
@@ -519,16 +521,16 @@ def run_node(args):
         k = counter[0]; counter[0] = k + 1
         dp, cp = ring[k % R]
         if config5:
-            check(lib.pcs_node_submit_voxel_device(h, dp, cp, LEAF, VP(outs[k & 1].data_ptr()), cap, C.byref(tick)))
+            check(lib.pcs_node_submit_voxel_device(cur[0]._h, dp, cp, LEAF, VP(outs[k & 1].data_ptr()), cap, C.byref(tick)))
         else:
-            check(lib.pcs_node_submit_device(h, dp, cp, VP(outs[k & 1].data_ptr()), cap, C.byref(tick)))
+            check(lib.pcs_node_submit_device(cur[0]._h, dp, cp, VP(outs[k & 1].data_ptr()), cap, C.byref(tick)))
         return tick.value
 
     def wait(t):
         if config5:
-            check(lib.pcs_node_wait_voxel(h, t, C.byref(tot)))
+            check(lib.pcs_node_wait_voxel(cur[0]._h, t, C.byref(tot)))
         else:
-            check(lib.pcs_node_wait(h, t, cnt_arr, C.byref(tot)))
+            check(lib.pcs_node_wait(cur[0]._h, t, cnt_arr, C.byref(tot)))
         return tot.value
 
     def sync_all():
@@ -661,6 +663,34 @@ def run_node(args):
         out["scaling_note"] = ("strong scaling with a gather: every peer's packed cloud crosses ONE xGMI link into GPU 0 each step, so the step "
                                "is bound by bytes_into_root_per_step over the links (and by one host thread enqueueing for N GPUs), not by the "
                                "kernels; see DESIGN.md §9")
+    if P > 1 and not config5 and flags == 0 and node_error is None:
+        # the same frame loop with the gather done by the pack kernels' own stores into GPU 0's stitched buffer over xGMI
+        # (PCS_NODE_DIRECT_STORE: no exchange step, no RCCL kernel) — reported beside the RCCL figure, never instead of it
+        try:
+            node_d = N.PcsNode(cfgs, devices=devices, flags=flags, node_flags=N.DIRECT_STORE)
+            cur[0] = node_d
+            k0 = counter[0]
+            t_a = submit(); t_b = submit()
+            got = []
+            for t_, o_ in ((t_a, outs[k0 & 1]), (t_b, outs[(k0 + 1) & 1])):
+                n_ = wait(t_); got.append(o_[:n_ * POINT_SHORTS].cpu().numpy())
+            for j, g_ in enumerate(got):
+                src = (k0 + j) % R % DISTINCT
+                want, _ = O.process_frames(cfgs, host[src][0], host[src][1], flags, 1)
+                if g_.size != want.size or (g_.reshape(-1, 5) != want).any():
+                    raise RuntimeError("direct-store gather differs from the oracle")
+            run(max(args.warmup, 10)); sync_all()
+            t0d = time.perf_counter(); run(args.steps); sync_all()
+            el_d = time.perf_counter() - t0d
+            out["direct_store"] = {"ms_per_step": round(el_d * 1e3 / args.steps, 5), "value": round(pts_step * args.steps / el_d / 1e6, 1),
+                                   "checked_against_oracle": True,
+                                   "note": "PCS_NODE_DIRECT_STORE: every peer's pack kernel writes its records straight into its camera-order "
+                                           "slice of GPU 0's stitched buffer (peer access over xGMI); no exchange step, no RCCL kernel"}
+            cur[0] = node
+            node_d.close()
+        except Exception as e:          # noqa: BLE001
+            cur[0] = node
+            out["direct_store"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if virtual:
         out["debug"] = ("virtual peers: device ids repeat, the peers of one GPU share it and their transfers are RCCL self send/recv "
                         "pairs. Exercises the N > 1 flow; says nothing about scaling")
@@ -695,6 +725,18 @@ def main():
     if route == "auto":
         # (--debug-backend gloo is the control-flow test of the ranks route)
         route = "node" if ((args.gpus > 1 or args.node_devices) and args.debug_backend != "gloo") else "ranks"
+        if route == "node" and world > 1 and not args.node_devices:
+            # launched one rank per GPU: the node route needs rank 0 to SEE all N GPUs. A launcher that hides all but one
+            # from every rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) leaves the ranks route, which every rank
+            # decides for itself from what it sees (the same answer on every rank of such a launcher)
+            from pointcloud_stitching_amd import lib as _L
+            try:
+                visible = int(_L.load().pcs_device_count())
+            except Exception:       # noqa: BLE001
+                visible = 0
+            hidden = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            if 0 < visible < args.gpus and hidden:
+                route = "ranks"          # (without such a variable the box simply has fewer GPUs: the node route folds the peers)
     if route == "node":
         if int(os.environ.get("RANK", "0")) != 0:
             return 0                     # under torch.distributed.run: rank 0's process drives every GPU of the node
@@ -719,6 +761,7 @@ def main():
     debug_gloo = args.debug_backend == "gloo"
     if debug_gloo:
         local_rank = 0
+    local_rank %= max(torch.cuda.device_count(), 1)      # (a launcher that shows every rank only its own GPU: index 0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

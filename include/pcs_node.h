@@ -41,6 +41,13 @@ int  pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int s
  * own cameras and only the root's slice of the stitched buffer is written (the counts are still the whole node's). A
  * diagnostic ("what do the kernels alone sustain") and bench.py's fall-back when RCCL refuses to come up.              */
 #define PCS_NODE_NO_EXCHANGE 0x1u
+/* PCS_NODE_DIRECT_STORE: frame-sets whose counts follow from the configuration (no CUTOFF / DROP_INVALID) are gathered by the
+ * pack kernels themselves — every peer's kernel writes its records straight into its camera-order slice of the ROOT GPU's
+ * stitched buffer over xGMI (peer access), so there is no exchange step, no RCCL kernel and no second copy of the payload.
+ * Same bytes. Tickets under a predicate, and the voxel route, still use the grouped RCCL exchange. pcs_node_create_ex fails
+ * with PCS_ERR_UNSUPPORTED if a GPU of the node cannot address the root's memory. Opt-in: xGMI favours RCCL's large
+ * transfers over a kernel's 16-byte stores on some topologies — measure both (bench.py reports the pair at N > 1).        */
+#define PCS_NODE_DIRECT_STORE 0x2u
 int  pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int streams_per_device,
                         const pcs_stream_config* streams, uint32_t flags, int downsample, uint32_t node_flags);
 void pcs_node_destroy(pcs_node* node);

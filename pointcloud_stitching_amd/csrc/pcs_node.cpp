@@ -71,6 +71,8 @@ struct pcs_node {
     bool broken = false;                  // an RCCL call failed: the communicators were aborted
     bool pred = false;                    // CUTOFF / DROP_INVALID: the exchange is sized by data-dependent counts
     bool timing = false;
+    bool direct = false;                  // PCS_NODE_DIRECT_STORE and peer access granted: dense tickets need no exchange
+    std::vector<int32_t> static_cnt;      // [peer * (S + 1) + k]: the counts of a frame-set without a predicate
     Ticket inflight[2];
     int next_ticket = 0;
     int32_t* h_counts[2] = {nullptr, nullptr};    // page-locked: [slot][peer * (S + 1) + k]
@@ -260,6 +262,7 @@ void issue_exchange(pcs_node* n, Ticket& tk)
             HIPCHK(n, hipStreamWaitEvent(g.comm_stream, n->peers[r].packed[slot], 0));
         }
         if (n->timing) { HIPCHK(n, hipSetDevice(rootg.dev)); HIPCHK(n, hipEventRecord(n->ev_x0[slot], rootg.comm_stream)); }
+        if (tk.kind == kStitch && n->direct && !n->pred) xs.clear();      // the peers' kernels stored into the root themselves
         if (!(n->node_flags & PCS_NODE_NO_EXCHANGE)) {
             const int rc = run_exchange(n, xs);
             if (rc != PCS_OK) return rc;
@@ -470,6 +473,32 @@ int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int
         }
         if (he != hipSuccess) return bail(PCS_ERR_HIP, "root events / page-locked counts", hipGetErrorString(he));
     }
+    n->static_cnt.assign((size_t)n_devices * (streams_per_device + 1), 0);
+    for (int r = 0; r < n_devices; r++) {
+        int64_t tot = 0;
+        for (int k = 0; k < streams_per_device; k++) {
+            const int32_t c = (pcs_stream_points(n->peers[r].ctx, k) + downsample - 1) / downsample;
+            n->static_cnt[(size_t)r * (streams_per_device + 1) + k] = c;
+            tot += c;
+        }
+        n->static_cnt[(size_t)r * (streams_per_device + 1) + streams_per_device] = (int32_t)tot;
+    }
+    if ((node_flags & PCS_NODE_DIRECT_STORE) && !(node_flags & PCS_NODE_NO_EXCHANGE) && n_devices > 1) {
+        // every peer's kernels will store into the root GPU's memory themselves: that needs peer access from each other GPU
+        bool ok = true;
+        const int root_dev = n->peers[0].dev;
+        for (const Gpu& g : n->gpus) {
+            if (g.dev == root_dev) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, g.dev, root_dev) != hipSuccess || !can) { ok = false; break; }
+            if (hipSetDevice(g.dev) != hipSuccess) { ok = false; break; }
+            const hipError_t e = hipDeviceEnablePeerAccess(root_dev, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ok = false; break; }
+        }
+        (void)hipGetLastError();
+        if (!ok) return bail(PCS_ERR_UNSUPPORTED, "PCS_NODE_DIRECT_STORE", "a GPU of the node cannot address the root GPU's memory (no peer access)");
+        n->direct = true;
+    }
     if (n_devices > 1 && !(node_flags & PCS_NODE_NO_EXCHANGE)) {
         // one communicator rank per GPU, all in this process; virtual peers share their GPU's rank
         std::vector<int> ids;
@@ -537,9 +566,15 @@ int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const ui
         hipStream_t ks = kstream(p);
         if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
         if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
-        int16_t* dst = r == 0 ? d_stitched : static_cast<int16_t*>(p.d_payload[slot]);
+        // where this peer packs: the root into the head of the stitched buffer; a peer into its payload slot — or, with direct
+        // stores and no predicate (its camera-order offset follows from the configuration), straight into the ROOT GPU's stitched
+        // buffer over xGMI: the pack kernel's own stores are the gather
+        const bool into_root = r == 0 || (n->direct && !n->pred);
+        size_t before = 0;
+        if (into_root) for (int q = 0; q < r; q++) before += (size_t)n->static_cnt[(size_t)q * (S + 1) + S];
+        int16_t* dst = into_root ? d_stitched + before * PCS_POINT_SHORTS : static_cast<int16_t*>(p.d_payload[slot]);
         PCSCHK(n, p.ctx, pcs_process_frames_device(p.ctx, d_depth + (size_t)r * S, d_color + (size_t)r * S, dst,
-                                                   r == 0 ? stitched_shorts : p.payload_shorts,
+                                                   into_root ? stitched_shorts - before * PCS_POINT_SHORTS : p.payload_shorts,
                                                    n->pred ? static_cast<int32_t*>(p.d_counts) : nullptr));
         if (n->pred)
             HIPCHK(n, hipMemcpyAsync(n->h_counts[slot] + (size_t)r * (S + 1), p.d_counts, sizeof(int32_t) * (S + 1), hipMemcpyDeviceToHost, ks));
@@ -552,15 +587,7 @@ int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const ui
     flush_other(n, slot);
     // 3. this frame-set's, when nothing on the device sizes it
     if (!n->pred) {
-        for (int r = 0; r < P; r++) {
-            int64_t tot = 0;
-            for (int k = 0; k < S; k++) {
-                const int32_t c = (pcs_stream_points(n->peers[r].ctx, k) + n->downsample - 1) / n->downsample;
-                tk.cnt[(size_t)r * (S + 1) + k] = c;
-                tot += c;
-            }
-            tk.cnt[(size_t)r * (S + 1) + S] = (int32_t)tot;
-        }
+        tk.cnt = n->static_cnt;
         issue_exchange(n, tk);
         if (tk.rc != PCS_OK) {          // report it here; the ticket is gone (its drained events are recorded)
             tk.busy = false;

@@ -23,6 +23,7 @@ VOXEL_PAYLOADS = 1      # PCS_NODE_VOXEL_PAYLOADS: packed payloads gathered, vox
 
 
 NO_EXCHANGE = 1         # PCS_NODE_NO_EXCHANGE
+DIRECT_STORE = 2        # PCS_NODE_DIRECT_STORE
 
 
 class NodeStats(C.Structure):

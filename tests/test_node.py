@@ -188,6 +188,37 @@ def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags,downsample", [(0, 1), (0, 3), (FLAG_DROP_INVALID, 1)])
+def test_direct_store_gather_writes_the_same_stitched_buffer(oracle, flags, downsample):
+    """PCS_NODE_DIRECT_STORE: without a predicate every peer's pack kernel stores straight into its camera-order slice of the
+    root's stitched buffer (no exchange, no RCCL kernel); under a predicate the node falls back to the grouped exchange.
+    Pipelined over both slots, ragged shapes (slices that do not start on 16-byte boundaries), same bytes as the oracle."""
+    from pointcloud_stitching_amd.node import PcsNode, DIRECT_STORE
+    n, w, h, frames = 6, 203, 57, 4
+    cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
+    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 13 * f) for s in range(n)],
+             [S.synth_color(w, h, s, seed=S.SEED + 13 * f) for s in range(n)]) for f in range(frames)]
+    want = [oracle.process_frames(cfgs, d, c, flags, downsample) for d, c in sets]
+    with PcsNode(cfgs, devices=[0, 0, 0], flags=flags, downsample=downsample, node_flags=DIRECT_STORE) as node, PcsContext(cfgs[:1]) as mem:
+        cap = node.max_payload_shorts
+        dev_sets = [_upload(mem, d, c) for d, c in sets]
+        out = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        t = node.submit_device(*dev_sets[0], out[0], cap)
+        for k in range(1, frames + 1):
+            t2 = node.submit_device(*dev_sets[k], out[k & 1], cap) if k < frames else None
+            counts, total = node.wait(t)
+            assert counts == want[k - 1][1] and total == want[k - 1][0].shape[0]
+            assert (_fetch(mem, out[(k - 1) & 1], total) == want[k - 1][0]).all(), k - 1
+            assert node.last_stats()["exchanged_bytes"] == 10 * sum(want[k - 1][1][2:])
+            t = t2
+        # the voxel route on the same node still goes through the exchange
+        tv = node.submit_voxel_device(*dev_sets[0], 60, out[0], cap)
+        nv = node.wait_voxel(tv)
+        wv = oracle.voxel_grid(want[0][0], 60)
+        assert nv == wv.shape[0] and (_fetch(mem, out[0], nv) == wv).all()
+
+
+@pytest.mark.gpu
 def test_no_exchange_flag_packs_every_peer_but_gathers_nothing(oracle):
     from pointcloud_stitching_amd.node import PcsNode, NO_EXCHANGE
     cfgs, depth, color = S.synth_frame_set(4, 160, 120)
