@@ -93,6 +93,7 @@ def parse():
                          "ncclSend/ncclRecv to GPU 0 per frame-set, pipelined submit/wait). ranks: one process per GPU over "
                          "torch.distributed (needs torch.distributed.run; launched plain it re-executes itself under it). "
                          "auto (default): node for N > 1, the single-GPU legs for N = 1")
+    ap.add_argument("--node-direct-child", action="store_true", help=argparse.SUPPRESS)      # (the direct-store leg's own process)
     ap.add_argument("--node-devices", type=str, default="",
                     help="node route: explicit device ids, one per peer (default 0..N-1). A repeated id makes virtual peers of "
                          "one GPU whose transfers become RCCL self send/recv pairs: `--gpus 2 --node-devices 0,0` runs the N = 2 "
@@ -469,8 +470,10 @@ def run_node(args):
     out = {}
     node, node_error = None, None
     try:
-        node = N.PcsNode(cfgs, devices=devices, flags=flags)
+        node = N.PcsNode(cfgs, devices=devices, flags=flags, node_flags=N.DIRECT_STORE if args.node_direct_child else 0)
     except PcsError as e:
+        if args.node_direct_child:
+            raise
         # RCCL would not come up: measure what the kernels alone sustain, say so, and still print a line
         node_error = f"{type(e).__name__}: {e}"[:300]
         node = N.PcsNode(cfgs, devices=devices, flags=flags, node_flags=N.NO_EXCHANGE)
@@ -639,7 +642,7 @@ def run_node(args):
                    "ring_cold": bool((R - 1) * in_bytes_gpu >= 2 * INFINITY_CACHE_BYTES),
                    "gather_to_rank0": bool(P > 1 and node_error is None), "devices": devices,
                    "parallelism": f"streams sharded {S}/GPU x {P}"},
-        "rccl_ranks": node.rccl_ranks,
+        "rccl_ranks": node.rccl_ranks, "direct_store_gather": bool(args.node_direct_child),
         "check": checked,
         "phases_ms": {"kernel": round(kern_ms, 5), "exchange": round(float(np.median(ph["exchange"])), 5),
                       "root": round(float(np.median(ph["root"])), 5),
@@ -663,33 +666,29 @@ def run_node(args):
         out["scaling_note"] = ("strong scaling with a gather: every peer's packed cloud crosses ONE xGMI link into GPU 0 each step, so the step "
                                "is bound by bytes_into_root_per_step over the links (and by one host thread enqueueing for N GPUs), not by the "
                                "kernels; see DESIGN.md §9")
-    if P > 1 and not config5 and flags == 0 and node_error is None:
+    if P > 1 and not config5 and flags == 0 and node_error is None and not args.node_direct_child:
         # the same frame loop with the gather done by the pack kernels' own stores into GPU 0's stitched buffer over xGMI
-        # (PCS_NODE_DIRECT_STORE: no exchange step, no RCCL kernel) — reported beside the RCCL figure, never instead of it
+        # (PCS_NODE_DIRECT_STORE: no exchange step, no RCCL kernel) — reported beside the RCCL figure, never instead of it. In a
+        # process of its own: peer-to-peer stores have never met a multi-GPU box, and a fault there must not cost the line.
+        import subprocess
         try:
-            node_d = N.PcsNode(cfgs, devices=devices, flags=flags, node_flags=N.DIRECT_STORE)
-            cur[0] = node_d
-            k0 = counter[0]
-            t_a = submit(); t_b = submit()
-            got = []
-            for t_, o_ in ((t_a, outs[k0 & 1]), (t_b, outs[(k0 + 1) & 1])):
-                n_ = wait(t_); got.append(o_[:n_ * POINT_SHORTS].cpu().numpy())
-            for j, g_ in enumerate(got):
-                src = (k0 + j) % R % DISTINCT
-                want, _ = O.process_frames(cfgs, host[src][0], host[src][1], flags, 1)
-                if g_.size != want.size or (g_.reshape(-1, 5) != want).any():
-                    raise RuntimeError("direct-store gather differs from the oracle")
-            run(max(args.warmup, 10)); sync_all()
-            t0d = time.perf_counter(); run(args.steps); sync_all()
-            el_d = time.perf_counter() - t0d
-            out["direct_store"] = {"ms_per_step": round(el_d * 1e3 / args.steps, 5), "value": round(pts_step * args.steps / el_d / 1e6, 1),
-                                   "checked_against_oracle": True,
-                                   "note": "PCS_NODE_DIRECT_STORE: every peer's pack kernel writes its records straight into its camera-order "
-                                           "slice of GPU 0's stitched buffer (peer access over xGMI); no exchange step, no RCCL kernel"}
-            cur[0] = node
-            node_d.close()
+            cmd = [sys.executable, os.path.abspath(__file__), "--route", "node", "--node-direct-child", "--gpus", str(args.gpus),
+                   "--steps", str(args.steps), "--warmup", str(args.warmup), "--preheat-ms", str(min(args.preheat_ms, 200.0)),
+                   "--streams", str(args.streams), "--width", str(W), "--height", str(H)]
+            if args.node_devices:
+                cmd += ["--node-devices", args.node_devices]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"child exited {r.returncode}: {(r.stderr or r.stdout)[-200:]}")
+            dch = json.loads(lines[-1])
+            out["direct_store"] = {"ms_per_step": dch["ms_per_step"], "value": dch["value"], "checked_against_oracle": dch["check"],
+                                   "phases_ms": {k: dch["phases_ms"][k] for k in ("kernel", "exchange")},
+                                   "note": "PCS_NODE_DIRECT_STORE (its own process): every peer's pack kernel writes its records straight into "
+                                           "its camera-order slice of GPU 0's stitched buffer (peer access over xGMI); no exchange step, no "
+                                           "RCCL kernel"}
         except Exception as e:          # noqa: BLE001
-            cur[0] = node
             out["direct_store"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if virtual:
         out["debug"] = ("virtual peers: device ids repeat, the peers of one GPU share it and their transfers are RCCL self send/recv "

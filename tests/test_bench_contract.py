@@ -121,6 +121,11 @@ def test_plain_launch_with_two_gpus_prints_a_line_from_the_node_route():
     ph = d["phases_ms"]
     assert ph["kernel"] > 0 and ph["exchange"] > 0
     assert abs(d["value"] - 8 * 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    # the direct-store gather, measured by a child process of the same script and reported beside the RCCL figure
+    ds = d["direct_store"]
+    assert "error" not in ds, ds
+    assert ds["ms_per_step"] > 0 and ds["checked_against_oracle"] == {"slots": [0, 1], "streams": 8, "exchange": True}
+    assert d["direct_store_gather"] is False
 
 
 @pytest.mark.gpu
