@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloud_stitching_amd import synthetic as S                                      # noqa: E402
 from pointcloud_stitching_amd.api import PcsContext                                      # noqa: E402
-from pointcloud_stitching_amd.node import PcsNode                                        # noqa: E402
+from pointcloud_stitching_amd.node import PcsNode, DIRECT_STORE                          # noqa: E402
 from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID   # noqa: E402
 from oracle import pcs_oracle as O                                                       # noqa: E402
 from tests.test_gpu_parity import _random_config                                         # noqa: E402
@@ -50,7 +50,8 @@ while time.time() < t_end:
         sets.append((depth, color))
     want = [O.process_frames(cfgs, d, c, flags, ds) for d, c in sets]
     leaf = int(rng.choice([7, 20, 35, 50, 120, 400, 3000]))
-    with PcsNode(cfgs, devices=[0] * peers, flags=flags, downsample=ds) as node, PcsContext(cfgs[:1]) as mem:
+    nf = DIRECT_STORE if rng.random() < 0.3 else 0          # (without a predicate the pack kernels then store into the root themselves)
+    with PcsNode(cfgs, devices=[0] * peers, flags=flags, downsample=ds, node_flags=nf) as node, PcsContext(cfgs[:1]) as mem:
         cap = node.max_payload_shorts
         dev = []
         for depth, color in sets:
