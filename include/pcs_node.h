@@ -17,6 +17,9 @@
  * RCCL self send/recv pairs on that GPU's communicator. That is how a one-GPU box runs every N > 1 code path — offsets,
  * slots, events, the grouped ncclSend/ncclRecv — on real RCCL (tests/test_node.py, bench.py --node-devices 0,0).
  *
+ * Threading: a node is driven by ONE host thread at a time (it switches the thread's current device as it goes and keeps
+ * per-ticket state without locks); different nodes may be driven by different threads.
+ *
  * Status: every path runs in the test-suite on ONE GPU (virtual peers, RCCL self exchange). A run over several physical
  * GPUs is what bench.py --gpus N produces; none is on record yet (the development boxes have one GPU).
  */
