@@ -717,25 +717,34 @@ def _reexec_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+def choose_route(route, gpus, node_devices, debug_backend, world, env, visible_devices):
+    """How `--gpus N` is driven. `visible_devices` is a callable (only asked when it matters).
+    node:  ONE process, libpcs_node — any N > 1, launched plain or one rank per GPU (rank 0 drives the node, the others exit).
+    ranks: one process per GPU over torch.distributed — N = 1's single-GPU legs; the gloo control-flow test; and a launcher
+           that hides all but one GPU from every rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank: rank 0 cannot
+           drive GPUs it does not see, and every rank of such a launcher reaches the same verdict on its own). A box that
+           simply has fewer GPUs than asked for stays on the node route, which folds the peers onto the visible ones."""
+    if route != "auto":
+        return route
+    route = "node" if ((gpus > 1 or node_devices) and debug_backend != "gloo") else "ranks"
+    if route == "node" and world > 1 and not node_devices:
+        hidden = any(env.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        if hidden and 0 < visible_devices() < gpus:
+            route = "ranks"
+    return route
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    route = args.route
-    if route == "auto":
-        # (--debug-backend gloo is the control-flow test of the ranks route)
-        route = "node" if ((args.gpus > 1 or args.node_devices) and args.debug_backend != "gloo") else "ranks"
-        if route == "node" and world > 1 and not args.node_devices:
-            # launched one rank per GPU: the node route needs rank 0 to SEE all N GPUs. A launcher that hides all but one
-            # from every rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) leaves the ranks route, which every rank
-            # decides for itself from what it sees (the same answer on every rank of such a launcher)
+
+    def visible():
+        try:
             from pointcloud_stitching_amd import lib as _L
-            try:
-                visible = int(_L.load().pcs_device_count())
-            except Exception:       # noqa: BLE001
-                visible = 0
-            hidden = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
-            if 0 < visible < args.gpus and hidden:
-                route = "ranks"          # (without such a variable the box simply has fewer GPUs: the node route folds the peers)
+            return int(_L.load().pcs_device_count())
+        except Exception:       # noqa: BLE001
+            return 0
+    route = choose_route(args.route, args.gpus, args.node_devices, args.debug_backend, world, os.environ, visible)
     if route == "node":
         if int(os.environ.get("RANK", "0")) != 0:
             return 0                     # under torch.distributed.run: rank 0's process drives every GPU of the node
