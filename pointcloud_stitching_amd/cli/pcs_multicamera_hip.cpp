@@ -23,6 +23,10 @@
 //                      voxel grid of the concatenated payloads;  -Z  drop invalid-depth pixels (PCS_FLAG_DROP_INVALID, -i only)
 //              -G <n> -V <mm>  BASELINE configs[4]: cameras sharded over n GPUs, per-GPU voxel partials, one RCCL exchange, sort +
 //                      segmented mean on GPU 0 (libpcs_node: pcs_node_process_voxel); -R payloads gathers the packed payloads instead
+//              -P      (with -G and -i synth:) the frame loop of a node whose rasters are already on their GPUs: a ring of synthetic
+//                      frame-sets is uploaded once, then pcs_node_submit_device(k+1); pcs_node_wait(k) (with -V: the voxel
+//                      tickets) keeps two frame-sets in flight for -r iterations; prints the period per frame-set and where a
+//                      frame-set's time went on GPU 0 (pcs_node_last_stats). -o dumps the last frame-set like the other modes.
 //     with neither -i nor -c the cameras are 8 synthetic 1280x720 streams on this node (there are no live cameras here).
 #include <chrono>
 #include <cstdio>
@@ -45,7 +49,7 @@ typedef std::chrono::duration<double, std::milli> timeMilli;
 
 static bool timer = false, serve = true;
 static int downsample = 1, n_streams = 8, device = 0, serve_port = 9000, max_sets = 30, n_gpus = 0, voxel_leaf = 0;
-static bool drop_invalid = false;
+static bool drop_invalid = false, pipelined = false;
 static std::vector<int> gpu_ids;
 static int voxel_route = PCS_NODE_VOXEL_PARTIALS;
 static const char* source = nullptr;
@@ -67,6 +71,7 @@ static void usage()
               << " -V <mm>          serve the voxel-grid downsample (leaf in millimetres) of the stitched cloud;  -Z drop invalid depth\n"
               << "                  with -G: every GPU pre-aggregates its cameras, ONE exchange of the voxel partials, reduced on GPU 0\n"
               << "                  (-R payloads: gather the packed payloads instead and downsample the stitched cloud on GPU 0)\n"
+              << " -P               with -G and -i synth:<W>x<H>: device-resident frame loop, two frame-sets in flight (submit / wait)\n"
               << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
 }
 
@@ -74,7 +79,7 @@ int main(int argc, char** argv)
 {
     signal(SIGPIPE, SIG_IGN);
     int c;
-    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:ZR:")) != -1) {
+    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:ZR:P")) != -1) {
         switch (c) {
             case 't': timer = true; break;
             case 'd': downsample = atoi(optarg); break;
@@ -100,6 +105,7 @@ int main(int argc, char** argv)
             case 'V': voxel_leaf = atoi(optarg); break;
             case 'R': voxel_route = (optarg[0] == 'p' && optarg[1] == 'a' && optarg[2] == 'y') ? PCS_NODE_VOXEL_PAYLOADS : PCS_NODE_VOXEL_PARTIALS; break;
             case 'Z': drop_invalid = true; break;
+            case 'P': pipelined = true; break;
             case 's': case 'v': case 'n':
                 std::cerr << "-" << (char)c << " drives the reference's PCL viewer / PLY writer, which this build does not include" << std::endl;
                 return 2;
@@ -246,6 +252,92 @@ int main(int argc, char** argv)
         memcpy(stitched.data(), &size_bytes, sizeof(int));
         return true;
     };
+
+    if (pipelined) {
+        // ---- the frame loop of a node with device-resident rasters: submit(k+1); wait(k) ------------------------------------
+        if (!node || !source || raw) { std::cerr << "-P needs -G <n> and -i synth:<W>x<H>" << std::endl; return 2; }
+        const int per = n_streams / n_gpus, ring = 3;
+        std::vector<int> ids(n_gpus);
+        for (int g = 0; g < n_gpus; g++) ids[g] = gpu_ids.empty() ? device + g : gpu_ids[g];
+        // one small context per peer for its device memory (the node's own contexts are private to it)
+        std::vector<pcs_ctx*> mem(n_gpus, nullptr);
+        for (int g = 0; g < n_gpus; g++) {
+            pcs_config mc; memset(&mc, 0, sizeof mc);
+            mc.device = ids[g]; mc.n_streams = 1; mc.streams = cfgs.data(); mc.downsample = 1;
+            if (pcs_create(&mem[g], &mc) != PCS_OK) { std::cerr << "pcs_create: " << pcs_last_error(nullptr) << std::endl; return 1; }
+        }
+        std::vector<std::vector<const uint16_t*>> rd(ring, std::vector<const uint16_t*>(n_streams));
+        std::vector<std::vector<const uint8_t*>> rc_(ring, std::vector<const uint8_t*>(n_streams));
+        std::vector<uint16_t> hd; std::vector<uint8_t> hc;
+        for (int k = 0; k < ring; k++)
+            for (int s = 0; s < n_streams; s++) {
+                pcs_ctx* m = mem[s / per];
+                pcs_synth::depth(W, H, s, pcs_synth::kSeed + 7919u * (uint32_t)k, hd);
+                pcs_synth::color(W, H, s, pcs_synth::kSeed + 7919u * (uint32_t)k, hc);
+                void *dd = nullptr, *dc = nullptr;
+                if (pcs_device_malloc(m, &dd, hd.size() * 2 + 64) != PCS_OK || pcs_device_malloc(m, &dc, hc.size() + 64) != PCS_OK ||
+                    pcs_memcpy_h2d(m, dd, hd.data(), hd.size() * 2) != PCS_OK || pcs_memcpy_h2d(m, dc, hc.data(), hc.size()) != PCS_OK) {
+                    std::cerr << pcs_last_error(m) << std::endl; return 1;
+                }
+                rd[k][s] = static_cast<const uint16_t*>(dd); rc_[k][s] = static_cast<const uint8_t*>(dc);
+            }
+        const size_t cap = pcs_node_max_payload_shorts(node);
+        void* d_out[2] = {nullptr, nullptr};
+        for (int k = 0; k < 2; k++)
+            if (pcs_device_malloc(mem[0], &d_out[k], cap * sizeof(int16_t) + 64) != PCS_OK) { std::cerr << pcs_last_error(mem[0]) << std::endl; return 1; }
+        pcs_node_set_timing(node, timer ? 1 : 0);
+        auto submit = [&](int k, int* t) {
+            return voxel_leaf ? pcs_node_submit_voxel_device(node, rd[k % ring].data(), rc_[k % ring].data(), voxel_leaf,
+                                                             static_cast<int16_t*>(d_out[k & 1]), cap, t)
+                              : pcs_node_submit_device(node, rd[k % ring].data(), rc_[k % ring].data(), static_cast<int16_t*>(d_out[k & 1]), cap, t);
+        };
+        int last_n = 0;
+        auto wait = [&](int t) {
+            return voxel_leaf ? pcs_node_wait_voxel(node, t, &last_n) : pcs_node_wait(node, t, nullptr, &last_n);
+        };
+        const int warm = 5, iters = max_sets < 1 ? 1 : max_sets;
+        int t_prev = -1, t_cur = -1;
+        clockTime::time_point t0;
+        pcs_node_stats st; memset(&st, 0, sizeof st);
+        double k_ms = 0, x_ms = 0, r_ms = 0;
+        for (int k = 0; k < warm + iters; k++) {
+            if (k == warm) {                                    // drain, then time `iters` steady-state periods
+                if (t_prev >= 0 && wait(t_prev) != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
+                t_prev = -1;
+                t0 = clockTime::now();
+            }
+            if (submit(k, &t_cur) != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
+            if (t_prev >= 0) {
+                if (wait(t_prev) != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
+                if (timer && k > warm) { pcs_node_last_stats(node, &st); k_ms += st.kernels_ms; x_ms += st.exchange_ms; r_ms += st.root_ms; }
+            }
+            t_prev = t_cur;
+        }
+        if (wait(t_prev) != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
+        const double ms = timeMilli(clockTime::now() - t0).count() / iters;
+        const double mpix = (double)n_streams * W * H / 1e6;
+        std::cout << "Pipelined " << (voxel_leaf ? "voxel grid" : "stitch") << " over " << n_gpus << " peer(s): " << ms << " ms per frame-set, "
+                  << mpix / ms * 1e3 << " Mpoints/s in, " << last_n << (voxel_leaf ? " voxels" : " points") << std::endl;
+        if (timer && iters > 1)
+            std::cout << "GPU " << ids[0] << " per frame-set: kernels " << k_ms / (iters - 1) << " ms, exchange " << x_ms / (iters - 1)
+                      << " ms, root " << r_ms / (iters - 1) << " ms (" << st.exchanged_bytes << " B into the root)" << std::endl;
+        if (dump_path) {       // the last frame-set, in the wire format of the other modes
+            size_bytes = last_n * PCS_POINT_BYTES;
+            if (!stitched.resize(PCS_HEADER_SHORTS + (size_t)last_n * PCS_POINT_SHORTS + 8)) return 1;
+            if (size_bytes && pcs_memcpy_d2h(mem[0], stitched.data() + PCS_HEADER_SHORTS, d_out[(warm + iters - 1) & 1], (size_t)size_bytes) != PCS_OK) return 1;
+            memcpy(stitched.data(), &size_bytes, sizeof(int));
+            FILE* f = fopen(dump_path, "wb");
+            if (f) { fwrite(stitched.data(), 1, (size_t)size_bytes + 4, f); fclose(f); }
+        }
+        pcs_node_destroy(node);
+        for (int k = 0; k < ring; k++)
+            for (int s = 0; s < n_streams; s++) { pcs_device_free(mem[s / per], const_cast<uint16_t*>(rd[k][s])); pcs_device_free(mem[s / per], const_cast<uint8_t*>(rc_[k][s])); }
+        for (int k = 0; k < 2; k++) pcs_device_free(mem[0], d_out[k]);
+        for (pcs_ctx* m : mem) pcs_destroy(m);
+        stitched.release();
+        pcs_destroy(ctx);
+        return 0;
+    }
 
     int listen_fd = -1, client_fd = -1;
     if (serve) {

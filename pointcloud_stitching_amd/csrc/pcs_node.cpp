@@ -87,6 +87,7 @@ struct pcs_node {
     // while the root's kernel stream pre-aggregates frame-set k+1: the tail is a dozen latency-bound launches that leave the GPU
     // almost empty, the pre-aggregation is VALU-bound — side by side they cost what the longer one costs
     pcs_ctx* reduce_ctx = nullptr;
+    hipStream_t reduce_stream = nullptr;
     // root: kernel stream events (timing enabled): start of the submit, own kernels done, reduce start, reduce done
     hipEvent_t ev_k0[2] = {nullptr, nullptr}, ev_k1[2] = {nullptr, nullptr}, ev_r0[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     hipEvent_t ev_x0[2] = {nullptr, nullptr};     // root: comm stream, the group is about to be enqueued
@@ -166,6 +167,41 @@ int upload_rasters(pcs_node* n, const uint16_t* const* depth, const uint8_t* con
     return PCS_OK;
 }
 
+// ---- a stream that really runs beside another one -------------------------------------------------------------------------
+__global__ void pcs_node_spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();                    // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void pcs_node_nop_kernel() {}
+
+// Tries up to six new streams on the current device; *out = the first one on which a launch completes while a spin kernel still
+// occupies `busy` (the others are destroyed), or nullptr if none did (the caller then keeps what it has).
+int pick_concurrent_stream(pcs_node* n, hipStream_t busy, hipStream_t* out)
+{
+    *out = nullptr;
+    hipEvent_t spun = nullptr, done = nullptr;
+    HIPCHK(n, hipEventCreateWithFlags(&spun, hipEventDisableTiming));
+    HIPCHK(n, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    std::vector<hipStream_t> rejected;
+    for (int attempt = 0; attempt < 6 && !*out; attempt++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        hipLaunchKernelGGL(pcs_node_spin_kernel, dim3(1), dim3(64), 0, busy, 30000ll);       // ~300 us
+        (void)hipEventRecord(spun, busy);
+        hipLaunchKernelGGL(pcs_node_nop_kernel, dim3(1), dim3(64), 0, cand);
+        (void)hipEventRecord(done, cand);
+        (void)hipEventSynchronize(done);
+        const bool beside = hipEventQuery(spun) == hipErrorNotReady;      // the spin was still going when the other stream finished
+        (void)hipEventSynchronize(spun);
+        (void)hipGetLastError();
+        if (beside) *out = cand; else rejected.push_back(cand);            // (kept alive until the search ends: the next stream then takes another queue)
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipEventDestroy(spun); (void)hipEventDestroy(done);
+    return PCS_OK;
+}
+
 // Voxel route buffers, on first use: two slots of key / partial arrays per peer (the root's take everybody's partials).
 int ensure_voxel_buffers(pcs_node* n)
 {
@@ -191,6 +227,14 @@ int ensure_voxel_buffers(pcs_node* n)
         if (rc != PCS_OK) return nfail(n, rc, "second root context: %s", pcs_last_error(nullptr));
         // (its own default-priority stream. A high-priority stream was tried: 0.330 instead of 0.198 ms per 16 x 1080p frame-set —
         // every short launch then pre-empts the pre-aggregation's workgroups)
+        // Which stream: the HIP runtime maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), round
+        // robin as they are created, and two streams on one queue do not overlap at all — in the C++ CLI the context's own stream
+        // happened to share the kernel stream's queue: 0.248 ms per frame-set instead of 0.195. Streams are therefore tried until
+        // one is SEEN to run beside the root's kernel stream (a no-op launched behind a 300 us spin on the kernel stream must
+        // finish first); stream priorities proved erratic (0.20 - 0.33 ms depending on the queue count) and are not used.
+        int rc2 = pick_concurrent_stream(n, kstream(root), &n->reduce_stream);
+        if (rc2 != PCS_OK) return rc2;
+        if (n->reduce_stream) PCSCHK(n, n->reduce_ctx, pcs_set_stream(n->reduce_ctx, n->reduce_stream));
     }
     for (int sl = 0; sl < 2; sl++) {
         if (!n->h_vcount[sl]) HIPCHK(n, hipHostMalloc((void**)&n->h_vcount[sl], sizeof(int32_t) * (size_t)(n->n_peers + 1), hipHostMallocPortable));
@@ -385,7 +429,8 @@ void pcs_node_destroy(pcs_node* n)
         if (n->h_counts[sl]) (void)hipHostFree(n->h_counts[sl]);
         if (n->h_vcount[sl]) (void)hipHostFree(n->h_vcount[sl]);
     }
-    if (n->reduce_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); pcs_destroy(n->reduce_ctx); }
+    if (n->reduce_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); pcs_destroy(n->reduce_ctx);
+                         if (n->reduce_stream) (void)hipStreamDestroy(n->reduce_stream); }
     for (Peer& p : n->peers) if (p.ctx) pcs_destroy(p.ctx);
     delete n;
 }

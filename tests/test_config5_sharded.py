@@ -253,6 +253,25 @@ def test_central_cli_over_virtual_peers_writes_the_same_bytes_as_one_gpu(extra):
     assert len(outs[0]) > 4 and outs[0] == outs[1] == outs[2]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["-Z"], ["-Z", "-V", "50"]])
+def test_central_cli_pipelined_frame_loop_ends_on_the_same_bytes(extra):
+    """`-P`: the C++ host's own frame loop over device-resident rasters — pcs_node_submit_device(k+1); pcs_node_wait(k) (with -V
+    the voxel tickets), two frame-sets in flight over three peers. Its last frame-set (loop index 8 = ring slot 2) must equal
+    what the synchronous host-form loop writes for its third frame-set."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        a, b = os.path.join(tmp, "pipe.bin"), os.path.join(tmp, "sync.bin")
+        common = [CENTRAL, "-i", "synth:320x240", "-N", "6", "-q", "-t", "-G", "0,0,0", *extra]
+        r = subprocess.run([*common, "-P", "-r", "4", "-o", a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Pipelined" in r.stdout and "ms per frame-set" in r.stdout and "per frame-set: kernels" in r.stdout
+        r2 = subprocess.run([*common, "-r", "3", "-o", b], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        pa, pb = open(a, "rb").read(), open(b, "rb").read()
+    assert len(pa) > 4 and pa == pb
+
+
 # ---- no GPU needed ------------------------------------------------------------------------------------------------------------
 def test_aggregate_point_count_is_refused_before_any_device_is_touched():
     """64 streams of 4096 x 4096 would stitch to 1.07 G points: the int32 byte-count header (and the 32-bit per-stream
