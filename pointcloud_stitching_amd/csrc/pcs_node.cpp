@@ -501,7 +501,13 @@ int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int
     }
     for (Gpu& g : n->gpus) {
         hipError_t he = hipSetDevice(g.dev);
-        if (he == hipSuccess) he = hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking);
+        if (he == hipSuccess && n_devices > 1) {
+            // the exchange of frame-set k is meant to run beside the kernels of k+1: a communication stream that is SEEN to run
+            // beside the kernel stream of the GPU's first peer (hardware-queue collisions: pick_concurrent_stream)
+            for (const Peer& p : n->peers)
+                if (n->gpus[p.gpu].dev == g.dev) { (void)pick_concurrent_stream(n, kstream(p), &g.comm_stream); break; }
+        }
+        if (he == hipSuccess && !g.comm_stream) he = hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking);
         for (int sl = 0; sl < 2 && he == hipSuccess; sl++) he = hipEventCreate(&g.drained[sl]);
         if (he != hipSuccess) return bail(PCS_ERR_HIP, "communication stream", hipGetErrorString(he));
     }
