@@ -108,107 +108,26 @@ def parse():
     return ap.parse_args()
 
 
-def _cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def _physical_cores():
-    """Distinct (socket, core) pairs of /proc/cpuinfo — the host's PHYSICAL core count, SMT siblings not counted."""
-    try:
-        pairs, phys, core = set(), None, None
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("physical id"):
-                phys = line.split(":", 1)[1].strip()
-            elif line.startswith("core id"):
-                core = line.split(":", 1)[1].strip()
-            elif not line.strip():
-                if phys is not None and core is not None:
-                    pairs.add((phys, core))
-                phys = core = None
-        if phys is not None and core is not None:
-            pairs.add((phys, core))
-        return len(pairs) or None
-    except OSError:
-        return None
-
-
-def cpu_baseline(cfgs, depth, color, budget_s):
-    """The reference's `-m -t<N>` path restated (oracle/pcs_oracle_simd.c), timed on this host.
-    Bracket A = the reference's own timed region (memset + pack, deprojection excluded, :291-293).
-    Bracket B adds the CPU deprojection, i.e. what the fused GPU kernel does."""
-    from oracle import pcs_oracle as O
-    L = O.lib()
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    S = len(cfgs)
-    npts = cfgs[0].n_points
-    vt = [O.deproject(cfgs[s], depth[s]) for s in range(S)]
-    # the reference's 5 000 000-short buffer (:157) holds 999 999 points; larger frames (1080p) would overflow it
-    # there — size ours from the geometry so the port measures the same work without corrupting the heap
-    buf_shorts = max(5_000_000, 2 + 5 * npts)
-    buf = np.zeros(buf_shorts, np.int16)
-
-    def send(cfg, v, t, col, threads):
-        if L.pcs_oracle_send_simd_omp(C.byref(cfg), v.ctypes.data, t.ctypes.data, npts, col.ctypes.data,
-                                      buf.ctypes.data, buf_shorts, threads) < 0:
-            raise RuntimeError("cpu baseline: buffer too small")
-
-    def run_a(threads):
-        for s in range(S):
-            send(cfgs[s], vt[s][0], vt[s][1], color[s], threads)
-
-    vv = np.empty((npts, 3), np.float32); tt = np.empty((npts, 2), np.float32)
-
-    def run_b(threads):
-        for s in range(S):
-            d = np.ascontiguousarray(depth[s]).reshape(-1)
-            L.pcs_oracle_deproject_omp(C.byref(cfgs[s]), d.ctypes.data, vv.ctypes.data, tt.ctypes.data, threads)
-            send(cfgs[s], vv, tt, color[s], threads)
-
-    def best(fn, threads, share):
-        fn(threads)                                # warm
-        t_end = time.perf_counter() + share
-        b = float("inf"); reps = 0
-        while time.perf_counter() < t_end or reps < 2:
-            t0 = time.perf_counter(); fn(threads); b = min(b, time.perf_counter() - t0); reps += 1
-        return b, reps
-
-    # The reference's schedule(static,10000) over its four-point iterations yields 24 chunks per 720p frame
-    # (230 400 / 10 000), so more than 24 threads cannot help it; the sweep still runs up to the PHYSICAL core count
-    # (thread counts beyond the cgroup's cores only thrash) and the best is reported.
-    phys = _physical_cores() or avail
-    cand = (1, 2, 4, 8, 12, 16, 24, 32, 48, 64)
-    sweep = sorted({t for t in cand if t <= max(min(avail, phys), 1)})
-    share = budget_s / (2.0 * len(sweep))
-    res_a = {t: best(run_a, t, share) for t in sweep}
-    res_b = {t: best(run_b, t, share) for t in sweep}
-    ta = min(res_a, key=lambda t: res_a[t][0]); tb = min(res_b, key=lambda t: res_b[t][0])
-    a_best, reps = res_a[ta]
-    pts = S * npts
-    return {
-        "value": round(pts / a_best / 1e6, 2), "unit": "Mpoints/s", "cores": ta, "kind": "port",
-        "sample": f"{S} x {cfgs[0].depth.width}x{cfgs[0].depth.height} frames back-to-back, best of {reps} passes, "
-                  f"best of -t{sweep}; bracket A = the reference's timed region (memset + pack, deprojection "
-                  f"excluded), SSE/FMA + OpenMP port of the -m -t<N> path",
-        "ms_per_frame_set": round(a_best * 1e3, 3),
-        "theoretical_fps_per_stream": round(S / a_best, 1),
-        "t1_value": round(pts / res_a[1][0] / 1e6, 2),
-        "by_threads": {str(t): round(pts / res_a[t][0] / 1e6, 1) for t in sweep},
-        "with_deprojection_value": round(pts / res_b[tb][0] / 1e6, 2),
-        "with_deprojection_cores": tb,
-        "with_deprojection_t1_value": round(pts / res_b[1][0] / 1e6, 2),
-        "host_physical_cores": phys,
-        "host_logical_cpus": avail,
-        "cpu_model": _cpu_model(),
-    }
+def cpu_baseline(width, height, streams, budget_s):
+    """The reference's `-m -t<N>` path restated (oracle/pcs_oracle_simd.c), timed on this host by a CHILD process
+    (oracle/cpu_baseline.py) BEFORE any GPU leg: the OpenMP team is bound (OMP_PROC_BIND=close, OMP_PLACES=cores are in the
+    child's environment when libgomp initialises), its buffers are first-touched by the team, no torch / HIP runtime
+    threads run beside it, and `value` is the median over >= 30 passes at the best thread count (best / p10 / p90 beside
+    it). Bracket A = the reference's own timed region (memset + pack, deprojection excluded, :291-293); bracket B adds the
+    CPU deprojection, i.e. what the fused GPU kernel does."""
+    import subprocess
+    env = dict(os.environ)
+    env["OMP_PROC_BIND"] = "close"
+    env["OMP_PLACES"] = "cores"
+    env.pop("OMP_NUM_THREADS", None)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--width", str(width), "--height", str(height),
+                        "--streams", str(streams), "--seconds", str(budget_s)], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=max(600.0, 20 * budget_s))
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline child failed: " + r.stderr[-600:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
 
 
 class Leg:
@@ -766,6 +685,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libpcs_hip has no CPU fallback")
+    # The CPU sample runs FIRST, in a child process, while this process has not yet created a HIP context or a stream:
+    # nothing of the GPU legs (runtime helper threads, pinned-memory traffic, thermal state of the host) can move it.
+    cpu_first, cpu_first_error = None, None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_first = cpu_baseline(args.width, args.height, args.streams, args.cpu_seconds)
+        except Exception as e:       # noqa: BLE001 — a leg must never cost the line
+            cpu_first_error = f"{type(e).__name__}: {e}"[:300]
     debug_gloo = args.debug_backend == "gloo"
     if debug_gloo:
         local_rank = 0
@@ -1075,6 +1002,15 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms = ctx.timer_elapsed_ms()
 
+    # The driver's --steps 20 makes the contract bracket 0.5 ms long. The SAME launch loop for >= 50 ms, printed beside it
+    # (roofline.long_sample_ms), says whether a low contract figure is the box or the run length.
+    long_sample = None
+    if world == 1:
+        n_long = max(int(50.0 / max(gpu_ms / args.steps, 1e-3)) + 1, args.steps)
+        long_ms = timed(launch, n_long)
+        torch.cuda.synchronize(dev)
+        long_sample = (long_ms, n_long)
+
     shard_only = None
     shard_gpu_ms = None
     if world > 1:
@@ -1153,6 +1089,9 @@ def main():
                                     "batch_drop_invalid": "pcs_fused_count_batch_kernel + pcs_scan_batch_kernel + pcs_fused_emit_batch_kernel",
                                     "cutoff": "pcs_fused_count_kernel + pcs_scan_kernel + pcs_fused_emit_kernel (PCS_COMPACT_PATH=single: pcs_fused_compact_kernel)"}[args.mode],
                          "arithmetic": policy, "avg_launch_ms": round(kern_ms, 5),
+                         "long_sample_ms": round(long_sample[0], 5) if long_sample else None,
+                         "long_sample_launches": long_sample[1] if long_sample else None,
+                         "long_sample_frac": round(algo_bytes / (long_sample[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if long_sample else None,
                          "algorithmic_bytes_per_launch": round(algo_bytes),
                          "algorithmic_bytes_per_point": round(bytes_pp, 3),
                          "timing": roofline_timing},
@@ -1608,7 +1547,9 @@ def main():
                 out["per_kernel_unprofiled_us"] = pk
         if world == 1 and not args.no_cpu_baseline:
             with Leg(out, "cpu_baseline"):
-                out["cpu_baseline"] = cpu_baseline(cfgs, host0[0], host0[1], args.cpu_seconds)
+                if cpu_first is None:
+                    raise RuntimeError(cpu_first_error or "cpu baseline did not run")
+                out["cpu_baseline"] = cpu_first
                 if args.mode == "dense":
                     out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)

@@ -83,6 +83,9 @@ void pcs_oracle_deproject_omp(const pcs_stream_config* sc, const uint16_t* depth
 int  pcs_oracle_send_simd_omp(const pcs_stream_config* sc, const float* vertices, const float* texcoords,
                               int n_points, const uint8_t* color, int16_t* buffer, size_t buffer_shorts, int n_threads);
 int  pcs_oracle_max_threads(void);
+/* first-touch placement of a sample buffer by the team that will use it (pack loop's work-sharing); src NULL = zero */
+void pcs_oracle_place_omp(void* dst, const void* src, size_t n_points, size_t bytes_per_point, int n_threads);
+void pcs_oracle_team_cpus(int* cpus, int n_threads);
 
 #ifdef __cplusplus
 }

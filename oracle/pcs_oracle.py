@@ -20,9 +20,15 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    """Always runs make (a no-op when the library is newer than every source and header it depends on, incl.
+    include/pcs_hip.h): a checker left over from before a header change must not survive it."""
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:      # two test processes must not run make at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout[-4000:])
     return _LIB_PATH
 
 
@@ -59,6 +65,10 @@ def lib():
         L.pcs_oracle_deproject_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pcs_oracle_send_simd_omp.restype = C.c_int
         L.pcs_oracle_send_simd_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.pcs_oracle_place_omp.restype = None
+        L.pcs_oracle_place_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.pcs_oracle_team_cpus.restype = None
+        L.pcs_oracle_team_cpus.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 

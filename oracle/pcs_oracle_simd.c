@@ -14,6 +14,9 @@
  *
  * Build: gcc -O3 -std=c11 -ffp-contract=off -fopenmp -mavx2 -mfma -fPIC
  */
+#define _GNU_SOURCE
+#include <sched.h>
+
 #include "pcs_oracle_impl.h"
 
 #include <immintrin.h>
@@ -26,6 +29,36 @@ int pcs_oracle_simd_available(void)
 }
 
 int pcs_oracle_max_threads(void) { return omp_get_max_threads(); }
+
+/* First-touch placement for the timed sample: copies n_points records of bytes_per_point bytes with the SAME
+ * work-sharing as the pack loop below (static chunks of 10000 four-point iterations, :413), so that with
+ * OMP_PROC_BIND set every page of a freshly mapped buffer is first written — and therefore physically placed on
+ * the NUMA node — by the thread that will later read or write it. src == NULL zero-fills. */
+void pcs_oracle_place_omp(void* dst, const void* src, size_t n_points, size_t bytes_per_point, int n_threads)
+{
+    const long n4 = (long)(n_points & ~(size_t)3);
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(static, 10000) num_threads(n_threads)
+    for (long i = 0; i < n4; i += 4) {
+        uint8_t* d = (uint8_t*)dst + (size_t)i * bytes_per_point;
+        if (src) memcpy(d, (const uint8_t*)src + (size_t)i * bytes_per_point, 4 * bytes_per_point);
+        else     memset(d, 0, 4 * bytes_per_point);
+    }
+    const size_t done = (size_t)n4 * bytes_per_point, all = n_points * bytes_per_point;
+    if (all > done) {
+        if (src) memcpy((uint8_t*)dst + done, (const uint8_t*)src + done, all - done);
+        else     memset((uint8_t*)dst + done, 0, all - done);
+    }
+}
+
+/* Which CPU each thread of a team of n_threads runs on (cpus[n_threads]) — recorded next to the sample so a line
+ * says where its threads were bound. */
+void pcs_oracle_team_cpus(int* cpus, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+    { cpus[omp_get_thread_num()] = sched_getcpu(); }
+}
 
 /* One point: lanes 0..2 of the result are the world x,y,z in float millimetres, lane 3 junk.
  * col0..col2, col3 = columns of the top 3x4 of tf_mat (:69-72). */

@@ -151,8 +151,15 @@ public:
     {
         fp_ = fopen(path, "rb");
         if (!fp_) { err = "cannot open file"; return false; }
-        char magic[13];
-        if (fread(magic, 1, 13, fp_) != 13 || memcmp(magic, "#ROSBAG V2.0\n", 13) != 0) { err = "not a ROS bag v2.0 file"; return false; }
+        char magic[40] = {0};
+        const size_t got = fread(magic, 1, sizeof magic - 1, fp_);
+        if (got >= 13 && memcmp(magic, "#ROSBAG V2.0\n", 13) == 0) {
+            /* a recording */
+        } else if (got >= 27 && memcmp(magic, "version https://git-lfs", 23) == 0) {
+            /* what a checkout without `git lfs pull` holds in place of samples/*.bag (.gitattributes:1) */
+            err = "a Git-LFS pointer file, not the recording itself (run `git lfs pull` to fetch the .bag)";
+            return false;
+        } else { err = "not a ROS bag v2.0 file"; return false; }
         fseek(fp_, 0, SEEK_END);
         const size_t fsize = (size_t)ftell(fp_);
         size_t pos = 13;

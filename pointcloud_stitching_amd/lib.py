@@ -80,14 +80,15 @@ class PcsBuildError(RuntimeError):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libpcs_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    if os.path.exists(LIB_PATH) and not force:
-        srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
-                if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(INCLUDE_DIR, "pcs_hip.h")]
-        if all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
-            return LIB_PATH
-    cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    """Compile libpcs_hip.so and libpcs_node.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+    Always defers to make — a no-op when both libraries are newer than every source, header and the Makefile — so a
+    library left over from before a source change cannot be loaded; a lock keeps concurrent processes from building at once."""
+    import fcntl
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose:
         print(proc.stdout)
     if proc.returncode != 0 or not os.path.exists(LIB_PATH):
@@ -96,12 +97,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 def load() -> C.CDLL:
-    """Load libpcs_hip.so (building it first if it is missing). Raises if that is impossible."""
+    """Load libpcs_hip.so (make runs first: it rebuilds a missing or stale library). Raises if that is impossible."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        build()
+    build()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:   # pragma: no cover - depends on the box

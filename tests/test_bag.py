@@ -173,3 +173,18 @@ def test_camera_cli_plays_a_bag(tools, oracle, tmp_path, compression):
     want, _ = oracle.process_frames([cfg], [frames[2][0]], [frames[2][1]])
     got = np.fromfile(out, dtype=np.uint8)[4:4 + want.nbytes].view(np.int16).reshape(-1, 5)
     assert (got == want).all()
+
+
+def test_git_lfs_pointer_is_named(tools, tmp_path):
+    """The reference's samples/*.bag are Git-LFS pointers in a plain checkout (.gitattributes:1): the reader says so
+    instead of 'not a ROS bag'."""
+    path = str(tmp_path / "samples.bag")
+    with open(path, "w") as f:
+        f.write("version https://git-lfs.github.com/spec/v1\noid sha256:" + "0" * 64 + "\nsize 134350502\n")
+    r = info(tools, path)
+    assert r.returncode != 0 and "Git-LFS pointer" in (r.stderr + r.stdout)
+    short = str(tmp_path / "short.bag")
+    with open(short, "w") as f:
+        f.write("#ROS")
+    r = info(tools, short)
+    assert r.returncode != 0 and "not a ROS bag v2.0 file" in (r.stderr + r.stdout)

@@ -195,10 +195,25 @@ def test_bench_leg_guard_records_and_swallows_exceptions():
             raise KeyboardInterrupt
 
 
-def test_bench_reports_physical_cores():
-    b = _load_bench_module()
-    n = b._physical_cores()
+def test_cpu_sample_reports_physical_cores():
+    from oracle import cpu_baseline as CB
+    n = CB._physical_cores()
     assert n is None or (1 <= n <= (os.cpu_count() or 1))
+    allowed = os.sched_getaffinity(0)
+    m = CB._physical_cores(allowed)
+    assert m is None or (1 <= m <= len(allowed))
+
+
+def test_cpu_sample_child_process_line():
+    """bench.py's cpu_baseline leg runs oracle/cpu_baseline.py as a child with the OpenMP team bound; the object it prints
+    carries the median, its spread and where the team ran. (A tiny geometry: this is the contract, not a measurement.)"""
+    b = _load_bench_module()
+    d = b.cpu_baseline(64, 48, 2, 0.3)
+    assert d["kind"] == "port" and d["unit"] == "Mpoints/s" and d["statistic"] == "median" and d["passes"] >= 30
+    assert d["p10_value"] <= d["value"] <= d["p90_value"] <= d["best_value"]
+    assert d["cores"] >= 1 and len(d["team_cpus"]) == d["cores"] and d["t1_value"] > 0 and d["with_deprojection_value"] > 0
+    assert "OMP_PROC_BIND=close" in d["sample"] and "OMP_PLACES=cores" in d["sample"]
+    assert d["host_physical_cores"] >= 1 and d["host_logical_cpus"] >= d["host_physical_cores"]
 
 
 def test_route_choice_never_depends_on_how_the_script_was_launched():
