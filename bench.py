@@ -376,12 +376,16 @@ def run_node(args):
         # fewer GPUs than asked for: never a reason to print no line — fold the peers onto the GPUs that exist, and say so
         note = f"{args.gpus} GPUs requested, {avail} visible: peers folded onto the visible GPUs (virtual peers)"
         devices = [d % avail for d in devices]
-    virtual = len(set(devices)) < P
     defaults = (args.streams, args.width, args.height) == (8, 1280, 720)
     total_streams, W, H = (16, 1920, 1080) if (config5 and defaults) else (args.streams, args.width, args.height)
     if total_streams % P:
-        raise SystemExit(f"{total_streams} streams do not divide over {P} peers")
+        # never an exit without a line: use the largest peer count <= P that divides the streams, on the first GPUs, and say so
+        P2 = max(q for q in range(1, P + 1) if total_streams % q == 0)
+        note = ((note + "; ") if note else "") + (f"{total_streams} streams do not divide over {P} peers: folded to {P2} peers "
+                                                   f"({total_streams // P2} cameras each) on the first {P2} device entries")
+        devices, P = devices[:P2], P2
     S, npts = total_streams // P, W * H
+    virtual = len(set(devices)) < P
     LEAF = args.leaf
     flags = FLAG_DROP_INVALID if config5 else {"drop_invalid": FLAG_DROP_INVALID, "cutoff": FLAG_CUTOFF}.get(args.mode, 0)
     cfgs = [Syn.synth_stream_config(W, H, g) for g in range(total_streams)]
@@ -507,7 +511,7 @@ def run_node(args):
 
     # ---- where a frame-set's time goes (HIP events on the root GPU; a separate loop: the events cost host time) ----------------------
     node.set_timing(True)
-    ph = {"kernel": [], "exchange": [], "root": []}
+    ph = {"kernel": [], "exchange": [], "root": [], "submit_host": [], "exchange_host": []}
     xbytes = reduced = 0
     n_ph = 30
     t = submit()
@@ -515,11 +519,26 @@ def run_node(args):
         t2 = submit(); wait(t); t = t2
         st = node.last_stats()
         ph["kernel"].append(st["kernels_ms"]); ph["exchange"].append(st["exchange_ms"]); ph["root"].append(st["root_ms"])
-        xbytes, reduced = st["exchanged_bytes"], st["reduced"]
+        ph["submit_host"].append(st["submit_host_ms"]); ph["exchange_host"].append(st["exchange_host_ms"])
+        xbytes, reduced = st["exchanged_bytes"] + st["direct_bytes"], st["reduced"]
         counts = [int(x) for x in cnt_arr] if not config5 else None       # of the same frame-set as xbytes
     wait(t)
     node.set_timing(False)
     kern_ms = float(np.median(ph["kernel"]))
+    # ---- what answered and what connects the GPUs: the first multi-GPU record must explain itself --------------------------------
+    rccl = {"runtime_version": node.rccl_version, "header_version": node.rccl_header_version, "library": node.rccl_library}
+    links, link_error = [], None
+    try:
+        probe_bytes = 0 if not config5 else 8 << 20
+        per_peer_ms = node.probe_links(probe_bytes, 5) if (P > 1 and node_error is None) else [0.0] * P
+        pb = (S * npts * 10) if not config5 else probe_bytes
+        for r in range(P):
+            ln = node.link_info(r)
+            ln["probe_ms"] = round(per_peer_ms[r], 5)
+            ln["probe_GBps"] = round(pb / (per_peer_ms[r] * 1e-3) / 1e9, 1) if per_peer_ms[r] > 0 else None
+            links.append(ln)
+    except Exception as e:      # noqa: BLE001
+        link_error = f"{type(e).__name__}: {e}"[:300]
 
     pts_step = total_streams * npts
     ms_per_step = elapsed * 1e3 / args.steps
@@ -562,6 +581,13 @@ def run_node(args):
                    "gather_to_rank0": bool(P > 1 and node_error is None), "devices": devices,
                    "parallelism": f"streams sharded {S}/GPU x {P}"},
         "rccl_ranks": node.rccl_ranks, "direct_store_gather": bool(args.node_direct_child),
+        "rccl": rccl,
+        "links": {"per_peer": links, "probe": "pcs_node_probe_links: one ncclSend/ncclRecv pair at a time of one peer's payload "
+                                               "(config5: 8 MiB) into GPU 0, event pair on GPU 0's communication stream, mean of 5; link_type "
+                                               "per hipExtGetLinkTypeAndHopCount (4 = xGMI)", "error": link_error},
+        "host_enqueue_ms": {"submit": round(float(np.median(ph["submit_host"])), 5), "exchange": round(float(np.median(ph["exchange_host"])), 5),
+                            "note": "host time of ONE thread per frame-set: submit = every peer's kernels enqueued; exchange = the grouped "
+                                    "ncclSend/ncclRecv (config5: + the root's sort + mean) enqueued"},
         "check": checked,
         "phases_ms": {"kernel": round(kern_ms, 5), "exchange": round(float(np.median(ph["exchange"])), 5),
                       "root": round(float(np.median(ph["root"])), 5),

@@ -87,6 +87,9 @@ int  pcs_node_process_device(pcs_node* node, const uint16_t* const* d_depth, con
 int  pcs_node_submit_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                             int16_t* d_stitched_payload_root, size_t stitched_shorts, int* ticket);
 int  pcs_node_wait(pcs_node* node, int ticket, int* points_per_stream, int* total_points);
+/* Fault injection for the test-suite: the NEXT grouped exchange fails as if ncclGroupStart had (communicators aborted, node
+ * unusable) — the only way to walk the abort path on a healthy box. */
+int  pcs_node_inject_exchange_failure(pcs_node* node);
 
 /* Where a frame-set's time went, from HIP events on the ROOT GPU (pcs_node_set_timing(node, 1) before the submit; the
  * events cost a few host microseconds per submit, hence opt-in). pcs_node_last_stats returns the figures of the ticket most
@@ -96,11 +99,42 @@ typedef struct pcs_node_stats {
     float    kernels_ms;         /* root kernel stream: this submit's first enqueue -> the root's own kernels done            */
     float    exchange_ms;        /* root communication stream: group enqueued (all its peers' kernels done) -> payloads landed */
     float    root_ms;            /* voxel tickets: the root's sort + segmented mean                                            */
-    int64_t  exchanged_bytes;    /* bytes the peers sent to the root                                                           */
+    int64_t  exchanged_bytes;    /* bytes the grouped RCCL exchange moved to the root (0 for a direct-store ticket)            */
     int64_t  reduced;            /* points in the stitched cloud (stitch tickets) / partials the root reduced (voxel tickets)  */
+    int64_t  direct_bytes;       /* PCS_NODE_DIRECT_STORE tickets: bytes the peers' own kernels stored into the root's buffer  */
+    float    submit_host_ms;     /* HOST time the submit spent enqueueing every peer's kernels (filled with or without timing) */
+    float    exchange_host_ms;   /* HOST time spent enqueueing this ticket's exchange (+ the root's reduce for a voxel ticket) */
 } pcs_node_stats;
+/* The setting is latched into a ticket when it is SUBMITTED: changing it while a frame-set is in flight affects later ones only. */
 int  pcs_node_set_timing(pcs_node* node, int enable);
 int  pcs_node_last_stats(const pcs_node* node, pcs_node_stats* out);
+
+/* Which RCCL answered. libpcs_node is compiled against /opt/rocm's rccl.h; the dynamic loader binds the librccl.so.1 the
+ * process loaded first (under Python that is the one bundled with torch). pcs_node_rccl_version = ncclGetVersion() of the
+ * bound library (0: the node has no communicator), pcs_node_rccl_header_version = NCCL_VERSION_CODE it was compiled for,
+ * pcs_node_rccl_library = the bound library's path. pcs_node_create_ex refuses (PCS_ERR_UNSUPPORTED) a different MAJOR version. */
+int  pcs_node_rccl_version(const pcs_node* node);
+int  pcs_node_rccl_header_version(void);
+const char* pcs_node_rccl_library(const pcs_node* node);
+
+/* What connects peer `peer`'s GPU to the root GPU (hipDeviceCanAccessPeer, hipDeviceGetP2PAttribute,
+ * hipExtGetLinkTypeAndHopCount); -1 where the runtime gave no answer. link_type follows HSA_AMD_LINK_INFO_TYPE_*
+ * (1 = QPI, 2 = PCIe, 3 = InfiniBand, 4 = xGMI). */
+typedef struct pcs_node_link {
+    int32_t device, root_device;
+    int32_t same_device;         /* a virtual peer of the root's GPU: no link involved                         */
+    int32_t can_access_root;     /* hipDeviceCanAccessPeer(device -> root): what PCS_NODE_DIRECT_STORE needs   */
+    int32_t link_type, hops;     /* hipExtGetLinkTypeAndHopCount                                               */
+    int32_t performance_rank;    /* hipDevP2PAttrPerformanceRank                                               */
+    int32_t native_atomics;      /* hipDevP2PAttrNativeAtomicSupported                                         */
+} pcs_node_link;
+int  pcs_node_link_info(pcs_node* node, int peer, pcs_node_link* out);
+/* Per-peer transfer time into the root, one peer at a time: `bytes` (0 or too large = the smallest peer payload capacity) from
+ * the peer's payload slot into a scratch buffer on the root as a group of ONE ncclSend/ncclRecv pair, between an event pair on
+ * the root's communication stream; mean of `repeats` after one untimed transfer. ms_per_peer[n_peers], entry 0 (the root) = 0.
+ * The node must be idle (no ticket in flight). Without a communicator every entry is 0. A frame-set's grouped exchange is one
+ * RCCL operation for all pairs, so this is the only way to see a single link. */
+int  pcs_node_probe_links(pcs_node* node, size_t bytes, int repeats, float* ms_per_peer);
 
 /* ---- BASELINE configs[4]: voxel-grid downsample of the cloud the node's cameras stitch to ---------------------------- *
  * 16 x 1920x1080 streams, 2 per GPU, invalid-depth compaction, voxel grid of the stitched cloud on the root. Two routes, the

@@ -7,12 +7,16 @@
 // communicator rank and the communication stream. Normally peers and GPUs are the same list; a device id that repeats
 // makes VIRTUAL peers that share a GPU (their transfers to the root become RCCL self send/recv pairs on that GPU's
 // communicator) — how the one-GPU development boxes run every N > 1 code path on real RCCL.
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <dlfcn.h>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -46,6 +50,7 @@ enum TicketKind { kStitch = 0, kVoxel = 1 };
 
 struct Ticket {
     bool busy = false, exchanged = false;
+    bool timing = false;                  // pcs_node_set_timing as of the SUBMIT: the events of this slot were recorded (or not) then
     int id = -1, kind = kStitch, rc = PCS_OK;
     std::string err;
     // stitch
@@ -56,8 +61,15 @@ struct Ticket {
     int leaf = 0;
     int16_t* d_voxels = nullptr;
     size_t voxels_shorts = 0;
-    int64_t exchanged_bytes = 0;
+    int64_t exchanged_bytes = 0;          // moved by the grouped RCCL exchange
+    int64_t direct_bytes = 0;             // stored into the root's buffer by the peers' own kernels (PCS_NODE_DIRECT_STORE)
+    float submit_host_ms = 0.0f, exchange_host_ms = 0.0f;     // host time spent enqueueing (submit without / the exchange itself)
 };
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 }  // namespace
 
@@ -69,6 +81,7 @@ struct pcs_node {
     std::vector<Gpu> gpus;
     bool have_comm = false;
     bool broken = false;                  // an RCCL call failed: the communicators were aborted
+    bool inject_fail = false;             // pcs_node_inject_exchange_failure: the next exchange fails as if RCCL had
     bool pred = false;                    // CUTOFF / DROP_INVALID: the exchange is sized by data-dependent counts
     bool timing = false;
     bool direct = false;                  // PCS_NODE_DIRECT_STORE and peer access granted: dense tickets need no exchange
@@ -92,6 +105,8 @@ struct pcs_node {
     hipEvent_t ev_k0[2] = {nullptr, nullptr}, ev_k1[2] = {nullptr, nullptr}, ev_r0[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     hipEvent_t ev_x0[2] = {nullptr, nullptr};     // root: comm stream, the group is about to be enqueued
     pcs_node_stats last{};
+    int rccl_version = 0;                 // ncclGetVersion of the library that answered (0: no communicator was asked for)
+    std::string rccl_library;             // its path (dladdr)
     std::string err;
 };
 
@@ -122,7 +137,8 @@ int run_exchange(pcs_node* n, const std::vector<Xfer>& xs)
 {
     if (!n->have_comm || xs.empty()) return PCS_OK;
     Gpu& root = n->gpus[n->peers[0].gpu];
-    ncclResult_t first = ncclGroupStart();
+    ncclResult_t first = n->inject_fail ? ncclInternalError : ncclGroupStart();
+    n->inject_fail = false;
     if (first == ncclSuccess) {
         for (const Xfer& x : xs) {
             if (!x.bytes) continue;
@@ -253,7 +269,11 @@ void issue_exchange(pcs_node* n, Ticket& tk)
     const int slot = tk.id & 1, S = n->per_dev, P = n->n_peers;
     Peer& root = n->peers[0];
     Gpu& rootg = n->gpus[root.gpu];
+    const double t_host0 = now_ms();
     auto body = [&]() -> int {
+        // an earlier exchange failed and the communicators are gone: this frame-set was never gathered — say so instead of
+        // returning counts for a buffer that holds the root's slice only (include/pcs_node.h: every later call fails)
+        if (n->broken) return nfail(n, PCS_ERR_HIP, "the node's communicators were aborted after an RCCL failure: this frame-set was not gathered");
         const bool counts_on_device = tk.kind == kVoxel || n->pred;
         if (counts_on_device) {
             // the copies were enqueued behind the kernels in submit: by now (a whole submit later in a pipelined loop) they
@@ -305,8 +325,12 @@ void issue_exchange(pcs_node* n, Ticket& tk)
             HIPCHK(n, hipSetDevice(g.dev));
             HIPCHK(n, hipStreamWaitEvent(g.comm_stream, n->peers[r].packed[slot], 0));
         }
-        if (n->timing) { HIPCHK(n, hipSetDevice(rootg.dev)); HIPCHK(n, hipEventRecord(n->ev_x0[slot], rootg.comm_stream)); }
-        if (tk.kind == kStitch && n->direct && !n->pred) xs.clear();      // the peers' kernels stored into the root themselves
+        if (tk.timing) { HIPCHK(n, hipSetDevice(rootg.dev)); HIPCHK(n, hipEventRecord(n->ev_x0[slot], rootg.comm_stream)); }
+        if (tk.kind == kStitch && n->direct && !n->pred) {
+            // the peers' kernels stored into the root themselves: nothing is exchanged, and the stats say so
+            tk.direct_bytes = tk.exchanged_bytes; tk.exchanged_bytes = 0;
+            xs.clear();
+        }
         if (!(n->node_flags & PCS_NODE_NO_EXCHANGE)) {
             const int rc = run_exchange(n, xs);
             if (rc != PCS_OK) return rc;
@@ -325,7 +349,7 @@ void issue_exchange(pcs_node* n, Ticket& tk)
             hipStream_t ks = static_cast<hipStream_t>(pcs_get_stream(n->reduce_ctx));      // not the root's kernel stream: see reduce_ctx
             HIPCHK(n, hipStreamWaitEvent(ks, root.packed[slot], 0));                        // the root's own partials
             if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, rootg.drained[slot], 0));    // everybody else's
-            if (n->timing) HIPCHK(n, hipEventRecord(n->ev_r0[slot], ks));
+            if (tk.timing) HIPCHK(n, hipEventRecord(n->ev_r0[slot], ks));
             PCSCHK(n, n->reduce_ctx, pcs_voxel_grid_from_partials_device(n->reduce_ctx, static_cast<const uint64_t*>(root.d_vkeys[slot]),
                                                                     static_cast<const pcs_voxel_partial*>(root.d_vparts[slot]), (int)tk.total,
                                                                     nullptr, tk.leaf, tk.d_voxels, tk.voxels_shorts,
@@ -337,6 +361,7 @@ void issue_exchange(pcs_node* n, Ticket& tk)
         rc = reduce();
     }
     if (rc != PCS_OK) { tk.rc = rc; tk.err = n->err; }
+    tk.exchange_host_ms = (float)(now_ms() - t_host0);
 }
 
 // The other slot's exchange, if a submit left it pending (predicate / voxel: it waits for device counts).
@@ -362,12 +387,15 @@ void fill_stats(pcs_node* n, const Ticket& tk)
     st.ticket = tk.id;
     st.exchanged_bytes = tk.exchanged_bytes;
     st.reduced = (int64_t)tk.total;
-    if (!n->timing) return;
+    st.direct_bytes = tk.direct_bytes;
+    st.submit_host_ms = tk.submit_host_ms;
+    st.exchange_host_ms = tk.exchange_host_ms;
+    if (!tk.timing) return;          // latched at submit: a set_timing while the ticket was in flight must not read events never recorded
     const int slot = tk.id & 1;
     Gpu& rootg = n->gpus[n->peers[0].gpu];
     if (hipSetDevice(rootg.dev) != hipSuccess) return;
     (void)hipEventElapsedTime(&st.kernels_ms, n->ev_k0[slot], n->ev_k1[slot]);
-    if (n->have_comm) (void)hipEventElapsedTime(&st.exchange_ms, n->ev_x0[slot], rootg.drained[slot]);
+    if (n->have_comm && !tk.direct_bytes) (void)hipEventElapsedTime(&st.exchange_ms, n->ev_x0[slot], rootg.drained[slot]);
     if (tk.kind == kVoxel) (void)hipEventElapsedTime(&st.root_ms, n->ev_r0[slot], n->ev_done[slot]);
     (void)hipGetLastError();
 }
@@ -551,6 +579,21 @@ int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int
         n->direct = true;
     }
     if (n_devices > 1 && !(node_flags & PCS_NODE_NO_EXCHANGE)) {
+        // Which RCCL answers: this library is compiled against /opt/rocm's rccl.h, but the dynamic loader binds whatever
+        // librccl.so.1 the process loaded first (under Python: the one bundled with torch). Record version and path, and refuse
+        // a different MAJOR version — its ABI is not the one these calls were compiled for.
+        int ver = 0;
+        if (ncclGetVersion(&ver) != ncclSuccess) return bail(PCS_ERR_HIP, "ncclGetVersion", "failed");
+        n->rccl_version = ver;
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void*>(&ncclGetVersion), &di) && di.dli_fname) n->rccl_library = di.dli_fname;
+        const int major_rt = ver >= 10000 ? ver / 10000 : ver / 1000, major_hdr = NCCL_MAJOR;
+        if (major_rt != major_hdr) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "runtime version %d (%s) has major %d, compiled against %d.%d.%d", ver,
+                     n->rccl_library.c_str(), major_rt, NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+            return bail(PCS_ERR_UNSUPPORTED, "RCCL", msg);
+        }
         // one communicator rank per GPU, all in this process; virtual peers share their GPU's rank
         std::vector<int> ids;
         std::vector<ncclComm_t> comms(n->gpus.size(), nullptr);
@@ -568,6 +611,92 @@ int pcs_node_create(pcs_node** out, int n_devices, const int* device_ids, int st
                     const pcs_stream_config* streams, uint32_t flags, int downsample)
 {
     return pcs_node_create_ex(out, n_devices, device_ids, streams_per_device, streams, flags, downsample, 0u);
+}
+
+int pcs_node_inject_exchange_failure(pcs_node* n)
+{
+    if (!n) return PCS_ERR_INVALID_ARG;
+    n->inject_fail = true;
+    return PCS_OK;
+}
+
+int pcs_node_rccl_version(const pcs_node* n) { return n ? n->rccl_version : 0; }
+int pcs_node_rccl_header_version(void) { return NCCL_VERSION_CODE; }
+const char* pcs_node_rccl_library(const pcs_node* n) { return n ? n->rccl_library.c_str() : ""; }
+
+int pcs_node_link_info(pcs_node* n, int peer, pcs_node_link* out)
+{
+    if (!n || !out || peer < 0 || peer >= n->n_peers) return nfail(n, PCS_ERR_INVALID_ARG, "bad peer index");
+    std::memset(out, 0, sizeof *out);
+    const int root = n->peers[0].dev, dev = n->peers[peer].dev;
+    out->device = dev; out->root_device = root;
+    out->same_device = dev == root;
+    out->link_type = -1; out->hops = -1; out->performance_rank = -1;
+    if (dev == root) { out->can_access_root = 1; out->native_atomics = 1; return PCS_OK; }
+    int v = 0;
+    if (hipDeviceCanAccessPeer(&v, dev, root) == hipSuccess) out->can_access_root = v;
+    if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrPerformanceRank, dev, root) == hipSuccess) out->performance_rank = v;
+    if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrNativeAtomicSupported, dev, root) == hipSuccess) out->native_atomics = v;
+    uint32_t lt = 0, hc = 0;
+    if (hipExtGetLinkTypeAndHopCount(dev, root, &lt, &hc) == hipSuccess) { out->link_type = (int32_t)lt; out->hops = (int32_t)hc; }
+    (void)hipGetLastError();
+    return PCS_OK;
+}
+
+// One peer at a time: `bytes` from the peer's payload slot 0 into the root's scratch, as its OWN group of one send/recv pair,
+// bracketed by an event pair on the root's communication stream; `repeats` transfers per peer, the mean is reported. The
+// grouped exchange of a frame-set launches all pairs as one RCCL operation, so per-peer figures cannot be read off it.
+int pcs_node_probe_links(pcs_node* n, size_t bytes, int repeats, float* ms_per_peer)
+{
+    if (!n || !ms_per_peer) return nfail(n, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (n->broken) return nfail(n, PCS_ERR_HIP, "the node's communicators were aborted after an RCCL failure: destroy it");
+    if (n->inflight[0].busy || n->inflight[1].busy) return nfail(n, PCS_ERR_INVALID_ARG, "wait for the frame-sets in flight before probing the links");
+    const int P = n->n_peers;
+    for (int r = 0; r < P; r++) ms_per_peer[r] = 0.0f;
+    if (!n->have_comm || P < 2) return PCS_OK;
+    if (repeats < 1) repeats = 1;
+    Peer& root = n->peers[0];
+    Gpu& rootg = n->gpus[root.gpu];
+    HIPCHK(n, hipSetDevice(root.dev));
+    size_t cap = 0;
+    for (int r = 1; r < P; r++) cap = cap ? std::min(cap, n->peers[r].payload_shorts * sizeof(int16_t)) : n->peers[r].payload_shorts * sizeof(int16_t);
+    if (!bytes || bytes > cap) bytes = cap;
+    void* scratch = nullptr;
+    PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &scratch, bytes + 64));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PCS_OK;
+    auto body = [&]() -> int {
+        HIPCHK(n, hipEventCreate(&e0));
+        HIPCHK(n, hipEventCreate(&e1));
+        for (int r = 1; r < P; r++) {
+            float sum = 0.0f;
+            for (int it = -1; it < repeats; it++) {             // it == -1: untimed (connection set-up on first use)
+                HIPCHK(n, hipSetDevice(rootg.dev));
+                HIPCHK(n, hipEventRecord(e0, rootg.comm_stream));
+                std::vector<Xfer> one{Xfer{r, n->peers[r].d_payload[0], scratch, bytes}};
+                const int xr = run_exchange(n, one);
+                if (xr != PCS_OK) return xr;
+                HIPCHK(n, hipSetDevice(rootg.dev));
+                HIPCHK(n, hipEventRecord(e1, rootg.comm_stream));
+                HIPCHK(n, hipEventSynchronize(e1));
+                Gpu& g = n->gpus[n->peers[r].gpu];
+                HIPCHK(n, hipSetDevice(g.dev));
+                HIPCHK(n, hipStreamSynchronize(g.comm_stream));
+                float ms = 0.0f;
+                HIPCHK(n, hipSetDevice(rootg.dev));
+                HIPCHK(n, hipEventElapsedTime(&ms, e0, e1));
+                if (it >= 0) sum += ms;
+            }
+            ms_per_peer[r] = sum / (float)repeats;
+        }
+        return PCS_OK;
+    };
+    rc = body();
+    (void)hipSetDevice(root.dev);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    pcs_device_free(root.ctx, scratch);
+    return rc;
 }
 
 int pcs_node_set_timing(pcs_node* n, int enable)
@@ -606,9 +735,10 @@ int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const ui
     if (rc != PCS_OK) return rc;
     Ticket& tk = *tkp;
     const int S = n->per_dev, P = n->n_peers;
+    const double t_host0 = now_ms();
     tk = Ticket{};
     tk.cnt.assign((size_t)P * (S + 1), 0);
-    tk.kind = kStitch; tk.d_stitched = d_stitched; tk.id = n->next_ticket;
+    tk.kind = kStitch; tk.d_stitched = d_stitched; tk.id = n->next_ticket; tk.timing = n->timing;
     // 1. kernels. A failure here leaves the ticket free and the slot's drained events as they were (complete): the kernels
     //    already enqueued write payload slots nothing will read, and the next submit simply reuses the slot.
     for (int r = 0; r < P; r++) {
@@ -616,7 +746,7 @@ int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const ui
         HIPCHK(n, hipSetDevice(p.dev));
         hipStream_t ks = kstream(p);
         if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
-        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
+        if (r == 0 && tk.timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
         // where this peer packs: the root into the head of the stitched buffer; a peer into its payload slot — or, with direct
         // stores and no predicate (its camera-order offset follows from the configuration), straight into the ROOT GPU's stitched
         // buffer over xGMI: the pack kernel's own stores are the gather
@@ -629,10 +759,11 @@ int pcs_node_submit_device(pcs_node* n, const uint16_t* const* d_depth, const ui
                                                    n->pred ? static_cast<int32_t*>(p.d_counts) : nullptr));
         if (n->pred)
             HIPCHK(n, hipMemcpyAsync(n->h_counts[slot] + (size_t)r * (S + 1), p.d_counts, sizeof(int32_t) * (S + 1), hipMemcpyDeviceToHost, ks));
-        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
+        if (r == 0 && tk.timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
         HIPCHK(n, hipEventRecord(p.packed[slot], ks));
     }
     tk.busy = true;
+    tk.submit_host_ms = (float)(now_ms() - t_host0);        // every peer's kernels enqueued; the exchange's own enqueue is exchange_host_ms
     *ticket = n->next_ticket++;
     // 2. the older frame-set's exchange, if it was waiting for its counts
     flush_other(n, slot);
@@ -680,7 +811,7 @@ int pcs_node_wait(pcs_node* n, int ticket, int* points_per_stream, int* total_po
     const int rc = wait_common(n, ticket, kStitch, tk);
     if (rc != PCS_OK) return rc;
     const int S = n->per_dev;
-    if (n->timing) {            // the root's own kernels may still be running when the peers' payloads have landed
+    if (tk->timing) {           // the root's own kernels may still be running when the peers' payloads have landed
         HIPCHK(n, hipSetDevice(n->peers[0].dev));
         HIPCHK(n, hipEventSynchronize(n->peers[0].packed[ticket & 1]));
     }
@@ -754,23 +885,26 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     if (rc != PCS_OK) return rc;
     Ticket& tk = *tkp;
     const int S = n->per_dev, P = n->n_peers;
+    const double t_host0 = now_ms();
     tk = Ticket{};
     tk.kind = kVoxel; tk.id = n->next_ticket; tk.leaf = leaf_mm; tk.d_voxels = d_voxels; tk.voxels_shorts = voxels_shorts;
+    tk.timing = n->timing;
     for (int r = 0; r < P; r++) {
         Peer& p = n->peers[r];
         HIPCHK(n, hipSetDevice(p.dev));
         hipStream_t ks = kstream(p);
         if (n->have_comm) HIPCHK(n, hipStreamWaitEvent(ks, n->gpus[p.gpu].drained[slot], 0));
-        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
+        if (r == 0 && tk.timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
         PCSCHK(n, p.ctx, pcs_process_frames_voxel_partials_device(p.ctx, d_depth + (size_t)r * S, d_color + (size_t)r * S, leaf_mm,
                                                                   static_cast<uint64_t*>(p.d_vkeys[slot]),
                                                                   static_cast<pcs_voxel_partial*>(p.d_vparts[slot]),
                                                                   r == 0 ? n->vcap_total : p.vcap, static_cast<int32_t*>(p.d_vcount[slot])));
         HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + r, p.d_vcount[slot], sizeof(int32_t), hipMemcpyDeviceToHost, ks));
-        if (r == 0 && n->timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
+        if (r == 0 && tk.timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
         HIPCHK(n, hipEventRecord(p.packed[slot], ks));
     }
     tk.busy = true;
+    tk.submit_host_ms = (float)(now_ms() - t_host0);
     *ticket = n->next_ticket++;
     flush_other(n, slot);
     return PCS_OK;
@@ -799,6 +933,11 @@ int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, c
                      voxels_shorts, pcs_node_max_payload_shorts(n));
     if (n->inflight[0].busy || n->inflight[1].busy)
         return nfail(n, PCS_ERR_INVALID_ARG, "wait for the frame-sets in flight before a synchronous voxel call");
+    if (route == PCS_NODE_VOXEL_PAYLOADS && n->n_peers > 1 && !n->have_comm)
+        // nothing is gathered without a communicator: the stitched buffer holds the root's slice only, and a voxel grid over
+        // the whole node's point count would read memory no kernel wrote
+        return nfail(n, PCS_ERR_UNSUPPORTED, "route PAYLOADS needs the exchange: the node was created with PCS_NODE_NO_EXCHANGE "
+                     "(or its communicators were aborted)");
     const bool was_timing = n->timing;
     n->timing = n->timing || stats != nullptr;
     struct Restore { pcs_node* n; bool t; ~Restore() { n->timing = t; } } restore{n, was_timing};

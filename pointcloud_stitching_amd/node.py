@@ -28,7 +28,16 @@ DIRECT_STORE = 2        # PCS_NODE_DIRECT_STORE
 
 class NodeStats(C.Structure):
     _fields_ = [("ticket", C.c_int32), ("kernels_ms", C.c_float), ("exchange_ms", C.c_float), ("root_ms", C.c_float),
-                ("exchanged_bytes", C.c_int64), ("reduced", C.c_int64)]
+                ("exchanged_bytes", C.c_int64), ("reduced", C.c_int64), ("direct_bytes", C.c_int64),
+                ("submit_host_ms", C.c_float), ("exchange_host_ms", C.c_float)]
+
+
+class NodeLink(C.Structure):
+    _fields_ = [("device", C.c_int32), ("root_device", C.c_int32), ("same_device", C.c_int32), ("can_access_root", C.c_int32),
+                ("link_type", C.c_int32), ("hops", C.c_int32), ("performance_rank", C.c_int32), ("native_atomics", C.c_int32)]
+
+
+LINK_TYPES = {-1: "unknown", 0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi"}
 
 
 class VoxelStats(C.Structure):
@@ -49,6 +58,12 @@ SYMBOLS = [
     ("pcs_node_process_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _P(C.c_int), _P(C.c_int)]),
     ("pcs_node_submit_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_node_wait", C.c_int, [_VP, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    ("pcs_node_inject_exchange_failure", C.c_int, [_VP]),
+    ("pcs_node_rccl_version", C.c_int, [_VP]),
+    ("pcs_node_rccl_header_version", C.c_int, []),
+    ("pcs_node_rccl_library", C.c_char_p, [_VP]),
+    ("pcs_node_link_info", C.c_int, [_VP, C.c_int, _P(NodeLink)]),
+    ("pcs_node_probe_links", C.c_int, [_VP, C.c_size_t, C.c_int, _P(C.c_float)]),
     ("pcs_node_set_timing", C.c_int, [_VP, C.c_int]),
     ("pcs_node_last_stats", C.c_int, [_VP, _P(NodeStats)]),
     ("pcs_node_submit_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
@@ -124,6 +139,36 @@ class PcsNode:
     @property
     def rccl_ranks(self) -> int:
         return int(self._lib.pcs_node_rccl_ranks(self._h))
+
+    @property
+    def rccl_version(self) -> int:
+        """ncclGetVersion() of the librccl the process bound (0: the node has no communicator)."""
+        return int(self._lib.pcs_node_rccl_version(self._h))
+
+    @property
+    def rccl_header_version(self) -> int:
+        return int(self._lib.pcs_node_rccl_header_version())
+
+    @property
+    def rccl_library(self) -> str:
+        d = self._lib.pcs_node_rccl_library(self._h)
+        return d.decode() if d else ""
+
+    def link_info(self, peer: int) -> dict:
+        ln = NodeLink()
+        self._check(self._lib.pcs_node_link_info(self._h, int(peer), C.byref(ln)))
+        d = {f: int(getattr(ln, f)) for f, _ in NodeLink._fields_}
+        d["link"] = "same GPU" if d["same_device"] else LINK_TYPES.get(d["link_type"], str(d["link_type"]))
+        return d
+
+    def probe_links(self, nbytes: int = 0, repeats: int = 5) -> List[float]:
+        """ms per peer for `nbytes` into the root, one ncclSend/ncclRecv pair at a time (entry 0, the root, is 0)."""
+        ms = (C.c_float * len(self.devices))()
+        self._check(self._lib.pcs_node_probe_links(self._h, int(nbytes), int(repeats), ms))
+        return [float(x) for x in ms]
+
+    def inject_exchange_failure(self) -> None:
+        self._check(self._lib.pcs_node_inject_exchange_failure(self._h))
 
     def set_timing(self, enable: bool) -> None:
         self._check(self._lib.pcs_node_set_timing(self._h, int(bool(enable))))

@@ -209,7 +209,10 @@ def test_direct_store_gather_writes_the_same_stitched_buffer(oracle, flags, down
             counts, total = node.wait(t)
             assert counts == want[k - 1][1] and total == want[k - 1][0].shape[0]
             assert (_fetch(mem, out[(k - 1) & 1], total) == want[k - 1][0]).all(), k - 1
-            assert node.last_stats()["exchanged_bytes"] == 10 * sum(want[k - 1][1][2:])
+            st = node.last_stats()          # without a predicate nothing is exchanged: the kernels' own stores are reported apart
+            moved = 10 * sum(want[k - 1][1][2:])
+            assert (st["direct_bytes"], st["exchanged_bytes"]) == ((moved, 0) if flags == 0 else (0, moved))
+            assert st["submit_host_ms"] > 0
             t = t2
         # the voxel route on the same node still goes through the exchange
         tv = node.submit_voxel_device(*dev_sets[0], 60, out[0], cap)
@@ -229,6 +232,128 @@ def test_no_exchange_flag_packs_every_peer_but_gathers_nothing(oracle):
         own = sum(wcounts[:2])
         assert counts == wcounts and size == want.nbytes
         assert (buf[2:2 + own * 5].reshape(-1, 5) == want[:own]).all()       # the root's slice only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["stitch", "voxel"])
+def test_after_an_rccl_failure_every_later_call_fails(oracle, kind):
+    """include/pcs_node.h: an RCCL failure aborts the communicators and EVERY later call fails with PCS_ERR_HIP. Two tickets in
+    flight under a predicate (their exchanges are deferred); the first one's exchange is made to fail: the wait for it reports
+    the failure, and the wait for the SECOND one — whose exchange can no longer run — must not return PCS_OK with the whole
+    node's counts over a buffer nothing was gathered into."""
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    with PcsNode(cfgs, devices=[0, 0], flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
+        cap = node.max_payload_shorts
+        dd, dc = _upload(mem, depth, color)
+        out = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        if kind == "stitch":
+            t0 = node.submit_device(dd, dc, out[0], cap)
+            node.inject_exchange_failure()
+            t1 = node.submit_device(dd, dc, out[1], cap)          # issues t0's deferred exchange: it fails, parked in the ticket
+            waits = [lambda: node.wait(t0), lambda: node.wait(t1)]
+        else:
+            t0 = node.submit_voxel_device(dd, dc, 50, out[0], cap)
+            node.inject_exchange_failure()
+            t1 = node.submit_voxel_device(dd, dc, 50, out[1], cap)
+            waits = [lambda: node.wait_voxel(t0), lambda: node.wait_voxel(t1)]
+        for w in waits:
+            with pytest.raises(PcsError) as e:
+                w()
+            assert e.value.status == -3 and "abort" in str(e.value)
+        assert node.rccl_ranks == 0
+        with pytest.raises(PcsError) as e:
+            node.submit_device(dd, dc, out[0], cap)
+        assert e.value.status == -3
+        with pytest.raises(PcsError):
+            node.probe_links()
+
+
+@pytest.mark.gpu
+def test_timing_is_latched_at_submit(oracle):
+    """pcs_node_set_timing while a ticket is in flight must not make its wait read events that were never recorded."""
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, 0, 1)
+    with PcsNode(cfgs, devices=[0, 0]) as node, PcsContext(cfgs[:1]) as mem:
+        cap = node.max_payload_shorts
+        dd, dc = _upload(mem, depth, color)
+        out = mem.device_malloc(cap * 2 + 64)
+        t = node.submit_device(dd, dc, out, cap)
+        node.set_timing(True)
+        counts, total = node.wait(t)
+        st = node.last_stats()
+        assert counts == wcounts and st["kernels_ms"] == 0 and st["exchange_ms"] == 0 and st["exchanged_bytes"] > 0
+        t = node.submit_device(dd, dc, out, cap)
+        node.set_timing(False)
+        node.wait(t)
+        st = node.last_stats()
+        assert st["kernels_ms"] > 0 and st["exchange_ms"] > 0 and st["exchange_host_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_payloads_route_is_refused_without_an_exchange():
+    from pointcloud_stitching_amd.node import PcsNode, NO_EXCHANGE, VOXEL_PAYLOADS, VOXEL_PARTIALS
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    with PcsNode(cfgs, devices=[0, 0], flags=FLAG_DROP_INVALID, node_flags=NO_EXCHANGE) as node:
+        with pytest.raises(PcsError) as e:
+            node.process_voxel(depth, color, 50, VOXEL_PAYLOADS)
+        assert e.value.status == -4 and "NO_EXCHANGE" in str(e.value)
+        vox, _ = node.process_voxel(depth, color, 50, VOXEL_PARTIALS)        # the root's own cameras only, by definition of the flag
+        assert vox.shape[0] > 0
+
+
+@pytest.mark.gpu
+def test_the_node_says_which_rccl_answered_and_what_links_it_has():
+    """The first N > 1 record must explain itself: RCCL version (runtime vs the header libpcs_node was compiled against), the
+    library path that was bound, link type / hops / peer access root <-> peer, and a per-peer transfer time."""
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs = [S.synth_stream_config(160, 120, s) for s in range(4)]
+    with PcsNode(cfgs, devices=[0, 0, 0, 0]) as node:
+        v, hv = node.rccl_version, node.rccl_header_version
+        assert v > 20000 and hv > 20000 and v // 10000 == hv // 10000
+        assert "rccl" in node.rccl_library.lower() and os.path.exists(node.rccl_library)
+        for r in range(4):
+            ln = node.link_info(r)
+            assert ln["same_device"] == 1 and ln["can_access_root"] == 1 and ln["link"] == "same GPU"
+        ms = node.probe_links(0, 3)
+        assert ms[0] == 0 and all(m > 0 for m in ms[1:])
+    with PcsNode(cfgs, devices=[0]) as node:
+        assert node.rccl_version == 0 and node.probe_links() == [0.0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
+def test_two_physical_gpus_direct_store_and_rccl(oracle, flags):
+    """The branch no one-GPU box can take: a DISTINCT second device id — hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess for
+    PCS_NODE_DIRECT_STORE, a two-rank communicator, payloads crossing a link. Skips with a reason on a one-GPU box; the day a
+    box with two GPUs runs the suite the branch is covered without a code change."""
+    from pointcloud_stitching_amd import lib as L
+    from pointcloud_stitching_amd.node import PcsNode, DIRECT_STORE
+    ngpu = int(L.load().pcs_device_count())
+    if ngpu < 2:
+        pytest.skip(f"needs two physical GPUs; this box shows {ngpu}")
+    cfgs, depth, color = S.synth_frame_set(4, 320, 240)
+    want, wcounts = oracle.process_frames(cfgs, depth, color, flags, 1)
+    for node_flags in (0, DIRECT_STORE):
+        with PcsNode(cfgs, devices=[0, 1], flags=flags, node_flags=node_flags) as node:
+            assert node.rccl_ranks == 2
+            ln = node.link_info(1)
+            assert ln["same_device"] == 0 and ln["device"] == 1 and ln["root_device"] == 0
+            if node_flags == DIRECT_STORE:
+                assert ln["can_access_root"] == 1
+            for _ in range(3):
+                buf, counts, size = node.process(depth, color)
+                assert counts == wcounts and size == want.nbytes
+                assert (buf[2:2 + want.size].reshape(-1, 5) == want).all()
+            st = node.last_stats()
+            moved = 10 * sum(wcounts[2:])
+            if node_flags == DIRECT_STORE and flags == 0:
+                assert st["direct_bytes"] == moved and st["exchanged_bytes"] == 0
+            else:
+                assert st["exchanged_bytes"] == moved
+            ms = node.probe_links(0, 3)
+            assert ms[1] > 0
 
 
 # ---- no GPU needed ------------------------------------------------------------------------------------------------------------
