@@ -1269,6 +1269,38 @@ def main():
                                     "note": "copyPointCloudXYZRGBToBufferSIMD's twin on device-resident rs2::points arrays "
                                             "(12 B vertex + 8 B texcoord + 3 B RGB in, 10 B out): pcs_copy_pointclouds_xyzrgb_to_buffer_device "
                                             "(one launch for all cameras) vs pcs_copy_pointcloud_xyzrgb_to_buffer_device per camera"}
+        if extra:
+            with Leg(out, "centre_transform"):
+                # ---- what pcs-multicamera-optimized does to packed payloads on the centre (src/pcs-multicamera-optimized.cpp:226-265,
+                # 289): decode, transform[i], re-encode, concatenate — one launch for all cameras, 10 B in + 10 B out per record.
+                # Inputs: the payload slices of the ring's frame-sets (device-resident, cold), output: a ring of stitched buffers.
+                from pointcloud_stitching_amd.types import TRANSFORMS as _TR
+                xo = [torch.empty(payload_shorts + 64, dtype=torch.int16, device=dev) for _ in range(min(R, 8))]
+                mats = [_TR[s % 8] for s in range(S)]
+                xk = [0]
+
+                def launch_xform():
+                    k = xk[0]; xk[0] = k + 1
+                    src = d_out[k % R].data_ptr()
+                    ctx0.transform_payloads_device([src + s * npts * 10 for s in range(S)], [npts] * S, mats, 1,
+                                                   xo[k % len(xo)].data_ptr(), payload_shorts)
+                launch_xform(); torch.cuda.synchronize(dev)
+                from oracle import pcs_oracle as _O
+                got_x = xo[0][:payload_shorts].cpu().numpy().reshape(-1, 5)
+                src0 = d_out[0][:payload_shorts].cpu().numpy().reshape(-1, 5)
+                want_x = _O.transform_payload(src0[:npts], mats[0], 1)
+                if (got_x[:npts] != want_x).any():
+                    raise RuntimeError("centre transform differs from the oracle")
+                for _ in range(20):
+                    launch_xform()
+                torch.cuda.synchronize(dev)
+                ms_x = timed(launch_xform, max(50, n_leg // 2), ctx0)
+                ach_x = set_points * 20 / (ms_x * 1e-3) / 1e9
+                out["centre_transform"] = {"ms_per_frame_set": round(ms_x, 5), "achieved": round(ach_x, 1), "frac": round(ach_x / HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes_per_point": 20, "kernel": "pcs_transform_payload_kernel",
+                                           "note": "pcs_transform_payloads_device: the centre-side decode / pcl::transformPointCloud / re-encode of "
+                                                   "pcs-multicamera-optimized over 8 packed 1280x720 payloads in one launch, camera-order "
+                                                   "concatenation fused (CLI: -c ... -T <file>); camera 0 compared with the oracle before timing"}
         if extra and not args.no_config5:
             with Leg(out, "config5_one_gpu"):
                 # ---- BASELINE configs[4] on ONE GPU: 16 x 1920x1080 -> invalid-depth compaction -> camera-order stitch -> voxel

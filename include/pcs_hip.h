@@ -263,6 +263,32 @@ int pcs_deproject(pcs_ctx* ctx, int stream, const uint16_t* depth, float* vertic
 int pcs_stitch_device(pcs_ctx* ctx, const int16_t* const* d_cam_payload, const int* cam_points, int n_cams,
                       int downsample, int16_t* d_stitched_payload, size_t stitched_shorts, int* total_points);
 
+/* ---- the centre's re-transform of already packed payloads (src/pcs-multicamera-optimized.cpp:226-265, 289) ---------------- *
+ * What the reference's pcs-multicamera-optimized does with every camera's payload before it concatenates them
+ * (updateCloudXYZRGB, :268-299; send_stitchedXYZRGB, :301-318) — in contrast with pcs-multicamera-client, which copies the
+ * records as they are (pcs_stitch_device). Per kept record (i % downsample == 0, :236):
+ *   x,y,z = (float)int16 / 1000.0f                     CONV_RATE is `const float CONV_RATE = 1000.0` in THAT file (:46)
+ *   p'    = ((m0*x + m1*y) + m2*z) + m3 per row         pcl::transformPointCloud(cloud, cloud, transform[i]) (:289): PCL 1.8
+ *                                                       transforms.hpp's expression; products and sums individually rounded
+ *                                                       (the target is built without -mfma). THIRD-PARTY: parity unpinned.
+ *   int16 = low 16 bits of cvttss2si(p' * 1000.0f)      static_cast<short>(x * CONV_RATE) (:255-257)
+ *   colour: short 3 (R | G<<8) survives bit for bit, short 4 becomes B with a zero high byte (:240-242, :258-259)
+ * The round trip is LOSSY (decode, move, truncate) — it is the reference program's behaviour, not an improvement; the default
+ * of the work-alike CLI stays the lossless concatenation. Cameras are written in index order into ONE stitched
+ * payload (what `*stitched_cloud += *cloud_ptr[i]`, :361-364, and convertPointCloudXYZRGBToBuffer produce); all cameras of a
+ * call share launches of up to 16 clouds. `cams` is a HOST array whose payload pointers are DEVICE pointers. A camera may be
+ * transformed in place (its output slice starting exactly at its input, downsample 1); any other overlap of an input with an
+ * output slice is refused. points_per_cam (optional, host) and *total_points are host-known: ceil(n_points / downsample)
+ * (the reference sizes its cloud with size / downsample, rounded DOWN, and then writes past it when size % downsample != 0,
+ * :231-246; the ceiling is what its loop produces). 20 B of HBM traffic per kept record.                                    */
+typedef struct pcs_payload_desc {
+    const int16_t* d_payload;      /* the camera's packed records (no header), device memory                             */
+    int32_t        n_points;
+    float          transform[16];  /* transform[i], row-major 4x4 in metres; the last row is not used                    */
+} pcs_payload_desc;
+int pcs_transform_payloads_device(pcs_ctx* ctx, int n_cams, const pcs_payload_desc* cams, int downsample,
+                                  int16_t* d_stitched_payload, size_t stitched_shorts, int* points_per_cam, int* total_points);
+
 /* ---- voxel-grid downsample of a packed payload (BASELINE config 5) ------------------------------ *
  * NOT in the reference (it includes pcl/filters/voxel_grid.h but never instantiates it). Defined in the
  * payload's integer millimetre domain: voxel = floor(coord / leaf_mm) per axis; one output point per occupied

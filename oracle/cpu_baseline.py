@@ -67,13 +67,15 @@ def _pct(sorted_vals, q):
 
 
 def sample(width, height, streams, seconds, min_passes=30, camera0=0):
-    from oracle import pcs_oracle as O
-    from pointcloud_stitching_amd import synthetic as Syn
-    L = O.lib()
+    # the CPUs this process may use — read BEFORE libgomp initialises: with OMP_PROC_BIND set it binds the calling (master) thread
+    # to the first place, and sched_getaffinity would then report that one core
     try:
         allowed = os.sched_getaffinity(0)
     except AttributeError:
         allowed = set(range(os.cpu_count() or 1))
+    from oracle import pcs_oracle as O
+    from pointcloud_stitching_amd import synthetic as Syn
+    L = O.lib()
     avail = len(allowed)
     phys = _physical_cores(allowed) or avail
     S, npts = streams, width * height

@@ -200,3 +200,41 @@ int pcs_oracle_voxel_grid(const int16_t* payload, int n_points, int leaf_mm, int
     free(v);
     return nv;
 }
+
+/* The centre's re-transform restated: src/pcs-multicamera-optimized.cpp:226-248 (convertBufferToPointCloudXYZRGB), :289
+ * (pcl::transformPointCloud with transform[thread_num]), :251-265 (convertPointCloudXYZRGBToBuffer). In THAT file CONV_RATE is
+ * `const float CONV_RATE = 1000.0;` (:46), so the divide and the multiply are single precision. The affine's evaluation order
+ * is PCL's (third-party, absent from /root/reference; Ubuntu 18.04's libpcl-dev = 1.8.1, Dockerfile:1,24): transforms.hpp
+ * computes  m(r,0)*x + m(r,1)*y + m(r,2)*z + m(r,3)  left to right in float — restated from the published source, PARITY
+ * UNPINNED. No contraction: the target has no -mfma (src/CMakeLists.txt) and this file is built with -ffp-contract=off.
+ * static_cast<short>(float) is cvttss2si + the low 16 bits on x86-64. Returns the records written (the loop's count, :236-245:
+ * every i with i % downsample == 0). */
+int pcs_oracle_transform_payload(const int16_t* in, int n_points, int downsample, const float* m16, int16_t* out)
+{
+    int count = 0;
+    if (downsample < 1) downsample = 1;
+    for (int i = 0; i < n_points; i++) {
+        if (i % downsample != 0) continue;                                               /* :236 */
+        const float x = (float)in[i * 5 + 0] / 1000.0f;                                  /* :237 */
+        const float y = (float)in[i * 5 + 1] / 1000.0f;                                  /* :238 */
+        const float z = (float)in[i * 5 + 2] / 1000.0f;                                  /* :239 */
+        const uint8_t r = (uint8_t)(in[i * 5 + 3] & 0xFF);                               /* :240 */
+        const uint8_t g = (uint8_t)(in[i * 5 + 3] >> 8);                                 /* :241 */
+        const uint8_t b = (uint8_t)(in[i * 5 + 4] & 0xFF);                               /* :242 */
+        float w[3];
+        for (int k = 0; k < 3; k++) {                                                    /* :289, PCL 1.8 transforms.hpp */
+            const float* m = m16 + 4 * k;
+            float a = m[0] * x;
+            a = a + m[1] * y;
+            a = a + m[2] * z;
+            w[k] = a + m[3];
+        }
+        out[count * 5 + 0] = (int16_t)pcs_oracle_cvtt(w[0] * 1000.0f);                   /* :255 */
+        out[count * 5 + 1] = (int16_t)pcs_oracle_cvtt(w[1] * 1000.0f);                   /* :256 */
+        out[count * 5 + 2] = (int16_t)pcs_oracle_cvtt(w[2] * 1000.0f);                   /* :257 */
+        out[count * 5 + 3] = (int16_t)((short)r + (short)(g << 8));                      /* :258 */
+        out[count * 5 + 4] = (int16_t)b;                                                 /* :259 */
+        count++;
+    }
+    return count;
+}

@@ -60,6 +60,10 @@ int pcs_oracle_send_xyzrgb_pointcloud(const pcs_stream_config* sc, const float* 
 int pcs_oracle_stitch(const int16_t* const* cam_payload, const int* cam_points, int n_cams,
                       int downsample, int16_t* stitched_payload);
 
+/* The centre-side re-transform of pcs-multicamera-optimized (src/pcs-multicamera-optimized.cpp:226-265, 289): decode, PCL
+ * affine, re-encode. PCL's evaluation order is third-party: parity unpinned. Returns the records written. */
+int pcs_oracle_transform_payload(const int16_t* in, int n_points, int downsample, const float* m16, int16_t* out);
+
 /* a5 + a2 + a7 composed for n_streams cameras; payload only (no header). counts[n_streams] optional.
  * scratch-free for the caller: allocates its own vertices/texcoords. Returns total points, <0 on OOM. */
 int pcs_oracle_process_frames(const pcs_stream_config* streams, int n_streams,

@@ -65,6 +65,8 @@ def lib():
         L.pcs_oracle_deproject_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pcs_oracle_send_simd_omp.restype = C.c_int
         L.pcs_oracle_send_simd_omp.argtypes = [SC, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.pcs_oracle_transform_payload.restype = C.c_int
+        L.pcs_oracle_transform_payload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.pcs_oracle_place_omp.restype = None
         L.pcs_oracle_place_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.pcs_oracle_team_cpus.restype = None
@@ -181,3 +183,13 @@ def voxel_grid(payload: np.ndarray, leaf_mm: int) -> np.ndarray:
     if nv < 0:
         raise MemoryError
     return out[:nv].copy()
+
+
+def transform_payload(payload: np.ndarray, m16, downsample: int = 1) -> np.ndarray:
+    """pcs-multicamera-optimized's centre-side decode / pcl::transformPointCloud / re-encode of one camera's records."""
+    p = np.ascontiguousarray(payload, np.int16).reshape(-1, POINT_SHORTS)
+    m = np.ascontiguousarray(np.asarray(m16, np.float32).reshape(-1))
+    assert m.size == 16
+    out = np.empty_like(p)
+    n = lib().pcs_oracle_transform_payload(_p(p), p.shape[0], int(downsample), _p(m), _p(out))
+    return out[:n].copy()

@@ -267,6 +267,28 @@ class PcsContext:
                                                 stitched_shorts, C.byref(total)))
         return total.value
 
+    def transform_payloads_device(self, d_cam_payload: Sequence[int], cam_points: Sequence[int], transforms, downsample: int,
+                                  d_stitched_payload: int, stitched_shorts: int):
+        """pcs_transform_payloads_device: what the reference's pcs-multicamera-optimized does to every camera's payload before it
+        concatenates them (decode, pcl::transformPointCloud(transform[i]), re-encode; src/pcs-multicamera-optimized.cpp:226-265,
+        289). Returns (points per camera, total points)."""
+        from .types import PayloadDesc
+        n = len(d_cam_payload)
+        descs = (PayloadDesc * max(n, 1))()
+        for i in range(n):
+            descs[i].d_payload = d_cam_payload[i]
+            descs[i].n_points = int(cam_points[i])
+            m = np.asarray(transforms[i], np.float32).reshape(-1)
+            if m.size != 16:
+                raise ValueError("a transform is 16 floats, row-major 4x4")
+            for k in range(16):
+                descs[i].transform[k] = float(m[k])
+        per = (C.c_int * max(n, 1))()
+        total = C.c_int(0)
+        self._check(self._lib.pcs_transform_payloads_device(self._h, n, descs, int(downsample), d_stitched_payload, stitched_shorts,
+                                                            per, C.byref(total)))
+        return [int(per[i]) for i in range(n)], total.value
+
     # -- voxel grid (defined by this build; see include/pcs_hip.h) --------------------------------
     def voxel_grid(self, payload: np.ndarray, leaf_mm: int) -> np.ndarray:
         """Voxel-grid downsample of packed records (int16 [n,5]) -> int16 [n_voxels,5]."""

@@ -156,7 +156,7 @@ public:
         if (got >= 13 && memcmp(magic, "#ROSBAG V2.0\n", 13) == 0) {
             /* a recording */
         } else if (got >= 27 && memcmp(magic, "version https://git-lfs", 23) == 0) {
-            /* what a checkout without `git lfs pull` holds in place of samples/*.bag (.gitattributes:1) */
+            // what a checkout without `git lfs pull` holds in place of the sample recordings (.gitattributes:1)
             err = "a Git-LFS pointer file, not the recording itself (run `git lfs pull` to fetch the .bag)";
             return false;
         } else { err = "not a ROS bag v2.0 file"; return false; }

@@ -27,6 +27,11 @@
 //                      frame-sets is uploaded once, then pcs_node_submit_device(k+1); pcs_node_wait(k) (with -V: the voxel
 //                      tickets) keeps two frame-sets in flight for -r iterations; prints the period per frame-set and where a
 //                      frame-set's time went on GPU 0 (pcs_node_last_stats). -o dumps the last frame-set like the other modes.
+//              -T <file>  (with -c) what the reference's pcs-multicamera-optimized does and pcs-multicamera-client does not: every
+//                      camera's payload is decoded to metres, moved by transform[i] (line i of the file: 16 values, row-major,
+//                      the format of pcs-camera-optimized -e) and re-encoded before the concatenation
+//                      (src/pcs-multicamera-optimized.cpp:226-265, 289; pcs_transform_payloads_device). Lossy, like the
+//                      reference's round trip; default off = pcs-multicamera-client's lossless concatenation.
 //     with neither -i nor -c the cameras are 8 synthetic 1280x720 streams on this node (there are no live cameras here).
 #include <chrono>
 #include <cstdio>
@@ -55,6 +60,7 @@ static int voxel_route = PCS_NODE_VOXEL_PARTIALS;
 static const char* source = nullptr;
 static const char* cameras = nullptr;
 static const char* dump_path = nullptr;
+static const char* transform_path = nullptr;
 
 static void usage()
 {
@@ -71,6 +77,8 @@ static void usage()
               << " -V <mm>          serve the voxel-grid downsample (leaf in millimetres) of the stitched cloud;  -Z drop invalid depth\n"
               << "                  with -G: every GPU pre-aggregates its cameras, ONE exchange of the voxel partials, reduced on GPU 0\n"
               << "                  (-R payloads: gather the packed payloads instead and downsample the stitched cloud on GPU 0)\n"
+              << " -T <file>        with -c: re-transform every camera's payload by transform[i] (16 values per line) before stitching,\n"
+              << "                  as the reference's pcs-multicamera-optimized does (decode, pcl::transformPointCloud, re-encode)\n"
               << " -P               with -G and -i synth:<W>x<H>: device-resident frame loop, two frame-sets in flight (submit / wait)\n"
               << " -s / -v / -n     PCL viewer features of the reference; not available in this build\n";
 }
@@ -79,7 +87,7 @@ int main(int argc, char** argv)
 {
     signal(SIGPIPE, SIG_IGN);
     int c;
-    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:ZR:P")) != -1) {
+    while ((c = getopt(argc, argv, "hftsvd:nc:N:g:p:r:o:qG:i:V:ZR:PT:")) != -1) {
         switch (c) {
             case 't': timer = true; break;
             case 'd': downsample = atoi(optarg); break;
@@ -106,6 +114,7 @@ int main(int argc, char** argv)
             case 'R': voxel_route = (optarg[0] == 'p' && optarg[1] == 'a' && optarg[2] == 'y') ? PCS_NODE_VOXEL_PAYLOADS : PCS_NODE_VOXEL_PARTIALS; break;
             case 'Z': drop_invalid = true; break;
             case 'P': pipelined = true; break;
+            case 'T': transform_path = optarg; break;
             case 's': case 'v': case 'n':
                 std::cerr << "-" << (char)c << " drives the reference's PCL viewer / PLY writer, which this build does not include" << std::endl;
                 return 2;
@@ -123,6 +132,8 @@ int main(int argc, char** argv)
         return 2;
     }
     if (voxel_leaf && n_gpus > 0 && cameras) { std::cerr << "-G shards cameras of this node (-i), not edge servers (-c)" << std::endl; return 2; }
+    if (transform_path && !cameras) { std::cerr << "-T re-transforms payloads received from edge servers (-c); cameras of this node (-i) "
+                                                   "get their extrinsic in the fused kernel" << std::endl; return 2; }
     if (drop_invalid && !source) { std::cerr << "-Z applies to cameras on this node (-i); edge servers drop with their own -c" << std::endl; return 2; }
 
     // ---- frame source / edge connections -------------------------------------------------------
@@ -158,6 +169,25 @@ int main(int argc, char** argv)
         n_streams = (int)cam_fd.size();
         // the stitch-only context needs a config; geometry is irrelevant for pcs_stitch_device
         cfgs.push_back(pcs_synth::stream_config(64, 48, 0, false));
+    }
+
+    std::vector<pcs_payload_desc> xf;           // -T: transform[i] per camera (src/pcs-multicamera-optimized.cpp:417-455 as a file)
+    if (transform_path) {
+        FILE* f = fopen(transform_path, "r");
+        if (!f) { std::cerr << "cannot open transform file " << transform_path << std::endl; return 2; }
+        char line[1024];
+        while ((int)xf.size() < n_streams && fgets(line, sizeof line, f)) {
+            char* hash = strchr(line, '#');
+            if (hash) *hash = 0;
+            pcs_payload_desc d; memset(&d, 0, sizeof d);
+            int got = 0, pos = 0, adv = 0;
+            while (got < 16 && sscanf(line + pos, " %f%n", &d.transform[got], &adv) == 1) { got++; pos += adv; if (line[pos] == ',') pos++; }
+            if (got == 0) continue;
+            if (got != 16) { std::cerr << transform_path << ": expected 16 values per line" << std::endl; fclose(f); return 2; }
+            xf.push_back(d);
+        }
+        fclose(f);
+        if ((int)xf.size() < n_streams) { std::cerr << transform_path << ": only " << xf.size() << " matrices for " << n_streams << " cameras" << std::endl; return 2; }
     }
 
     pcs_config cfg;
@@ -437,6 +467,11 @@ int main(int argc, char** argv)
             }
             if (!ok) { std::cout << "camera stream ended" << std::endl; break; }
             int total_pts = 0;
+            if (transform_path) {       // the reference program's own semantics: decode, transform[i], re-encode, concatenate
+                for (int i = 0; i < n_streams; i++) { xf[i].d_payload = dptr[i]; xf[i].n_points = pts[i]; }
+                rc = pcs_transform_payloads_device(ctx, n_streams, xf.data(), downsample, static_cast<int16_t*>(d_stitched),
+                                                   (size_t)n_streams * cam_cap_bytes / 2, nullptr, &total_pts);
+            } else
             rc = pcs_stitch_device(ctx, dptr.data(), pts.data(), n_streams, downsample, static_cast<int16_t*>(d_stitched),
                                    (size_t)n_streams * cam_cap_bytes / 2, &total_pts);
             if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }

@@ -1464,6 +1464,60 @@ int pcs_stitch_device(pcs_ctx* c, const int16_t* const* d_cam_payload, const int
     return PCS_OK;
 }
 
+// ---- the centre's re-transform of packed payloads (src/pcs-multicamera-optimized.cpp:226-265, 289) ----------
+int pcs_transform_payloads_device(pcs_ctx* c, int n_cams, const pcs_payload_desc* cams, int downsample,
+                                  int16_t* d_stitched_payload, size_t stitched_shorts, int* points_per_cam, int* total_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (n_cams < 0 || (n_cams > 0 && (!cams || !d_stitched_payload))) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if (downsample < 1) return fail(c, PCS_ERR_INVALID_ARG, "downsample %d < 1", downsample);
+    size_t need = 0;
+    std::vector<size_t> first(n_cams > 0 ? n_cams : 0), kept(n_cams > 0 ? n_cams : 0);
+    for (int i = 0; i < n_cams; i++) {
+        if (cams[i].n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "camera %d: negative point count", i);
+        if (cams[i].n_points > 0 && !cams[i].d_payload) return fail(c, PCS_ERR_INVALID_ARG, "camera %d: NULL payload", i);
+        first[i] = need;
+        kept[i] = ((size_t)cams[i].n_points + downsample - 1) / downsample;
+        need += kept[i];
+    }
+    if (need * PCS_POINT_BYTES > 0x7FFFFFFFull)
+        return fail(c, PCS_ERR_INVALID_ARG, "stitched payload of %zu points exceeds the int32 byte-count header", need);
+    if (stitched_shorts < need * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "stitched payload holds %zu shorts, %zu needed", stitched_shorts, need * PCS_POINT_SHORTS);
+    // a tile reads all of its input before it writes, and tiles of one camera cover disjoint ranges: a camera may be transformed
+    // in place (same start, stride 1); any other meeting of an input with an output slice would be a race between workgroups
+    for (int i = 0; i < n_cams; i++) {
+        const uintptr_t o0 = (uintptr_t)(d_stitched_payload + first[i] * PCS_POINT_SHORTS), o1 = o0 + kept[i] * PCS_POINT_BYTES;
+        for (int j = 0; j < n_cams; j++) {
+            const uintptr_t i0 = (uintptr_t)cams[j].d_payload, i1 = i0 + (size_t)cams[j].n_points * PCS_POINT_BYTES;
+            if (o0 < i1 && i0 < o1 && !(i == j && i0 == o0 && downsample == 1))
+                return fail(c, PCS_ERR_INVALID_ARG, "camera %d's output slice overlaps camera %d's input (only an exact in-place "
+                            "transform with downsample 1 is allowed)", i, j);
+        }
+    }
+    DeviceGuard guard(c->device);
+    for (int base = 0; base < n_cams; base += kXformBatch) {
+        const int n = std::min(kXformBatch, n_cams - base);
+        XformBatch xb;
+        std::memset(&xb, 0, sizeof xb);
+        uint32_t max_out = 0;
+        for (int k = 0; k < n; k++) {
+            const int i = base + k;
+            XformCloud& x = xb.c[k];
+            x.in = cams[i].d_payload;
+            x.out = reinterpret_cast<uint8_t*>(d_stitched_payload + first[i] * PCS_POINT_SHORTS);
+            x.n_out = (uint32_t)kept[i];
+            x.ds = (uint32_t)downsample;
+            std::memcpy(x.M, cams[i].transform, sizeof x.M);
+            max_out = std::max(max_out, x.n_out);
+        }
+        HIPCHK(c, launch_transform_payloads(xb, n, max_out, c->stream));
+    }
+    if (points_per_cam) for (int i = 0; i < n_cams; i++) points_per_cam[i] = (int)kept[i];
+    if (total_points) *total_points = (int)need;
+    return PCS_OK;
+}
+
 // ---- voxel-grid downsample (not in the reference; defined in pcs_voxel.hip / DESIGN.md) ----------
 static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_points, const int32_t* d_n_points, int leaf_mm,
                                   int16_t* d_out, size_t out_shorts, int32_t* d_out_points)

@@ -204,6 +204,19 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
                                        uint32_t max_w, uint32_t max_h, bool patch_ok, bool any_dist, uint32_t flags,
                                        MathSel math, const FramePtrs& fp, const VoxelStage& vs, hipStream_t st);
 
+// Centre-side re-transform of already packed payloads (src/pcs-multicamera-optimized.cpp:226-265, 289): n clouds in one launch
+// (blockIdx.y = cloud), each decoded, moved by its own 3x4 and re-packed at its camera-order offset of one stitched payload.
+constexpr int kXformBatch = 16;
+struct XformCloud {
+    const int16_t* in;          // the camera's payload as received
+    uint8_t*       out;         // where its first kept record goes
+    uint32_t       n_out;       // records written = ceil(n_in / ds)
+    uint32_t       ds;          // keep every ds-th record (i % downsample == 0, :236)
+    float          M[12];       // top three rows of transform[i], row-major
+};
+struct XformBatch { XformCloud c[kXformBatch]; };
+hipError_t launch_transform_payloads(const XformBatch& xb, int n, uint32_t max_out, hipStream_t st);
+
 // a7 with stride.
 hipError_t launch_stitch(const int16_t* d_src, uint32_t src_points, int downsample,
                          int16_t* d_dst, hipStream_t st);

@@ -1665,6 +1665,114 @@ void pcs_deproject_kernel(const StreamParams* __restrict__ params, int stream, c
     texcoords[2 * (size_t)i + 1] = p.v;
 }
 
+// ---- the centre's re-transform of packed payloads (src/pcs-multicamera-optimized.cpp:226-265, 289) -------------------------
+// What pcs-multicamera-optimized does to every camera's payload before it concatenates them: int16 millimetres -> float metres
+// (`(float)buffer[..] / CONV_RATE`, CONV_RATE a `const float` 1000.0 in that file, :46, :237-239), pcl::transformPointCloud with
+// transform[thread_num] (:289), float metres -> int16 millimetres (`static_cast<short>(x * CONV_RATE)`, :255-257), colour bytes
+// re-packed (:240-242, :258-259: R | G<<8 survives as it is, the high byte of the B short is cleared). The affine is evaluated in
+// the order of PCL 1.8's transforms.hpp (Ubuntu 18.04's libpcl-dev, Dockerfile:1,24) — ((m0*x + m1*y) + m2*z) + m3, every product
+// and sum individually rounded (the target is built without -mfma, src/CMakeLists.txt) — third-party, so "parity unpinned".
+// HBM-bound: 10 B in + 10 B out per kept record. One tile = 2048 output records: the tile's input bytes come in as
+// lane-contiguous 16-byte loads into LDS at the input's 16-byte phase, every lane takes its 8 records into registers, and the
+// results are parked at the OUTPUT's phase and leave as 16-byte nontemporal stores (store_staged) — the same LDS buffer twice.
+__device__ __forceinline__ void load_staged(uint8_t* lds, uint32_t head, uint32_t nbytes, const uint8_t* g)
+{
+    const uint8_t* g0 = g - head;                            // 16-byte aligned
+    const uint32_t end = head + nbytes;
+    const uint32_t first_full = (head + 15u) >> 4, last_full = end >> 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (uint32_t j = first_full + threadIdx.x; j < last_full; j += kBlockThreads)
+        reinterpret_cast<u32x4*>(lds)[j] = reinterpret_cast<const u32x4*>(g0)[j];
+    const uint32_t head_end = min(first_full << 4, end);     // ragged ends as 2-byte loads: never a byte outside [g, g + nbytes)
+    for (uint32_t b = head + 2u * threadIdx.x; b < head_end; b += 2u * kBlockThreads)
+        *reinterpret_cast<uint16_t*>(lds + b) = *reinterpret_cast<const uint16_t*>(g0 + b);
+    if (last_full >= first_full) {
+        const uint32_t tail_begin = max(last_full << 4, head_end);
+        for (uint32_t b = tail_begin + 2u * threadIdx.x; b < end; b += 2u * kBlockThreads)
+            *reinterpret_cast<uint16_t*>(lds + b) = *reinterpret_cast<const uint16_t*>(g0 + b);
+    }
+}
+
+// stage_record read backwards: one record from a 2-byte aligned LDS offset with aligned accesses only.
+__device__ __forceinline__ Record unstage_record(const uint8_t* lds, uint32_t off)
+{
+    const bool odd = (off & 2u) != 0u;
+    const uint32_t h_off = odd ? off : off + 8u;
+    const uint32_t a_off = odd ? off + 2u : off;
+    const uint32_t h = *reinterpret_cast<const uint16_t*>(lds + h_off);
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(lds + a_off);
+    const uint32_t b = *reinterpret_cast<const uint32_t*>(lds + a_off + 4u);
+    Record r;
+    r.xy = odd ? perm(a, h, kLoLo) : a;
+    r.zc = odd ? perm(b, a, kHiLo) : b;
+    r.b = odd ? (b >> 16) : h;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t retransform_mm(const float* __restrict__ Mr, float x, float y, float z)
+{
+    const float a = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Mr[0], x), __fmul_rn(Mr[1], y)), __fmul_rn(Mr[2], z)), Mr[3]);
+    return (uint32_t)cvtt_x86(__fmul_rn(a, 1000.0f)) & 0xFFFFu;          // static_cast<short>: cvttss2si, low 16 bits
+}
+
+__device__ __forceinline__ Record retransform_record(const float* __restrict__ M, const Record& r)
+{
+    const float x = (float)(int32_t)(int16_t)(r.xy & 0xFFFFu) / 1000.0f;  // correctly rounded division (TU flag)
+    const float y = (float)((int32_t)r.xy >> 16) / 1000.0f;
+    const float z = (float)(int32_t)(int16_t)(r.zc & 0xFFFFu) / 1000.0f;
+    Record o;
+    o.xy = retransform_mm(M + 0, x, y, z) | (retransform_mm(M + 4, x, y, z) << 16);
+    o.zc = retransform_mm(M + 8, x, y, z) | (r.zc & 0xFFFF0000u);
+    o.b = r.b & 0xFFu;
+    return o;
+}
+
+template <bool DS1>
+__global__ __launch_bounds__(kBlockThreads)
+void pcs_transform_payload_kernel(XformBatch xb)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
+    const XformCloud& C = xb.c[blockIdx.y];
+    const uint32_t n_out = C.n_out;
+    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    if (tile0 >= n_out) return;
+    const uint32_t pts = min(kTilePoints, n_out - tile0);
+    uint8_t* gdst = C.out + (size_t)tile0 * PCS_POINT_BYTES;
+    const uint32_t ohead = (uint32_t)((uintptr_t)gdst & 15u);
+    Record rec[kPointsPerLane];
+    if (DS1) {
+        const uint8_t* gsrc = reinterpret_cast<const uint8_t*>(C.in) + (size_t)tile0 * PCS_POINT_BYTES;
+        const uint32_t ihead = (uint32_t)((uintptr_t)gsrc & 15u);
+        load_staged(stage, ihead, pts * PCS_POINT_BYTES, gsrc);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPointsPerLane; k++) {
+            const uint32_t j = threadIdx.x + (uint32_t)k * kBlockThreads;
+            if (j < pts) rec[k] = unstage_record(stage, ihead + j * PCS_POINT_BYTES);
+        }
+        __syncthreads();                                     // everybody holds its records: the buffer may be overwritten
+    } else {
+        const uint32_t ds = C.ds;
+#pragma unroll
+        for (int k = 0; k < kPointsPerLane; k++) {
+            const uint32_t j = threadIdx.x + (uint32_t)k * kBlockThreads;
+            if (j < pts) {
+                const uint16_t* s = reinterpret_cast<const uint16_t*>(C.in) + (size_t)(tile0 + j) * ds * PCS_POINT_SHORTS;
+                rec[k].xy = (uint32_t)s[0] | ((uint32_t)s[1] << 16);
+                rec[k].zc = (uint32_t)s[2] | ((uint32_t)s[3] << 16);
+                rec[k].b = s[4];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPointsPerLane; k++) {
+        const uint32_t j = threadIdx.x + (uint32_t)k * kBlockThreads;
+        if (j < pts) stage_record(stage, ohead + j * PCS_POINT_BYTES, retransform_record(C.M, rec[k]));
+    }
+    __syncthreads();
+    store_staged(stage, ohead, pts * PCS_POINT_BYTES, gdst);
+}
+
 // ---- a7 with stride ----------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads)
 void pcs_stitch_kernel(const uint16_t* __restrict__ src, uint32_t out_points, uint32_t ds, uint8_t* __restrict__ dst)
@@ -1992,6 +2100,18 @@ hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n
     const dim3 grid((n_points + kBlockThreads - 1) / kBlockThreads);
     hipLaunchKernelGGL((pcs_deproject_kernel<true, true>), grid, dim3(kBlockThreads), 0, st,
                        d_params, stream, d_depth, d_vertices, d_texcoords);
+    return hipGetLastError();
+}
+
+hipError_t launch_transform_payloads(const XformBatch& xb, int n, uint32_t max_out, hipStream_t st)
+{
+    if (n <= 0 || max_out == 0) return hipSuccess;
+    if (n > kXformBatch) return hipErrorInvalidValue;
+    bool ds1 = true;
+    for (int i = 0; i < n; i++) ds1 = ds1 && xb.c[i].ds == 1u;
+    const dim3 grid = tile_grid(max_out, n);
+    if (ds1) hipLaunchKernelGGL((pcs_transform_payload_kernel<true>), grid, dim3(kBlockThreads), 0, st, xb);
+    else     hipLaunchKernelGGL((pcs_transform_payload_kernel<false>), grid, dim3(kBlockThreads), 0, st, xb);
     return hipGetLastError();
 }
 

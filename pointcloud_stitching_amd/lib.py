@@ -10,7 +10,7 @@ import os
 import subprocess
 from typing import Optional
 
-from .types import CloudDesc, Config, StreamConfig
+from .types import CloudDesc, Config, PayloadDesc, StreamConfig
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_PKG, "csrc")
@@ -48,6 +48,7 @@ SYMBOLS = [
     ("pcs_collect_frames", C.c_int, [_VP, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(C.c_int)]),
     ("pcs_deproject", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("pcs_stitch_device", C.c_int, [_VP, _P(_VP), _P(C.c_int), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
+    ("pcs_transform_payloads_device", C.c_int, [_VP, C.c_int, _P(PayloadDesc), C.c_int, _VP, C.c_size_t, _P(C.c_int), _P(C.c_int)]),
     ("pcs_voxel_grid_device", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     ("pcs_voxel_grid_device_counted", C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     ("pcs_process_frames_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, C.c_size_t, _VP]),

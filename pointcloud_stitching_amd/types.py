@@ -74,6 +74,11 @@ class CloudDesc(C.Structure):
                 ("color", C.c_void_p), ("pc_buffer", C.c_void_p)]
 
 
+class PayloadDesc(C.Structure):
+    """pcs_payload_desc: one camera's packed records (device pointer) and the 4x4 the centre moves them by."""
+    _fields_ = [("d_payload", C.c_void_p), ("n_points", C.c_int32), ("transform", C.c_float * 16)]
+
+
 # --- the reference's surveyed extrinsics (data, not code) -------------------------------------
 # src/pcs-camera-optimized.cpp:64-67
 TF_MAT = np.array([

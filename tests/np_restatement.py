@@ -86,3 +86,24 @@ def deproject_np(sc, depth, half_pixel=False):
     vtx = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(f32)
     tex = np.stack([u, v], -1).reshape(-1, 2).astype(f32)
     return vtx, tex
+
+
+def transform_payload_np(payload, m16, downsample=1):
+    """The centre's decode / affine / re-encode (src/pcs-multicamera-optimized.cpp:226-265, 289) in numpy float32: division by
+    1000.0f, ((m0*x + m1*y) + m2*z) + m3 with every product and sum rounded to float32, * 1000.0f, truncation, low 16 bits."""
+    f32 = np.float32
+    p = np.asarray(payload, np.int16).reshape(-1, 5)[::max(int(downsample), 1)]
+    M = np.asarray(m16, f32).reshape(-1)
+    out = np.empty_like(p)
+    with np.errstate(all="ignore"):
+        x, y, z = [(p[:, k].astype(f32) / f32(1000.0)).astype(f32) for k in range(3)]
+        for r in range(3):
+            a = (M[4 * r] * x).astype(f32)
+            a = (a + (M[4 * r + 1] * y).astype(f32)).astype(f32)
+            a = (a + (M[4 * r + 2] * z).astype(f32)).astype(f32)
+            a = (a + M[4 * r + 3]).astype(f32)
+            a = (a * f32(1000.0)).astype(f32)
+            out[:, r] = (cvtt(a) & 0xFFFF).astype(np.uint16).view(np.int16)
+    out[:, 3] = p[:, 3]
+    out[:, 4] = (p[:, 4].view(np.uint16) & 0xFF).astype(np.int16)
+    return out

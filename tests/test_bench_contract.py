@@ -48,6 +48,7 @@ def test_bench_line_has_the_contract_keys():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mpoints/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["host_physical_cores"] >= 1 and cb["host_logical_cpus"] >= cb["host_physical_cores"]
+    assert cb["host_logical_cpus"] == len(os.sched_getaffinity(0)) and cb["statistic"] == "median" and cb["passes"] >= 30
     # the other kernels' legs ride on the default line, each with its own byte model
     comp = d["compaction"]
     assert 0.85 < comp["kept_fraction"] < 0.95 and abs(comp["algorithmic_bytes_per_point"] - (5 + 10 * comp["kept_fraction"])) < 1e-2
@@ -214,6 +215,8 @@ def test_cpu_sample_child_process_line():
     assert d["cores"] >= 1 and len(d["team_cpus"]) == d["cores"] and d["t1_value"] > 0 and d["with_deprojection_value"] > 0
     assert "OMP_PROC_BIND=close" in d["sample"] and "OMP_PLACES=cores" in d["sample"]
     assert d["host_physical_cores"] >= 1 and d["host_logical_cpus"] >= d["host_physical_cores"]
+    # the child reads its CPU set before libgomp binds the master thread to the first place
+    assert d["host_logical_cpus"] == len(os.sched_getaffinity(0))
 
 
 def test_route_choice_never_depends_on_how_the_script_was_launched():

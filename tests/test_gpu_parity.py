@@ -336,6 +336,59 @@ def test_stitch_device_with_stride(oracle):
             assert_same(got.reshape(-1, 5), want)
 
 
+@pytest.mark.parametrize("stride", [1, 2, 7])
+def test_centre_side_transform_of_packed_payloads(oracle, stride):
+    """pcs_transform_payloads_device — the decode / pcl::transformPointCloud / re-encode pcs-multicamera-optimized applies to every
+    camera's payload before concatenating (src/pcs-multicamera-optimized.cpp:226-265, 289) — against the oracle's restatement:
+    every int16 value per coordinate (all 65 536 quotients by 1000.0f), int16 wrap-around of the moved coordinates, negative
+    truncation, NaN / inf / huge matrix entries, ragged sizes (0, 1, 2047, 2049 records), payloads at 2-, 4- and 10-byte phases of a
+    16-byte line (the wire's buffer + 2 shorts), more cameras than one launch holds, and an in-place transform."""
+    from pointcloud_stitching_amd.types import TRANSFORMS, TF_MAT
+    rng = np.random.default_rng(11 + stride)
+    allv = np.arange(-32768, 32768, dtype=np.int16)
+    sweep = np.zeros((65536 * 3, 5), np.int16)
+    for k in range(3):
+        sweep[65536 * k:65536 * (k + 1), k] = allv
+        sweep[65536 * k:65536 * (k + 1), (k + 1) % 3] = rng.integers(-32768, 32768, 65536, dtype=np.int16)
+    sweep[:, 3:] = rng.integers(-32768, 32768, (sweep.shape[0], 2), dtype=np.int16)
+    sizes = [sweep.shape[0], 0, 1, 2047, 2049, 5000] + [300 + 17 * i for i in range(14)]          # 20 cameras: two launches
+    cams = [sweep] + [rng.integers(-32768, 32768, (n, 5), dtype=np.int16) for n in sizes[1:]]
+    wild = np.array([1e6, -3e7, 2.5, 7e9, np.nan, 1, 1, 0, 0, 0, np.inf, -4, 0, 0, 0, 1], np.float32)
+    mats = [TRANSFORMS[i % 8] for i in range(len(cams))]
+    mats[3], mats[4], mats[5] = wild, TF_MAT, np.eye(4, dtype=np.float32).reshape(-1)
+    want = np.concatenate([oracle.transform_payload(c, m, stride) for c, m in zip(cams, mats)])
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        phases = [0, 4, 2, 10, 6, 14, 8, 12]
+        dptr = []
+        for i, c in enumerate(cams):
+            base = ctx.device_malloc(max(c.nbytes, 16) + 64)
+            dptr.append(base + phases[i % len(phases)])
+            if c.size:
+                ctx.memcpy_h2d(dptr[-1], c)
+        out = ctx.device_malloc(want.nbytes + 64)
+        for out_phase in (0, 4, 10):
+            per, total = ctx.transform_payloads_device(dptr, [c.shape[0] for c in cams], mats, stride, out + out_phase, want.size)
+            ctx.synchronize()
+            assert total == want.shape[0] and per == [-(-c.shape[0] // stride) for c in cams]
+            got = np.empty(want.size, np.int16)
+            ctx.memcpy_d2h(got, out + out_phase)
+            assert_same(got.reshape(-1, 5), want)
+        # capacity and overlap checks
+        with pytest.raises(PcsError) as e:
+            ctx.transform_payloads_device(dptr, [c.shape[0] for c in cams], mats, stride, out, want.size - 5)
+        assert e.value.status == -5
+        with pytest.raises(PcsError) as e:                     # camera 1's output slice would land inside camera 0's input
+            ctx.transform_payloads_device([dptr[0], dptr[5]], [cams[0].shape[0], cams[5].shape[0]], mats[:2], stride, dptr[0] + 10, 10 ** 7)
+        assert e.value.status == -1 and "overlaps" in str(e.value)
+        if stride == 1:                                         # in place: one camera, output = input
+            per, total = ctx.transform_payloads_device([dptr[0]], [cams[0].shape[0]], [mats[0]], 1, dptr[0], cams[0].size)
+            ctx.synchronize()
+            got = np.empty(cams[0].size, np.int16)
+            ctx.memcpy_d2h(got, dptr[0])
+            assert_same(got.reshape(-1, 5), oracle.transform_payload(cams[0], mats[0], 1))
+
+
 def test_sixteen_streams_1080p_digest(oracle):
     # config 5 geometry: full compare through a digest to keep host memory in check
     cfgs, depth, color = S.synth_frame_set(16, 1920, 1080)

@@ -179,3 +179,31 @@ def test_cvtt_matches_x86(oracle):
     assert oracle.cvtt(2147483648.0) == -2**31 and oracle.cvtt(-3e9) == -2**31
     assert oracle.cvtt(float("nan")) == -2**31 and oracle.cvtt(float("inf")) == -2**31
     assert oracle.cvtt(-2147483648.0) == -2**31 and oracle.cvtt(2147483520.0) == 2147483520
+
+
+def test_centre_transform_restatement_agrees_with_numpy(oracle):
+    """oracle.transform_payload (src/pcs-multicamera-optimized.cpp:226-265, 289 restated in C) against the independent numpy
+    statement: every int16 value in every coordinate, the surveyed transforms, wrap-around, a NaN / inf / huge matrix, strides."""
+    from tests.np_restatement import transform_payload_np
+    from pointcloud_stitching_amd.types import TRANSFORMS, TF_MAT
+    rng = np.random.default_rng(5)
+    allv = np.arange(-32768, 32768, dtype=np.int16)
+    p = np.zeros((65536 * 3 + 4000, 5), np.int16)
+    for k in range(3):
+        p[65536 * k:65536 * (k + 1), k] = allv
+        p[65536 * k:65536 * (k + 1), (k + 1) % 3] = rng.integers(-32768, 32768, 65536, dtype=np.int16)
+    p[65536 * 3:, :3] = rng.integers(-32768, 32768, (4000, 3), dtype=np.int16)
+    p[:, 3:] = rng.integers(-32768, 32768, (p.shape[0], 2), dtype=np.int16)
+    wild = np.array([1e6, -3e7, 2.5, 7e9, np.nan, 1, 1, 0, 0, 0, np.inf, -4, 0, 0, 0, 1], np.float32)
+    ident = np.eye(4, dtype=np.float32).reshape(-1)
+    for m in [TRANSFORMS[0], TRANSFORMS[6], TF_MAT, ident, wild]:
+        for d in (1, 3):
+            got = oracle.transform_payload(p, m, d)
+            want = transform_payload_np(p, m, d)
+            assert got.shape == want.shape and (got == want).all()
+    # the round trip through the identity is NOT lossless: x/1000*1000 truncates below some integers (the reference's known loss)
+    back = oracle.transform_payload(p, ident, 1)
+    assert (back[:, 3] == p[:, 3]).all() and (back[:, 4] == (p[:, 4] & 0xFF)).all()
+    dx = back[:, 0].astype(np.int32) - p[:, 0].astype(np.int32)
+    assert set(np.unique(dx)) <= {-1, 0, 1} and (dx != 0).any()
+    assert oracle.transform_payload(p[:0], ident, 1).shape == (0, 5)

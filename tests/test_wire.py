@@ -151,6 +151,47 @@ def test_full_star_topology_two_edges_one_central(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stride", [1, 3])
+def test_star_with_the_centre_side_transform(oracle, tmp_path, stride):
+    """`pcs-multicamera-optimized -c ... -T transforms.txt`: the semantics of the program the CLI is installed as — every camera's
+    payload decoded, moved by transform[i], re-encoded, then concatenated (src/pcs-multicamera-optimized.cpp:226-265, 289) —
+    against the oracle's restatement; without -T the same star serves the untouched records (the other tests)."""
+    from pointcloud_stitching_amd.types import TRANSFORMS
+    tf = tmp_path / "transforms.txt"
+    tf.write_text("# transform[0], transform[1] of src/pcs-multicamera-optimized.cpp:417-427\n" +
+                  "\n".join(" ".join(repr(float(v)) for v in np.asarray(TRANSFORMS[i], np.float32).reshape(-1)) for i in range(2)) + "\n")
+    p1, p2, p3 = free_port(), free_port(), free_port()
+    edges = [subprocess.Popen([EDGE, "-f", "synth:128x96", "-m", "-r", "4", "-p", str(p), "-P"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for p in (p1, p2)]
+    central = None
+    try:
+        time.sleep(0.5)
+        central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-d", str(stride), "-p", str(p3), "-r", "2", "-T", str(tf)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        consumer = connect(p3)
+        for frame in range(2):
+            consumer.sendall(b"Z")
+            got = read_frame(consumer)
+            cfgs, depth, color = frame_inputs(1, 128, 96, frame, single=True)
+            cam, _ = oracle.process_frames(cfgs, depth, color)
+            want = np.concatenate([oracle.transform_payload(cam, TRANSFORMS[i], stride) for i in range(2)])
+            assert got.shape == want.shape and (got == want).all()
+            assert (got != oracle.stitch([cam, cam], stride)).any()          # it really is a different cloud than the plain concatenation
+        consumer.close()
+        out, err = central.communicate(timeout=60)
+        assert central.returncode == 0, err
+        for e in edges:
+            e.communicate(timeout=60)
+            assert e.returncode == 0
+    finally:
+        for p in edges + ([central] if central else []):
+            if p.poll() is None:
+                p.kill()
+    r = subprocess.run([CENTRAL, "-i", "synth:64x48", "-T", str(tf), "-q"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 2 and "-T re-transforms payloads" in r.stderr
+
+
+@pytest.mark.gpu
 def test_central_all_gpu_mode(oracle):
     port = free_port()
     p = subprocess.Popen([CENTRAL, "-i", "synth:128x96", "-N", "3", "-d", "3", "-p", str(port), "-r", "2"],
