@@ -169,6 +169,7 @@ struct VoxelWsState {
     const void* base = nullptr;
     uint32_t    phase = 0;
     bool        clean = false;
+    int         spl_leaf = 0;       // bucket tail: the leaf the workspace's splitters were made for (0: none)
 };
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
                              size_t ws_bytes, VoxelWsState* ws, int16_t* d_out, int32_t* d_out_points, hipStream_t st);

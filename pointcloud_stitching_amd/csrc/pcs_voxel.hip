@@ -810,6 +810,485 @@ void pcs_voxel_fixup_kernel(unsigned int* __restrict__ ctl, const BlockPiece* __
     }
 }
 
+
+// ================================================================================================================
+// The BUCKET tail (round 5): the same result as steps 2-3 above in 5 launches instead of 12.
+//
+// The LSD sort above is a chain of 3 x (histogram, column scan, scatter) + heads + reduce + fix-up = 12 dependent
+// launches whose cost does not depend on their size at ~1 M partials: 79-85 us of which the memory work is a fraction.
+// What the result needs is weaker than a sort of the partials: (a) all partials of a voxel in one place, (b) the voxels
+// in key order. So:
+//   P1  partition histogram   the partials are split ONCE into kBkt = 1024 contiguous KEY RANGES by kBkt - 1 splitters
+//                             (upper_bound by binary search in LDS); per-chunk bucket counts, every element's bucket id
+//   P2  column scan           of the per-chunk counts (as above, 1024 columns)
+//   P3  scatter               (key, partial) to its bucket's range: 40 B per element, placed with returning LDS adds on a
+//                             per-chunk cursor — unstable, which integer sums do not care about
+//   G1  bucket reduce         one workgroup per bucket: LDS hash table over the bucket's ~870 partials (64-bit LDS
+//                             compare-and-swap + 64-bit LDS adds), bitonic sort of the occupied (key, slot) words in LDS, one
+//                             finished RECORD per voxel, in key order, parked at the bucket's own offset
+//   W   write                 exclusive scan of the buckets' voxel counts (every workgroup for itself: 1024 words), records
+//                             copied to their final place, voxel total, next call's control block cleared
+// Buckets are key ranges, so bucket order + key order inside a bucket IS the (z, y, x) output order.
+// SPLITTERS are quantiles of the key distribution. They only decide balance, never the result, so they come from the
+// previous call on this workspace: G1 has every bucket's sorted keys and rewrites, in place, the splitters that fall into
+// its share of the partials — consecutive frame-sets of a camera rig differ by sensor noise. A workspace without splitters
+// for this leaf runs a one-workgroup sample sort first (S0: 4096 evenly spaced keys, bitonic in LDS).
+// SKEW / STALE SPLITTERS cost speed, never bits: a bucket whose distinct voxels do not fit the 1024-slot table is worked
+// off in several passes over key sub-ranges [L, T): when the table fills up, T drops to the median of the keys seen so far
+// and the pass restarts; every pass emits its voxels in key order behind the previous pass's. A hot voxel (thousands of
+// partials of one key) is no skew at all: the bucket is streamed, only DISTINCT keys take slots.
+// ================================================================================================================
+constexpr unsigned int kBkt = 1024, kBktSample = 4096;
+constexpr unsigned int kBktChunk = 4096, kBktThreads = 512, kBktPer = kBktChunk / kBktThreads;     // 8 elements per lane
+constexpr unsigned int kBktGrid = 512;
+constexpr unsigned int kBktSlots = 1024;                           // G1's LDS table
+constexpr unsigned long long kBktInf = ~0ull;
+
+template <unsigned int N, unsigned int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* s)
+{
+    for (unsigned int size = 2; size <= N; size <<= 1)
+        for (unsigned int stride = size >> 1; stride; stride >>= 1) {
+            for (unsigned int t = threadIdx.x; t < N / 2; t += THREADS) {
+                const unsigned int lo = 2u * t - (t & (stride - 1u)), hi = lo + stride;
+                const bool up = (lo & size) == 0u;
+                const unsigned long long a = s[lo], b = s[hi];
+                if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+            }
+            __syncthreads();
+        }
+}
+
+// S0: splitters from a regular sample of the keys (cold start of a workspace / a new leaf).
+__global__ __launch_bounds__(1024)
+void pcs_vox_bkt_sample_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ ctl, RawKeys raw,
+                               unsigned long long* __restrict__ spl)
+{
+    __shared__ unsigned long long s[kBktSample];
+    const unsigned int m = raw.keys ? raw.count() : ctl[0];
+    const unsigned long long* __restrict__ k = raw.keys ? raw.keys : keys;
+    for (unsigned int i = threadIdx.x; i < kBktSample; i += 1024u) {
+        unsigned long long v = kBktInf;
+        if (m) {
+            const unsigned int e = (unsigned int)(((unsigned long long)i * m + (m >> 1)) / kBktSample);
+            v = k[e < m ? e : m - 1u];
+        }
+        s[i] = v;
+    }
+    __syncthreads();
+    bitonic_sort_lds<kBktSample, 1024u>(s);
+    for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += 1024u) spl[j - 1u] = s[j * (kBktSample / kBkt)];
+    if (threadIdx.x == 0) spl[kBkt - 1u] = kBktInf;
+}
+
+// P1: table[chunk][bucket] = elements of the chunk in the bucket; bucket_of[e]
+__global__ __launch_bounds__(kBktThreads)
+void pcs_vox_bkt_hist_kernel(const unsigned long long* __restrict__ keys, unsigned int* __restrict__ ctl, RawKeys raw,
+                             const unsigned long long* __restrict__ spl_g, unsigned int* __restrict__ table,
+                             unsigned short* __restrict__ bucket_of)
+{
+    __shared__ unsigned long long spl[kBkt];
+    __shared__ unsigned int hist[kBkt];
+    const bool from_raw = raw.keys != nullptr;
+    // raw input: this launch also publishes the element count for the device-driven kernels that follow
+    const unsigned int m = from_raw ? raw.count() : ctl[0];
+    if (from_raw && blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = m;
+    const unsigned long long* __restrict__ k = from_raw ? raw.keys : keys;
+    const unsigned int chunks = (m + kBktChunk - 1u) / kBktChunk;
+    if (blockIdx.x >= chunks) return;
+    for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) spl[j] = j + 1u < kBkt ? spl_g[j] : kBktInf;
+    __syncthreads();
+    // the splitters must ascend, or bucket order would not be key order. They do by construction (S0 sorts, G1 rewrites
+    // all of them monotonically); if they ever did not, every workgroup sees the same array and takes the same way out: one
+    // bucket for everything (slow, exact — and G1 then rewrites every splitter from sorted keys).
+    bool bad = false;
+    for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) bad |= spl[j - 1u] > spl[j];
+    if (__syncthreads_or(bad ? 1 : 0)) {
+        for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) spl[j] = kBktInf;
+        __syncthreads();
+    }
+    for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) hist[j] = 0u;
+        __syncthreads();
+        const unsigned int c0 = chunk * kBktChunk;
+        unsigned long long kk[kBktPer];
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            const unsigned int e = c0 + q * kBktThreads + threadIdx.x;
+            kk[q] = e < m ? k[e] : 0ull;
+        }
+        // the eight binary searches side by side (ten dependent LDS reads each)
+        unsigned int lo[kBktPer];
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) lo[q] = 0u;
+#pragma unroll
+        for (unsigned int step = kBkt / 2; step; step >>= 1) {
+#pragma unroll
+            for (unsigned int q = 0; q < kBktPer; q++)
+                if (spl[lo[q] + step - 1u] <= kk[q]) lo[q] += step;
+        }
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            const unsigned int e = c0 + q * kBktThreads + threadIdx.x;
+            if (e < m) {
+                atomicAdd(&hist[lo[q]], 1u);
+                bucket_of[e] = (unsigned short)lo[q];
+            }
+        }
+        __syncthreads();
+        for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) table[(size_t)chunk * kBkt + j] = hist[j];
+        __syncthreads();
+    }
+}
+
+// P2: exclusive scan of every bucket's column over the chunks (in place) + the bucket's total (the scheme of
+// pcs_voxel_colscan_kernel, kBkt columns).
+__global__ __launch_bounds__(256)
+void pcs_vox_bkt_colscan_kernel(unsigned int* __restrict__ table, const unsigned int* __restrict__ ctl, unsigned int* __restrict__ total)
+{
+    constexpr unsigned int kCols = 16;
+    __shared__ unsigned int tot[16][16];
+    const unsigned int m = ctl[0];
+    const unsigned int chunks = (m + kBktChunk - 1u) / kBktChunk;
+    if (chunks <= 256u) {
+        if (blockIdx.x >= kBkt / 16u) return;
+        const unsigned int d = blockIdx.x * 16u + (threadIdx.x & 15u), slot = threadIdx.x >> 4;
+        const unsigned int rps = (chunks + 15u) / 16u, r0 = slot * rps;
+        unsigned int v[16], sum = 0;
+#pragma unroll
+        for (unsigned int j = 0; j < 16; j++) {
+            const unsigned int r = r0 + j;
+            v[j] = (j < rps && r < chunks) ? table[(size_t)r * kBkt + d] : 0u;
+        }
+#pragma unroll
+        for (unsigned int j = 0; j < 16; j++) sum += v[j];
+        tot[slot][threadIdx.x & 15u] = sum;
+        __syncthreads();
+        unsigned int run = 0, all = 0;
+#pragma unroll
+        for (unsigned int q = 0; q < 16; q++) { const unsigned int t = tot[q][threadIdx.x & 15u]; run += q < slot ? t : 0u; all += t; }
+#pragma unroll
+        for (unsigned int j = 0; j < 16; j++) {
+            const unsigned int r = r0 + j;
+            if (j < rps && r < chunks) table[(size_t)r * kBkt + d] = run;
+            run += v[j];
+        }
+        if (slot == 0) total[d] = all;
+        return;
+    }
+    const unsigned int digit = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (digit >= kBkt) return;
+    unsigned int carry = 0;
+    for (unsigned int c0 = 0; c0 < chunks; c0 += 64 * kCols) {
+        unsigned int v[kCols];
+#pragma unroll
+        for (unsigned int q = 0; q < kCols; q++) {
+            const unsigned int c = c0 + q * 64 + lane;
+            v[q] = c < chunks ? table[(size_t)c * kBkt + digit] : 0u;
+        }
+#pragma unroll
+        for (unsigned int q = 0; q < kCols; q++) {
+            const unsigned int c = c0 + q * 64 + lane;
+            if (c0 + q * 64 < chunks) {                           // wave-uniform
+                const unsigned int inc = wave_incl_scan(v[q]);
+                if (c < chunks) table[(size_t)c * kBkt + digit] = carry + inc - v[q];
+                carry += (unsigned int)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+        }
+    }
+    if (lane == 0) total[digit] = carry;
+}
+
+// P3: every (key, partial) to its bucket's range. boff[b] = first element of bucket b (boff[kBkt] = m), written by block 0.
+__global__ __launch_bounds__(kBktThreads)
+void pcs_vox_bkt_scatter_kernel(const unsigned long long* __restrict__ keys, const VoxelPartial* __restrict__ part,
+                                const unsigned short* __restrict__ bucket_of, const unsigned int* __restrict__ ctl, RawKeys raw,
+                                const unsigned int* __restrict__ table, const unsigned int* __restrict__ total,
+                                unsigned long long* __restrict__ keys_s, VoxelPartial* __restrict__ part_s,
+                                unsigned int* __restrict__ boff)
+{
+    __shared__ unsigned int cur[kBkt];
+    __shared__ unsigned int wsum[kBktThreads / 64];
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned int m = ctl[0];
+    const unsigned long long* __restrict__ k = raw.keys ? raw.keys : keys;
+    const unsigned int chunks = (m + kBktChunk - 1u) / kBktChunk;
+    if (blockIdx.x >= chunks && blockIdx.x != 0) return;
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // bucket bases: exclusive scan of the kBkt totals, two buckets per lane
+    const u32x2 t2 = *reinterpret_cast<const u32x2*>(total + 2u * threadIdx.x);
+    const unsigned int s2 = t2.x + t2.y;
+    const unsigned int inc = wave_incl_scan(s2);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int run = inc - s2;
+    for (unsigned int w = 0; w < wave; w++) run += wsum[w];
+    const unsigned int base0 = run, base1 = run + t2.x;
+    if (blockIdx.x == 0) {
+        boff[2u * threadIdx.x] = base0; boff[2u * threadIdx.x + 1u] = base1;
+        if (threadIdx.x == kBktThreads - 1u) boff[kBkt] = base1 + t2.y;
+    }
+    for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const unsigned int c0 = chunk * kBktChunk;
+        // everything the chunk needs from memory, requested together
+        unsigned long long kk[kBktPer];
+        unsigned int bb[kBktPer];
+        u32x4 pa[kBktPer], pb[kBktPer];
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            const unsigned int e = c0 + q * kBktThreads + threadIdx.x;
+            const bool live = e < m;
+            kk[q] = live ? k[e] : 0ull;
+            bb[q] = live ? bucket_of[e] : 0u;
+            const u32x4* p4 = reinterpret_cast<const u32x4*>(part + (live ? e : 0u));
+            pa[q] = p4[0]; pb[q] = p4[1];
+        }
+        const u32x2 row = *reinterpret_cast<const u32x2*>(table + (size_t)chunk * kBkt + 2u * threadIdx.x);
+        cur[2u * threadIdx.x] = base0 + row.x;
+        cur[2u * threadIdx.x + 1u] = base1 + row.y;
+        __syncthreads();
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            const unsigned int e = c0 + q * kBktThreads + threadIdx.x;
+            if (e < m) {
+                const unsigned int dst = atomicAdd(&cur[bb[q]], 1u);
+                keys_s[dst] = kk[q];
+                u32x4* o4 = reinterpret_cast<u32x4*>(part_s + dst);
+                o4[0] = pa[q]; o4[1] = pb[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// G1's table: key + six 64-bit sums per slot (a voxel may collect every point of the cloud: 2^25 points x 2^16 overflow 32
+// bits in every field); blue and the count share a word (b < 2^34, n < 2^30).
+__device__ __forceinline__ void bkt_hash(unsigned long long key, unsigned int& first, unsigned int& step)
+{
+    const unsigned int lo = (unsigned int)key, hi = (unsigned int)(key >> 32);
+    const unsigned int h = __umul24(lo, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbit(hi, lo, 24), 0x85EBCBu);
+    first = h >> 22;                                                       // 10 bits
+    step = ((h >> 11) & (kBktSlots - 1u)) | 1u;                            // odd: the probe sequence visits every slot
+}
+
+// rank of v among NRUNS sorted runs of 64 words (padded with the sentinel) = its place in its own run + the words below it in
+// every other run: the binary searches run side by side
+template <unsigned int NRUNS>
+__device__ __forceinline__ unsigned int bkt_rank(const unsigned long long* runs, unsigned long long v, unsigned int my_run, unsigned int lane)
+{
+    unsigned int lo[NRUNS];
+#pragma unroll
+    for (unsigned int run = 0; run < NRUNS; run++) lo[run] = 0u;
+#pragma unroll
+    for (unsigned int step = 32; step; step >>= 1) {
+#pragma unroll
+        for (unsigned int run = 0; run < NRUNS; run++)
+            if (runs[run * 64u + lo[run] + step - 1u] < v) lo[run] += step;
+    }
+    unsigned int r = 0;
+#pragma unroll
+    for (unsigned int run = 0; run < NRUNS; run++) {
+        if (lo[run] == 63u && runs[run * 64u + 63u] < v) lo[run] = 64u;
+        r += run == my_run ? lane : lo[run];
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(kBktThreads)
+void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, const VoxelPartial* __restrict__ part_s,
+                               const unsigned int* __restrict__ boff, const unsigned int* __restrict__ ctl,
+                               int16_t* __restrict__ tmp_rec, unsigned int* __restrict__ dcount, unsigned long long* __restrict__ spl)
+{
+    __shared__ unsigned long long tkey[kBktSlots];
+    __shared__ unsigned long long tx[kBktSlots], ty[kBktSlots], tz[kBktSlots], tr[kBktSlots], tg[kBktSlots], tbn[kBktSlots];
+    __shared__ unsigned long long dl[kBktSlots];           // the occupied slots as (key << 10 | slot): dense, then in key order
+    __shared__ unsigned long long srt[kBktSlots];
+    __shared__ unsigned int wcnt[kBktThreads / 64];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned int m = ctl[0];
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (unsigned int b = blockIdx.x; b < kBkt; b += gridDim.x) {
+        const unsigned int o0 = boff[b], n = boff[b + 1u] - o0;
+        unsigned int emitted = 0, last_c = 0;
+        unsigned long long L = 0ull, T = kBktInf;              // this pass takes the keys in [L, T)
+        bool more = n != 0u;
+        while (more) {                                          // workgroup-uniform
+            // the first batch's loads go out before the table is cleared
+            unsigned long long key_n = 0ull;
+            u32x4 pa_n = u32x4{0u, 0u, 0u, 0u}, pb_n = pa_n;
+            if (threadIdx.x < n) {
+                key_n = keys_s[o0 + threadIdx.x];
+                const u32x4* p4 = reinterpret_cast<const u32x4*>(part_s + o0 + threadIdx.x);
+                pa_n = p4[0]; pb_n = p4[1];
+            }
+            {
+                u32x4* z4;
+                const u32x4 zero{0u, 0u, 0u, 0u}, ones{~0u, ~0u, ~0u, ~0u};
+                z4 = reinterpret_cast<u32x4*>(tkey); z4[threadIdx.x] = ones;                     // kEmptyKey = ~0
+                z4 = reinterpret_cast<u32x4*>(tx);  z4[threadIdx.x] = zero;
+                z4 = reinterpret_cast<u32x4*>(ty);  z4[threadIdx.x] = zero;
+                z4 = reinterpret_cast<u32x4*>(tz);  z4[threadIdx.x] = zero;
+                z4 = reinterpret_cast<u32x4*>(tr);  z4[threadIdx.x] = zero;
+                z4 = reinterpret_cast<u32x4*>(tg);  z4[threadIdx.x] = zero;
+                z4 = reinterpret_cast<u32x4*>(tbn); z4[threadIdx.x] = zero;
+            }
+            __syncthreads();
+            bool restart = false, over_any = false;
+            for (unsigned int i0 = 0; i0 < n; i0 += kBktThreads) {
+                const unsigned int e = i0 + threadIdx.x;
+                const bool live = e < n;
+                const unsigned long long key = key_n;
+                const u32x4 pa = pa_n, pb = pb_n;
+                {   // the next batch is requested before this one meets the table
+                    const unsigned int e2 = e + kBktThreads;
+                    if (e2 < n) {
+                        key_n = keys_s[o0 + e2];
+                        const u32x4* p4 = reinterpret_cast<const u32x4*>(part_s + o0 + e2);
+                        pa_n = p4[0]; pb_n = p4[1];
+                    }
+                }
+                const bool over = live && key >= T;
+                const bool in = live && key >= L && !over;
+                int slot = -1;
+                if (in) {
+                    unsigned int h, step;
+                    bkt_hash(key, h, step);
+                    for (unsigned int t = 0; t < kBktSlots; t++) {
+                        const unsigned long long old = atomicCAS(&tkey[h], kEmptyKey, key);
+                        if (old == kEmptyKey || old == key) { slot = (int)h; break; }
+                        h = (h + step) & (kBktSlots - 1u);
+                    }
+                }
+                over_any |= over;
+                if (__syncthreads_or((in && slot < 0) ? 1 : 0)) { restart = true; break; }     // somebody found the table FULL
+                if (in) {
+                    atomicAdd(&tx[slot], (unsigned long long)(long long)(int)pa.x);
+                    atomicAdd(&ty[slot], (unsigned long long)(long long)(int)pa.y);
+                    atomicAdd(&tz[slot], (unsigned long long)(long long)(int)pa.z);
+                    atomicAdd(&tr[slot], (unsigned long long)pa.w);
+                    atomicAdd(&tg[slot], (unsigned long long)pb.x);
+                    atomicAdd(&tbn[slot], (unsigned long long)pb.y | ((unsigned long long)pb.z << 34));
+                }
+            }
+            // did anybody meet a key at or above T? (also the barrier behind the last batch's adds)
+            const bool beyond = __syncthreads_or(over_any ? 1 : 0) != 0;
+            // the occupied slots, dense: every lane owns slots 2t, 2t + 1
+            const unsigned long long k0 = tkey[2u * threadIdx.x], k1 = tkey[2u * threadIdx.x + 1u];
+            const unsigned int c2 = (k0 != kEmptyKey) + (k1 != kEmptyKey);
+            const unsigned int inc = wave_incl_scan(c2);
+            if (lane == 63) wcnt[wave] = inc;
+            __syncthreads();
+            unsigned int pos = inc - c2, cnt = 0;
+            for (unsigned int w = 0; w < kBktThreads / 64; w++) { const unsigned int t = wcnt[w]; pos += w < wave ? t : 0u; cnt += t; }
+            if (k0 != kEmptyKey) dl[pos++] = (k0 << 10) | (2u * threadIdx.x);
+            if (k1 != kEmptyKey) dl[pos] = (k1 << 10) | (2u * threadIdx.x + 1u);
+            __syncthreads();
+            // Key order without a barrier-per-stage sort: a wavefront sorts its 64 entries in registers (bitonic network over
+            // cross-lane shuffles, 21 steps), parks the sorted run in LDS, and every entry then finds its rank by binary search
+            // in the other runs (6 + 1 LDS reads each, side by side). Entries are distinct words (the slot rides in the low
+            // bits). A lane holds entry t and, in a bucket with more than 512 voxels, entry t + 512 (runs 8..15). (A bitonic
+            // sort of the 1024 slots through LDS was 55 barrier stages and half of this kernel; ranking every entry by counting
+            // all others was worse.)
+            const unsigned int n_runs = cnt > kBktThreads ? 16u : 8u;
+            unsigned long long v0 = threadIdx.x < cnt ? dl[threadIdx.x] : kBktInf;
+            unsigned long long v1 = threadIdx.x + kBktThreads < cnt ? dl[threadIdx.x + kBktThreads] : kBktInf;
+            __syncthreads();                                    // dl is read; it becomes the runs' home
+#pragma unroll
+            for (unsigned int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+                    const bool keep_min = ((lane & j) == 0u) == ((lane & k) == 0u);
+                    const unsigned long long o0v = __shfl_xor(v0, (int)j);
+                    v0 = ((v0 < o0v) == keep_min) ? v0 : o0v;
+                    if (n_runs == 16u) {                        // workgroup-uniform
+                        const unsigned long long o1v = __shfl_xor(v1, (int)j);
+                        v1 = ((v1 < o1v) == keep_min) ? v1 : o1v;
+                    }
+                }
+            }
+            dl[wave * 64u + lane] = v0;
+            if (n_runs == 16u) dl[kBktThreads + wave * 64u + lane] = v1;
+            __syncthreads();
+            auto rank_of = [&](unsigned long long v, unsigned int my_run) {
+                return n_runs == 16u ? bkt_rank<16>(dl, v, my_run, lane) : bkt_rank<8>(dl, v, my_run, lane);
+            };
+            if (v0 != kBktInf) srt[rank_of(v0, wave)] = v0;
+            if (n_runs == 16u && v1 != kBktInf) srt[rank_of(v1, 8u + wave)] = v1;
+            __syncthreads();
+            if (restart) {
+                // more distinct keys in [L, T) than the table holds: lower T to the median of those seen so far and start the
+                // pass again. cnt == kBktSlots here and the keys are distinct, so the median is above the smallest of them.
+                T = srt[cnt / 2u] >> 10;
+                __syncthreads();
+                continue;
+            }
+            // one record per voxel of this pass, in key order, behind the earlier passes' of this bucket
+            for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
+                const unsigned int slot = (unsigned int)(srt[i] & (kBktSlots - 1u));
+                const unsigned long long bn = tbn[slot];
+                write_voxel(tmp_rec, o0 + emitted + i, (long long)tx[slot], (long long)ty[slot], (long long)tz[slot], tr[slot], tg[slot],
+                            bn & ((1ull << 34) - 1ull), (unsigned int)(bn >> 34));
+            }
+            emitted += cnt;
+            last_c = cnt;
+            // keys at or above T were left out: they are the next pass
+            if (beyond) { L = T; T = kBktInf; } else more = false;
+            if (more) __syncthreads();
+        }
+        // next call's splitters: the quantile positions j * m / kBkt that fall into this bucket's share of the partials,
+        // read off the sorted keys of the (last) pass; ascending within the bucket, and buckets are key ranges
+        if (n != 0u && m != 0u) {
+            for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
+                const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
+                if (q >= o0 && q < o0 + n) {
+                    const unsigned int i = (unsigned int)(((unsigned long long)(q - o0) * last_c) / n);
+                    spl[j - 1u] = srt[i < last_c ? i : last_c - 1u] >> 10;
+                }
+            }
+        }
+        if (threadIdx.x == 0) dcount[b] = emitted;
+        __syncthreads();
+    }
+}
+
+// W: records to their final place; the voxel total; the next call's control block.
+__global__ __launch_bounds__(256)
+void pcs_vox_bkt_write_kernel(const int16_t* __restrict__ tmp_rec, const unsigned int* __restrict__ boff,
+                              const unsigned int* __restrict__ dcount, unsigned int* __restrict__ ctl, int16_t* __restrict__ out,
+                              int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next)
+{
+    __shared__ unsigned int base[kBkt];
+    __shared__ unsigned int wsum[4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32x4 d = reinterpret_cast<const u32x4*>(dcount)[threadIdx.x];
+    const unsigned int s4 = d.x + d.y + d.z + d.w;
+    const unsigned int inc = wave_incl_scan(s4);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int run = inc - s4;
+    for (unsigned int w = 0; w < wave; w++) run += wsum[w];
+    base[4u * threadIdx.x] = run; base[4u * threadIdx.x + 1u] = run + d.x;
+    base[4u * threadIdx.x + 2u] = run + d.x + d.y; base[4u * threadIdx.x + 3u] = run + d.x + d.y + d.z;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            const unsigned int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            ctl[1] = total;
+            if (out_points) *out_points = (int32_t)total;
+        } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kCtlWords) {
+            if (zero_next) zero_next[threadIdx.x - 64] = 0u;
+        }
+    }
+    for (unsigned int b = blockIdx.x * 4u + wave; b < kBkt; b += gridDim.x * 4u) {
+        const unsigned int n5 = dcount[b] * PCS_POINT_SHORTS;
+        const int16_t* __restrict__ src = tmp_rec + (size_t)boff[b] * PCS_POINT_SHORTS;
+        int16_t* __restrict__ dst = out + (size_t)base[b] * PCS_POINT_SHORTS;
+        for (unsigned int i = lane; i < n5; i += 64u) dst[i] = src[i];
+    }
+}
+
 struct Workspace {
     unsigned long long *keys_a, *keys_b;
     unsigned int *idx_a, *idx_b;
@@ -818,6 +1297,15 @@ struct Workspace {
     BlockPiece *lead, *trail;
     unsigned int *ctl, *ctl_next;       // this call's control words (ctl[0] = m partials, [1] = voxels, [32..35] key
                                         // bits) and the block the NEXT call on this workspace will use: see plan_for
+    // bucket tail: splitters (kBkt words, persistent across calls), per-chunk bucket counts, bucket totals / offsets / voxel
+    // counts, the bucket-sorted partials and the parked records. keys_s aliases keys_b, bucket_of aliases idx_a (the LSD
+    // path's buffers; a call takes one tail or the other)
+    unsigned long long* spl;
+    unsigned int *btable, *btotal, *boff, *dcount;
+    unsigned long long* keys_s;
+    unsigned short* bucket_of;
+    VoxelPartial* part_s;
+    int16_t* tmp_rec;
     size_t bytes;
 };
 
@@ -828,6 +1316,10 @@ inline Workspace carve(uint8_t* base, size_t n)
     auto take = [&](size_t bytes) { uint8_t* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
     w.ctl = (unsigned int*)take(2 * kCtlWords * sizeof(unsigned int));      // first: where they are must not depend on n
     w.ctl_next = w.ctl + kCtlWords;
+    w.spl = (unsigned long long*)take(kBkt * 8);                             // (its place must not depend on n either)
+    w.btotal = (unsigned int*)take(kBkt * 4);
+    w.boff = (unsigned int*)take((kBkt + 1) * 4);
+    w.dcount = (unsigned int*)take(kBkt * 4);
     w.keys_a = (unsigned long long*)take(n * 8);
     w.keys_b = (unsigned long long*)take(n * 8);
     w.idx_a = (unsigned int*)take(n * 4);
@@ -842,6 +1334,11 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.super = (unsigned int*)take(((((n + kSegThreads - 1) / kSegThreads) >> kSuperShift) + 2) * (size_t)kSuperStride * 4);
     w.lead = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
     w.trail = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
+    w.btable = (unsigned int*)take(((n + kBktChunk - 1) / kBktChunk + 1) * (size_t)kBkt * 4);
+    w.part_s = (VoxelPartial*)take(n * sizeof(VoxelPartial));
+    w.tmp_rec = (int16_t*)take(n * (size_t)PCS_POINT_BYTES + 16);
+    w.keys_s = w.keys_b;
+    w.bucket_of = (unsigned short*)w.idx_a;
     w.bytes = (size_t)(p - base);
     return w;
 }
@@ -858,8 +1355,24 @@ struct Plan {
     VoxelDiv dv;
     unsigned int bits, idx_bits;
     bool track_bits;      // have the pre-aggregation record which key bits vary, so that the sort can skip passes
+    bool bucket = false;       // the bucket tail (5 launches) instead of the LSD sort + segmented mean (12)
+    bool need_sample = false;  // bucket tail: the workspace holds no splitters for this leaf yet
     RawKeys raw{nullptr, nullptr, 0u};      // exchange format: the first pass reads caller-held raw keys
 };
+
+// Which tail a call takes. Both give the same bytes for every input; they differ in what they cost. The bucket tail is built
+// for the ~1 M partials of BASELINE configs[4] (leaves of a few centimetres and up on a room-sized scene): 1024 buckets of
+// ~1000 partials. With many more partials its buckets outgrow the LDS table and are worked off in several passes — the LSD
+// sort is the better tool there. The host does not know the number of partials (nothing is read back), so the choice goes by
+// the leaf: PCS_VOXEL_TAIL=bucket / lsd overrides (read at every call: the tests run both).
+bool choose_bucket_tail(int leaf_mm)
+{
+    if (const char* v = getenv("PCS_VOXEL_TAIL")) {
+        if (v[0] == 'b') return true;
+        if (v[0] == 'l') return false;
+    }
+    return leaf_mm >= 32;
+}
 
 // The constants of floor(v / leaf) + bias for one leaf (pcs_voxel_agg.h: VoxelDiv) + the bits one axis takes.
 hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
@@ -900,6 +1413,7 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
         ws.clean = false;
         const hipError_t e = hipMemsetAsync(pl.w.ctl, 0, 2 * kCtlWords * sizeof(unsigned int), st);
         if (e != hipSuccess) return e;
+        if (ws.base != d_ws) ws.spl_leaf = 0;                    // another workspace: whatever splitters it holds are not ours
         ws.base = d_ws; ws.phase = 0; ws.clean = true;
     }
     if (ws.phase & 1u) std::swap(pl.w.ctl, pl.w.ctl_next);
@@ -922,12 +1436,38 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     static const int track_env = [] { const char* v = getenv("PCS_VOXEL_TRACK"); return v ? atoi(v) : -1; }();
     pl.track_bits = 3u * pl.bits > 3u * kRadixBits;
     if (track_env >= 0) pl.track_bits = track_env != 0;
+    pl.bucket = choose_bucket_tail(leaf_mm);
+    if (pl.bucket) {
+        pl.idx_bits = 0;              // raw keys, as in the exchange format: the bucket tail moves the partials themselves
+        pl.track_bits = false;
+        pl.need_sample = ws.spl_leaf != leaf_mm;
+    }
     return hipSuccess;
+}
+
+// The bucket tail on the partials a pre-aggregation left in the workspace (or a caller handed over: pl.raw).
+hipError_t bucket_tail(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
+{
+    const Workspace& w = pl.w;
+    const unsigned int max_chunks = (n_points + kBktChunk - 1u) / kBktChunk;
+    const unsigned int grid = std::max(1u, std::min(max_chunks, kBktGrid));
+    if (pl.need_sample)
+        hipLaunchKernelGGL(pcs_vox_bkt_sample_kernel, dim3(1), dim3(1024), 0, st, w.keys_a, w.ctl, pl.raw, w.spl);
+    hipLaunchKernelGGL(pcs_vox_bkt_hist_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.ctl, pl.raw, w.spl, w.btable, w.bucket_of);
+    hipLaunchKernelGGL(pcs_vox_bkt_colscan_kernel, dim3(kBkt / 4), dim3(256), 0, st, w.btable, w.ctl, w.btotal);
+    hipLaunchKernelGGL(pcs_vox_bkt_scatter_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.part, w.bucket_of, w.ctl, pl.raw,
+                       w.btable, w.btotal, w.keys_s, w.part_s, w.boff);
+    hipLaunchKernelGGL(pcs_vox_bkt_reduce_kernel, dim3(kBkt), dim3(kBktThreads), 0, st, w.keys_s, w.part_s, w.boff, w.ctl, w.tmp_rec,
+                       w.dcount, w.spl);
+    hipLaunchKernelGGL(pcs_vox_bkt_write_kernel, dim3(256), dim3(256), 0, st, w.tmp_rec, w.boff, w.dcount, w.ctl, d_out, d_out_points,
+                       w.ctl_next);
+    return hipGetLastError();
 }
 
 // Steps 2 and 3 on the partials a pre-aggregation left in the workspace.
 hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_t* d_out_points, hipStream_t st)
 {
+    if (pl.bucket) return bucket_tail(pl, n_points, d_out, d_out_points, st);
     const Workspace& w = pl.w;
     const unsigned int idx_bits = pl.idx_bits;
     const unsigned int n_passes = (3u * pl.bits + kRadixBits - 1u) / kRadixBits;  // the device may skip the first few (SortPass)
@@ -962,10 +1502,15 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
 
 // A call that was enqueued completely hands the other control block to the next one; anything else leaves the workspace
 // to be cleared again.
-hipError_t finish_call(VoxelWsState& ws, hipError_t e)
+hipError_t finish_call(VoxelWsState& ws, hipError_t e, int bucket_leaf = 0)
 {
-    if (e == hipSuccess) ws.phase++;
-    else ws.clean = false;
+    if (e == hipSuccess) {
+        ws.phase++;
+        if (bucket_leaf) ws.spl_leaf = bucket_leaf;      // the bucket tail leaves splitters for this leaf behind
+    } else {
+        ws.clean = false;
+        ws.spl_leaf = 0;
+    }
     return e;
 }
 
@@ -991,7 +1536,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
     if (lane8_ok && ((uintptr_t)d_payload & 15u) == 0u) {
         // 16-byte aligned payload: the reader that shares its table code with the raster reader (pcs_kernels.hip)
         VoxelStage vs{};
-        vs.keys = w.keys_a; vs.idx = w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
+        vs.keys = w.keys_a; vs.idx = pl.bucket ? nullptr : w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
         vs.leaf = (uint32_t)leaf_mm; vs.div_inv = pl.dv.inv; vs.div_c = pl.dv.c; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
         vs.track_bits = pl.track_bits ? 1u : 0u;
         e = launch_payload_voxel_partials(d_payload, n_points, d_n_points, vs, st);
@@ -1007,7 +1552,7 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
             hipLaunchKernelGGL(pcs_voxel_partials_kernel<false>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv,
                                pl.bits, pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
     }
-    return finish_call(*ws, sort_and_reduce(pl, n_points, d_out, d_out_points, st));
+    return finish_call(*ws, sort_and_reduce(pl, n_points, d_out, d_out_points, st), pl.bucket ? leaf_mm : 0);
 }
 
 // Raster source (pcs_kernels.hip: launch_fused_voxel_partials fills the stage between these two calls).
@@ -1018,7 +1563,7 @@ hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t
     hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
     if (e != hipSuccess) return e;
     ws->clean = false;                    // until voxel_finish has enqueued the kernel that clears the other block
-    stage->keys = pl.w.keys_a; stage->idx = pl.w.idx_a; stage->part = pl.w.part; stage->n_runs = pl.w.ctl;
+    stage->keys = pl.w.keys_a; stage->idx = pl.bucket ? nullptr : pl.w.idx_a; stage->part = pl.w.part; stage->n_runs = pl.w.ctl;
     stage->leaf = (uint32_t)leaf_mm; stage->div_inv = pl.dv.inv; stage->div_c = pl.dv.c;
     stage->bits = pl.bits; stage->idx_bits = pl.idx_bits;
     stage->track_bits = pl.track_bits ? 1u : 0u;
@@ -1033,7 +1578,7 @@ hipError_t voxel_finish(uint32_t capacity_points, int leaf_mm, void* d_ws, size_
     Plan pl;
     hipError_t e = plan_for(capacity_points, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
     if (e != hipSuccess) return finish_call(*ws, e);
-    return finish_call(*ws, sort_and_reduce(pl, capacity_points, d_out, d_out_points, st));
+    return finish_call(*ws, sort_and_reduce(pl, capacity_points, d_out, d_out_points, st), pl.bucket ? leaf_mm : 0);
 }
 
 // ---- partials as an exchange format (multi-GPU config 5) -----------------------------------------------------------------
@@ -1069,7 +1614,7 @@ hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const vo
     pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
     pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place
     pl.raw = RawKeys{d_keys, d_n_partials, n_partials};
-    return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st));
+    return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st), pl.bucket ? leaf_mm : 0);
 }
 
 }  // namespace pcs

@@ -9,6 +9,15 @@ from pointcloud_stitching_amd.api import PcsContext, PcsError
 from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID, FLAG_FORCE_IEEE
 
 
+@pytest.fixture(autouse=True, params=["bucket", "lsd"])
+def voxel_tail(request, monkeypatch):
+    """Every test of this file runs with each of the two tails of the voxel pipeline forced (PCS_VOXEL_TAIL is read at every
+    call): the bucket tail (one partition by key splitters + per-bucket LDS tables, 5 launches) and the LSD radix sort +
+    segmented mean (12 launches). Same bytes, whatever the leaf and the input."""
+    monkeypatch.setenv("PCS_VOXEL_TAIL", request.param)
+    return request.param
+
+
 def numpy_voxel_grid(p, leaf):
     p = np.asarray(p, np.int16).reshape(-1, 5)
     if p.shape[0] == 0:
@@ -503,3 +512,52 @@ def test_voxel_entry_forms_interleaved_on_one_context_without_synchronising(orac
         got = ctx.voxel_grid(clouds[1], 50)
         want = oracle.voxel_grid(clouds[1], 50)
         assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.gpu
+def test_bucket_tail_stale_splitters_and_crowded_buckets(oracle, voxel_tail):
+    """The bucket tail's splitters come from the PREVIOUS call on the context (they only decide balance). Worst cases for that:
+    (1) cloud A = two far-apart clusters, then cloud B = 400 k distinct voxels that all lie BETWEEN A's clusters, i.e. inside one
+    of A's key ranges — that bucket must be worked off in many passes over key sub-ranges; (2) then A again (B's splitters are
+    useless for it); (3) a cloud with ~2 M distinct voxels, twice what 1024 tables of 1024 slots hold, whatever the splitters;
+    (4) one voxel that collects 300 k points beside isolated ones (no skew: only distinct keys take slots). Every result against
+    the oracle, on ONE context without synchronising in between."""
+    rng = np.random.default_rng(91)
+    def cloud(n, lo, hi):
+        p = np.zeros((n, 5), np.int16)
+        p[:, :3] = rng.integers(lo, hi, (n, 3))
+        p[:, 3] = rng.integers(0, 65536, n).astype(np.uint16).view(np.int16)
+        p[:, 4] = rng.integers(0, 256, n)
+        return p
+    a = np.concatenate([cloud(60000, -30000, -29000), cloud(60000, 29000, 30000)])
+    bmid = cloud(400000, -4000, 4000)
+    hot = np.concatenate([cloud(300000, 1000, 1040), cloud(5000, -32768, 32767)])
+    many = cloud(2000000, -6000, 6000)
+    leaf = 40
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        for name, p, lf in (("A", a, leaf), ("B", bmid, leaf), ("A", a, leaf), ("hot", hot, leaf), ("B", bmid, leaf),
+                            ("many", many, 32), ("A", a, 32), ("hot", hot, 32767)):
+            got = ctx.voxel_grid(p, lf)
+            want = oracle.voxel_grid(p, lf)
+            assert got.shape == want.shape and (got == want).all(), (name, lf, voxel_tail)
+
+
+@pytest.mark.gpu
+def test_bucket_tail_is_the_default_at_config5_leaf_and_counts_its_launches(oracle, monkeypatch):
+    """Without PCS_VOXEL_TAIL the 50 mm call takes the bucket tail: pcs_kernel_times_ms... is not what says so — the result is
+    the same either way — so this checks the one observable: both forced forms and the default agree with the oracle on the
+    config-5 shape at reduced size, interleaved on one context (the tails share the workspace and its control blocks)."""
+    cfgs, depth, color = S.synth_frame_set(4, 640, 480)
+    stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+    want = oracle.voxel_grid(stitched, 50)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        n_max = sum(c.n_points for c in cfgs)
+        for tail in (None, "lsd", "bucket", None, "bucket", "lsd"):
+            if tail is None:
+                monkeypatch.delenv("PCS_VOXEL_TAIL", raising=False)
+            else:
+                monkeypatch.setenv("PCS_VOXEL_TAIL", tail)
+            got = _rasters_to_voxels(ctx, dd, dc, 50, n_max)
+            assert got.shape == want.shape and (got == want).all(), tail
