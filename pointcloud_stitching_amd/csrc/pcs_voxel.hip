@@ -838,7 +838,10 @@ void pcs_voxel_fixup_kernel(unsigned int* __restrict__ ctl, const BlockPiece* __
 // and the pass restarts; every pass emits its voxels in key order behind the previous pass's. A hot voxel (thousands of
 // partials of one key) is no skew at all: the bucket is streamed, only DISTINCT keys take slots.
 // ================================================================================================================
-constexpr unsigned int kBkt = 1024, kBktSample = 4096;
+#ifndef PCS_BKT
+#define PCS_BKT 1024
+#endif
+constexpr unsigned int kBkt = PCS_BKT, kBktSample = 4096;      // buckets: 256 .. 1024, a power of two
 constexpr unsigned int kBktChunk = 4096, kBktThreads = 512, kBktPer = kBktChunk / kBktThreads;     // 8 elements per lane
 constexpr unsigned int kBktGrid = 512;
 constexpr unsigned int kBktSlots = 1024;                           // G1's LDS table
@@ -896,7 +899,14 @@ void pcs_vox_bkt_hist_kernel(const unsigned long long* __restrict__ keys, unsign
     const unsigned long long* __restrict__ k = from_raw ? raw.keys : keys;
     const unsigned int chunks = (m + kBktChunk - 1u) / kBktChunk;
     if (blockIdx.x >= chunks) return;
-    for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) spl[j] = j + 1u < kBkt ? spl_g[j] : kBktInf;
+    // How many buckets this call uses: a power of two with ~700 - 1400 partials each (a bucket is one workgroup's LDS table:
+    // too many partials and it overflows, too few and 1024 workgroups queue up for nothing). The workspace keeps kBkt - 1
+    // splitters (the 1/1024 quantiles); a call with B buckets takes every (kBkt / B)-th. Buckets B .. kBkt - 1 stay empty:
+    // every later kernel sees zero counts for them and needs no special case.
+    unsigned int B = kBkt;
+    while (B > 32u && (unsigned long long)B * 700ull > m) B >>= 1;
+    const unsigned int stride = kBkt / B;
+    for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) spl[j] = j + 1u < B ? spl_g[(j + 1u) * stride - 1u] : kBktInf;
     __syncthreads();
     // the splitters must ascend, or bucket order would not be key order. They do by construction (S0 sorts, G1 rewrites
     // all of them monotonically); if they ever did not, every workgroup sees the same array and takes the same way out: one
@@ -1009,25 +1019,30 @@ void pcs_vox_bkt_scatter_kernel(const unsigned long long* __restrict__ keys, con
 {
     __shared__ unsigned int cur[kBkt];
     __shared__ unsigned int wsum[kBktThreads / 64];
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const unsigned int m = ctl[0];
     const unsigned long long* __restrict__ k = raw.keys ? raw.keys : keys;
     const unsigned int chunks = (m + kBktChunk - 1u) / kBktChunk;
     if (blockIdx.x >= chunks && blockIdx.x != 0) return;
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // bucket bases: exclusive scan of the kBkt totals, two buckets per lane
-    const u32x2 t2 = *reinterpret_cast<const u32x2*>(total + 2u * threadIdx.x);
-    const unsigned int s2 = t2.x + t2.y;
+    // bucket bases: exclusive scan of the kBkt totals, kOwn consecutive buckets per lane
+    constexpr unsigned int kOwn = (kBkt + kBktThreads - 1u) / kBktThreads;
+    const bool owner = threadIdx.x * kOwn < kBkt;
+    unsigned int tt[kOwn], s2 = 0;
+#pragma unroll
+    for (unsigned int q = 0; q < kOwn; q++) { tt[q] = owner ? total[threadIdx.x * kOwn + q] : 0u; s2 += tt[q]; }
     const unsigned int inc = wave_incl_scan(s2);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     unsigned int run = inc - s2;
     for (unsigned int w = 0; w < wave; w++) run += wsum[w];
-    const unsigned int base0 = run, base1 = run + t2.x;
-    if (blockIdx.x == 0) {
-        boff[2u * threadIdx.x] = base0; boff[2u * threadIdx.x + 1u] = base1;
-        if (threadIdx.x == kBktThreads - 1u) boff[kBkt] = base1 + t2.y;
+    unsigned int base[kOwn];
+#pragma unroll
+    for (unsigned int q = 0; q < kOwn; q++) { base[q] = run; run += tt[q]; }
+    if (blockIdx.x == 0 && owner) {
+#pragma unroll
+        for (unsigned int q = 0; q < kOwn; q++) boff[threadIdx.x * kOwn + q] = base[q];
+        if (threadIdx.x * kOwn + kOwn == kBkt) boff[kBkt] = run;
     }
     for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         const unsigned int c0 = chunk * kBktChunk;
@@ -1044,9 +1059,11 @@ void pcs_vox_bkt_scatter_kernel(const unsigned long long* __restrict__ keys, con
             const u32x4* p4 = reinterpret_cast<const u32x4*>(part + (live ? e : 0u));
             pa[q] = p4[0]; pb[q] = p4[1];
         }
-        const u32x2 row = *reinterpret_cast<const u32x2*>(table + (size_t)chunk * kBkt + 2u * threadIdx.x);
-        cur[2u * threadIdx.x] = base0 + row.x;
-        cur[2u * threadIdx.x + 1u] = base1 + row.y;
+        if (owner) {
+#pragma unroll
+            for (unsigned int q = 0; q < kOwn; q++)
+                cur[threadIdx.x * kOwn + q] = base[q] + table[(size_t)chunk * kBkt + threadIdx.x * kOwn + q];
+        }
         __syncthreads();
 #pragma unroll
         for (unsigned int q = 0; q < kBktPer; q++) {
@@ -1219,8 +1236,14 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
             if (restart) {
                 // more distinct keys in [L, T) than the table holds: lower T to the median of those seen so far and start the
                 // pass again. cnt == kBktSlots here and the keys are distinct, so the median is above the smallest of them.
-                T = srt[cnt / 2u] >> 10;
+                const unsigned long long t_new = srt[cnt / 2u] >> 10;
                 __syncthreads();
+                if (t_new >= T || t_new <= L) {                // cannot happen (distinct keys, cnt >= 2): never loop on it
+                    if (threadIdx.x == 0) atomicOr(const_cast<unsigned int*>(ctl) + 3, 1u);
+                    more = false;
+                    continue;
+                }
+                T = t_new;
                 continue;
             }
             // one record per voxel of this pass, in key order, behind the earlier passes' of this bucket
@@ -1262,21 +1285,24 @@ void pcs_vox_bkt_write_kernel(const int16_t* __restrict__ tmp_rec, const unsigne
     __shared__ unsigned int wsum[4];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32x4 d = reinterpret_cast<const u32x4*>(dcount)[threadIdx.x];
+    const bool owner = 4u * threadIdx.x < kBkt;
+    const u32x4 d = owner ? reinterpret_cast<const u32x4*>(dcount)[threadIdx.x] : u32x4{0u, 0u, 0u, 0u};
     const unsigned int s4 = d.x + d.y + d.z + d.w;
     const unsigned int inc = wave_incl_scan(s4);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     unsigned int run = inc - s4;
     for (unsigned int w = 0; w < wave; w++) run += wsum[w];
-    base[4u * threadIdx.x] = run; base[4u * threadIdx.x + 1u] = run + d.x;
-    base[4u * threadIdx.x + 2u] = run + d.x + d.y; base[4u * threadIdx.x + 3u] = run + d.x + d.y + d.z;
+    if (owner) {
+        base[4u * threadIdx.x] = run; base[4u * threadIdx.x + 1u] = run + d.x;
+        base[4u * threadIdx.x + 2u] = run + d.x + d.y; base[4u * threadIdx.x + 3u] = run + d.x + d.y + d.z;
+    }
     __syncthreads();
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             const unsigned int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
             ctl[1] = total;
-            if (out_points) *out_points = (int32_t)total;
+            if (out_points) *out_points = ctl[3] ? -1 : (int32_t)total;      // (ctl[3]: the reduce's never-taken way out)
         } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kCtlWords) {
             if (zero_next) zero_next[threadIdx.x - 64] = 0u;
         }
