@@ -1737,6 +1737,8 @@ int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm
     int32_t nv = 0;
     HIPCHK(c, hipMemcpyAsync(&nv, c->d_counts, sizeof nv, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nv < 0)       // the device forms report this count as it is (-1); see include/pcs_hip.h
+        return fail(c, PCS_ERR_HIP, "the voxel pipeline gave up waiting for one of its own workgroups (device stalled?)");
     if (out_shorts < (size_t)nv * PCS_POINT_SHORTS)
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts, %zu needed", out_shorts, (size_t)nv * PCS_POINT_SHORTS);
     if (nv) HIPCHK(c, hipMemcpy(out, c->s_voxel_out, (size_t)nv * PCS_POINT_BYTES, hipMemcpyDeviceToHost));

@@ -1241,7 +1241,15 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 // segmented mean run unchanged.
 #include "pcs_voxel_agg.h"
 
-constexpr int kVoxThreads = 512;
+#ifndef PCS_VOX_THREADS
+#define PCS_VOX_THREADS 512
+#endif
+// 512 lanes = 8 wavefronts, two workgroups per CU. (Round 5 tried 640 = 10 wavefronts for a fifth wavefront per SIMD at <= 96
+// VGPRs: 0.266 instead of 0.197 ms per 16 x 1080p frame-set — a workgroup's wavefronts are dealt to the SIMDs 3-3-2-2 and two such
+// workgroups would need six slots on two SIMDs, so only ONE fits a CU. A workgroup must be a multiple of four wavefronts.)
+constexpr int kVoxThreads = PCS_VOX_THREADS;
+constexpr uint32_t kVoxRows = kVoxThreads / 8;    // a round = kVoxRows rows of 64 pixels (8 lanes x 8 pixels)
+constexpr int kVoxOwn = (kSlots + kVoxThreads - 1) / kVoxThreads;      // table slots a lane flushes
 constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 points per round; `rounds` of them share one table
 
 // The workgroup's LDS table: slot = key + the seven sums in three 64-bit words and one 32-bit word: (x, y), (z, count),
@@ -1406,7 +1414,7 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
     // every lane owns four slots; one partial per occupied slot
     unsigned int c = 0;
 #pragma unroll
-    for (int q = 0; q < kSlots / kVoxThreads; q++) c += skey[threadIdx.x * (kSlots / kVoxThreads) + q] != kEmptyKey;
+    for (int q = 0; q < kVoxOwn; q++) { const int j = threadIdx.x * kVoxOwn + q; c += j < kSlots && skey[j] != kEmptyKey; }
     const unsigned int inc = wave_inclusive_scan(c);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
@@ -1418,9 +1426,9 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
     __syncthreads();
     unsigned int pos = base_s + wtot[wave] + inc - c;
 #pragma unroll
-    for (int q = 0; q < kSlots / kVoxThreads; q++) {
-        const int j = threadIdx.x * (kSlots / kVoxThreads) + q;
-        if (skey[j] != kEmptyKey) {
+    for (int q = 0; q < kVoxOwn; q++) {
+        const int j = threadIdx.x * kVoxOwn + q;
+        if (j < kSlots && skey[j] != kEmptyKey) {
             if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
             else { vs.keys[pos] = skey[j]; if (vs.idx) vs.idx[pos] = pos; }
             const unsigned long long xy = sxy[j], zn = szn[j], rg = srg[j];
@@ -1484,7 +1492,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     const uint32_t ry = rx ? (uint32_t)rounds / (uint32_t)rx : 1u;
     const uint32_t px = rx ? blockIdx.x % patches_x : 0u, py = rx ? blockIdx.x / patches_x : 0u;
     const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
-    if (rx ? (py * 64u * ry >= Hh) : (tile0 >= n)) return;
+    if (rx ? (py * kVoxRows * ry >= Hh) : (tile0 >= n)) return;
     const uint8_t* __restrict__ color = fp.color[s];
     DepthSource<DD, CD, Mth> src{fp.depth[s]};
     vox_table_init(T);
@@ -1492,7 +1500,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     for (int round = 0; round < rounds; round++) {
         uint32_t i0;
         if (rx) {
-            const uint32_t row = (py * ry + (uint32_t)round / (uint32_t)rx) * 64u + (threadIdx.x >> 3);
+            const uint32_t row = (py * ry + (uint32_t)round / (uint32_t)rx) * kVoxRows + (threadIdx.x >> 3);
             const uint32_t col = (px * (uint32_t)rx + (uint32_t)round % (uint32_t)rx) * 64u + (threadIdx.x & 7u) * 8u;
             i0 = (row < Hh && col < W) ? row * W + col : n;        // W % 8 == 0: a lane is inside the row or outside it
         } else {
@@ -1994,7 +2002,7 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     dim3 grid;
     if (rx) {
         const uint32_t ry = (uint32_t)rounds / (uint32_t)rx;
-        grid = dim3(((max_w + 64u * rx - 1) / (64u * rx)) * ((max_h + 64u * ry - 1) / (64u * ry)), (unsigned)n_launch, 1);
+        grid = dim3(((max_w + 64u * rx - 1) / (64u * rx)) * ((max_h + kVoxRows * ry - 1) / (kVoxRows * ry)), (unsigned)n_launch, 1);
     } else {
         const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
         grid = dim3((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);

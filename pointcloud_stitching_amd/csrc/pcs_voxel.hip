@@ -844,7 +844,7 @@ void pcs_voxel_fixup_kernel(unsigned int* __restrict__ ctl, const BlockPiece* __
 constexpr unsigned int kBkt = PCS_BKT, kBktSample = 4096;      // buckets: 256 .. 1024, a power of two
 constexpr unsigned int kBktChunk = 4096, kBktThreads = 512, kBktPer = kBktChunk / kBktThreads;     // 8 elements per lane
 constexpr unsigned int kBktGrid = 512;
-constexpr unsigned int kBktSlots = 1024;                           // G1's LDS table
+constexpr unsigned int kBktSlots = 1024, kBktProbe = 24;           // G1's LDS table
 constexpr unsigned long long kBktInf = ~0ull;
 
 template <unsigned int N, unsigned int THREADS>
@@ -1089,6 +1089,50 @@ __device__ __forceinline__ void bkt_hash(unsigned long long key, unsigned int& f
     step = ((h >> 11) & (kBktSlots - 1u)) | 1u;                            // odd: the probe sequence visits every slot
 }
 
+// First output voxel of bucket b = the voxel counts of the buckets before it, which they publish (tagged with this call's
+// generation: nobody clears the words) as soon as they know them. Waiting on LOWER-numbered workgroups only is safe on hardware
+// that starts workgroups in order (what rocPRIM's look-back scan relies on too); the wait is bounded all the same: after ~0.5 s
+// the workgroup gives up, flags the call (ctl[3] -> *out_points = -1) and carries on, so a launch can end wrong but never hang.
+__device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsigned int b, unsigned int gen, unsigned int* ctl, unsigned int* wsum)
+{
+    unsigned int sum = 0;
+    bool gave_up = false;
+    for (unsigned int t = threadIdx.x; t < b; t += kBktThreads) {
+        unsigned int v = __hip_atomic_load(pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 26) != gen) {
+            const long long t0 = wall_clock64();                           // 100 MHz
+            do {
+                __builtin_amdgcn_s_sleep(4);
+                v = __hip_atomic_load(pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((v >> 26) != gen && wall_clock64() - t0 < 50000000ll);
+            if ((v >> 26) != gen) { gave_up = true; v = 0u; }
+        }
+        sum += v & ((1u << 26) - 1u);
+    }
+    if (gave_up) atomicOr(ctl + 3, 2u);
+    const unsigned int inc = wave_incl_scan(sum);
+    __syncthreads();                                                       // wsum may still be read as the dense scan's scratch
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned int total = 0;
+    for (unsigned int w = 0; w < kBktThreads / 64; w++) total += wsum[w];
+    __syncthreads();
+    return total;
+}
+
+// sum of one word per lane over the workgroup (wsum: kBktThreads / 64 words of scratch)
+__device__ __forceinline__ unsigned int bkt_block_sum(unsigned int v, unsigned int* wsum)
+{
+    const unsigned int inc = wave_incl_scan(v);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned int total = 0;
+    for (unsigned int w = 0; w < kBktThreads / 64; w++) total += wsum[w];
+    __syncthreads();
+    return total;
+}
+
 // rank of v among NRUNS sorted runs of 64 words (padded with the sentinel) = its place in its own run + the words below it in
 // every other run: the binary searches run side by side
 template <unsigned int NRUNS>
@@ -1114,23 +1158,52 @@ __device__ __forceinline__ unsigned int bkt_rank(const unsigned long long* runs,
 
 __global__ __launch_bounds__(kBktThreads)
 void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, const VoxelPartial* __restrict__ part_s,
-                               const unsigned int* __restrict__ boff, const unsigned int* __restrict__ ctl,
-                               int16_t* __restrict__ tmp_rec, unsigned int* __restrict__ dcount, unsigned long long* __restrict__ spl)
+                               const unsigned int* __restrict__ boff, unsigned int* __restrict__ ctl,
+                               int16_t* __restrict__ out, int16_t* __restrict__ tmp_rec, unsigned int* __restrict__ pub, unsigned int gen,
+                               unsigned long long* __restrict__ spl, int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next)
 {
     __shared__ unsigned long long tkey[kBktSlots];
     __shared__ unsigned long long tx[kBktSlots], ty[kBktSlots], tz[kBktSlots], tr[kBktSlots], tg[kBktSlots], tbn[kBktSlots];
     __shared__ unsigned long long dl[kBktSlots];           // the occupied slots as (key << 10 | slot): dense, then in key order
     __shared__ unsigned long long srt[kBktSlots];
     __shared__ unsigned int wcnt[kBktThreads / 64];
+    __shared__ unsigned long long smp[64];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const unsigned int m = ctl[0];
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (unsigned int b = blockIdx.x; b < kBkt; b += gridDim.x) {
         const unsigned int o0 = boff[b], n = boff[b + 1u] - o0;
-        unsigned int emitted = 0, last_c = 0;
+        unsigned int emitted = 0, base = 0, fed = 0;
+        bool have_base = false, published = false;
         unsigned long long L = 0ull, T = kBktInf;              // this pass takes the keys in [L, T)
         bool more = n != 0u;
+        const bool big = n > 2u * kBktSlots;                    // far more partials than slots: the bucket will take several passes
+        if (big) {
+            // 64 evenly spaced keys, sorted by the first wavefront: every pass takes an upper bound T from them that lets about
+            // 3/4 of a table's worth of partials in, instead of finding out by overflowing (stale splitters, or a cloud with far
+            // more voxels than 1024 tables hold: the LSD tail's territory, but it must not be a cliff)
+            if (wave == 0) {
+                unsigned long long v = keys_s[o0 + (unsigned int)(((unsigned long long)lane * n) >> 6)];
+#pragma unroll
+                for (unsigned int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                    for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+                        const bool keep_min = ((lane & j) == 0u) == ((lane & k) == 0u);
+                        const unsigned long long o = __shfl_xor(v, (int)j);
+                        v = ((v < o) == keep_min) ? v : o;
+                    }
+                }
+                smp[lane] = v;
+            }
+            __syncthreads();
+        }
         while (more) {                                          // workgroup-uniform
+            if (big && T == kBktInf) {
+                const unsigned int want = max(1u, (64u * 768u) / n);       // sample keys per pass
+                unsigned int below = 0;
+                for (unsigned int i = 0; i < 64u; i++) below += smp[i] < L;
+                if (below + want < 64u) { const unsigned long long t = smp[below + want]; if (t > L) T = t; }
+            }
             // the first batch's loads go out before the table is cleared
             unsigned long long key_n = 0ull;
             u32x4 pa_n = u32x4{0u, 0u, 0u, 0u}, pb_n = pa_n;
@@ -1152,6 +1225,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
             }
             __syncthreads();
             bool restart = false, over_any = false;
+            unsigned int my_in = 0;                              // partials this lane fed into the table in this pass
             for (unsigned int i0 = 0; i0 < n; i0 += kBktThreads) {
                 const unsigned int e = i0 + threadIdx.x;
                 const bool live = e < n;
@@ -1171,14 +1245,18 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 if (in) {
                     unsigned int h, step;
                     bkt_hash(key, h, step);
-                    for (unsigned int t = 0; t < kBktSlots; t++) {
+                    // a key that finds no slot within kBktProbe probes calls the table crowded (at half load that happens to one
+                    // key in 2^24): the pass then restarts below the median. Probing a full table to the end cost 1024 dependent
+                    // LDS round trips per lane.
+                    for (unsigned int t = 0; t < kBktProbe; t++) {
                         const unsigned long long old = atomicCAS(&tkey[h], kEmptyKey, key);
                         if (old == kEmptyKey || old == key) { slot = (int)h; break; }
                         h = (h + step) & (kBktSlots - 1u);
                     }
                 }
                 over_any |= over;
-                if (__syncthreads_or((in && slot < 0) ? 1 : 0)) { restart = true; break; }     // somebody found the table FULL
+                my_in += in ? 1u : 0u;
+                if (__syncthreads_or((in && slot < 0) ? 1 : 0)) { restart = true; break; }     // somebody found the table crowded
                 if (in) {
                     atomicAdd(&tx[slot], (unsigned long long)(long long)(int)pa.x);
                     atomicAdd(&ty[slot], (unsigned long long)(long long)(int)pa.y);
@@ -1200,6 +1278,11 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
             for (unsigned int w = 0; w < kBktThreads / 64; w++) { const unsigned int t = wcnt[w]; pos += w < wave ? t : 0u; cnt += t; }
             if (k0 != kEmptyKey) dl[pos++] = (k0 << 10) | (2u * threadIdx.x);
             if (k1 != kEmptyKey) dl[pos] = (k1 << 10) | (2u * threadIdx.x + 1u);
+            // a bucket that is done in this pass (almost all are) tells the later buckets its voxel count NOW, before it sorts
+            if (!restart && !beyond && !published) {
+                if (threadIdx.x == 0) __hip_atomic_store(pub + b, (gen << 26) | (emitted + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                published = true;
+            }
             __syncthreads();
             // Key order without a barrier-per-stage sort: a wavefront sorts its 64 entries in registers (bitonic network over
             // cross-lane shuffles, 21 steps), parks the sorted run in LDS, and every entry then finds its rank by binary search
@@ -1234,8 +1317,9 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
             if (n_runs == 16u && v1 != kBktInf) srt[rank_of(v1, 8u + wave)] = v1;
             __syncthreads();
             if (restart) {
-                // more distinct keys in [L, T) than the table holds: lower T to the median of those seen so far and start the
-                // pass again. cnt == kBktSlots here and the keys are distinct, so the median is above the smallest of them.
+                // more distinct keys in [L, T) than the table takes gracefully: lower T to the median of those seen so far and
+                // start the pass again. The keys are distinct and cnt >= 2 (a lone key always finds its first slot), so the
+                // median is above the smallest of them and below T.
                 const unsigned long long t_new = srt[cnt / 2u] >> 10;
                 __syncthreads();
                 if (t_new >= T || t_new <= L) {                // cannot happen (distinct keys, cnt >= 2): never loop on it
@@ -1246,72 +1330,64 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 T = t_new;
                 continue;
             }
-            // one record per voxel of this pass, in key order, behind the earlier passes' of this bucket
+            // A bucket that is done in ONE pass (almost all are) writes its voxels straight to their final place: behind those of
+            // all earlier buckets (their published counts; see bkt_base). A bucket that takes several passes parks its records
+            // at its own offset and moves them when it is through — if it waited for the earlier buckets between its passes,
+            // the crowded buckets of a call would run one after the other.
+            const bool direct = emitted == 0u && !beyond;
+            if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
+            int16_t* const rec = direct ? out : tmp_rec;
+            const unsigned int first = direct ? base : o0 + emitted;
             for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
                 const unsigned int slot = (unsigned int)(srt[i] & (kBktSlots - 1u));
                 const unsigned long long bn = tbn[slot];
-                write_voxel(tmp_rec, o0 + emitted + i, (long long)tx[slot], (long long)ty[slot], (long long)tz[slot], tr[slot], tg[slot],
+                write_voxel(rec, first + i, (long long)tx[slot], (long long)ty[slot], (long long)tz[slot], tr[slot], tg[slot],
                             bn & ((1ull << 34) - 1ull), (unsigned int)(bn >> 34));
             }
+            // Next call's splitters: the quantile positions j * m / kBkt that fall into THIS PASS's share of the partials — the
+            // passes of a bucket are key ranges in ascending order, so the pass holds the partials of sorted rank
+            // [o0 + fed, o0 + fed + n_in) — read off the pass's sorted keys. Ascending within the pass, across the passes and
+            // across the buckets. (Taking all of a bucket's positions from its LAST pass squeezed its splitters into the top of
+            // its key range: the bucket grew from call to call.)
+            const unsigned int n_in = bkt_block_sum(my_in, wcnt);
+            if (m != 0u && n_in != 0u) {
+                for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
+                    const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
+                    if (q >= o0 + fed && q < o0 + fed + n_in) {
+                        const unsigned int i = (unsigned int)(((unsigned long long)(q - o0 - fed) * cnt) / n_in);
+                        spl[j - 1u] = srt[i < cnt ? i : cnt - 1u] >> 10;
+                    }
+                }
+            }
+            fed += n_in;
             emitted += cnt;
-            last_c = cnt;
             // keys at or above T were left out: they are the next pass
             if (beyond) { L = T; T = kBktInf; } else more = false;
             if (more) __syncthreads();
         }
-        // next call's splitters: the quantile positions j * m / kBkt that fall into this bucket's share of the partials,
-        // read off the sorted keys of the (last) pass; ascending within the bucket, and buckets are key ranges
-        if (n != 0u && m != 0u) {
-            for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
-                const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
-                if (q >= o0 && q < o0 + n) {
-                    const unsigned int i = (unsigned int)(((unsigned long long)(q - o0) * last_c) / n);
-                    spl[j - 1u] = srt[i < last_c ? i : last_c - 1u] >> 10;
-                }
+        if (!published && threadIdx.x == 0)                    // empty buckets, and buckets that took several passes
+            __hip_atomic_store(pub + b, (gen << 26) | emitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!have_base && emitted != 0u) {                     // several passes: the parked records to their final place
+            base = bkt_base(pub, b, gen, ctl, wcnt);
+            have_base = true;
+            __threadfence_block();
+            const int16_t* __restrict__ src = tmp_rec + (size_t)o0 * PCS_POINT_SHORTS;
+            int16_t* __restrict__ dst = out + (size_t)base * PCS_POINT_SHORTS;
+            for (unsigned int i = threadIdx.x; i < emitted * PCS_POINT_SHORTS; i += kBktThreads) dst[i] = src[i];
+        }
+        if (b == kBkt - 1u) {
+            // the last bucket knows the total; it also clears the next call's control block (plan_for)
+            if (!have_base) base = bkt_base(pub, b, gen, ctl, wcnt);
+            if (threadIdx.x == 0) {
+                const unsigned int total = base + emitted;
+                const bool failed = __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                ctl[1] = total;
+                if (out_points) *out_points = failed ? -1 : (int32_t)total;
+            } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kCtlWords) {
+                if (zero_next) zero_next[threadIdx.x - 64] = 0u;
             }
         }
-        if (threadIdx.x == 0) dcount[b] = emitted;
         __syncthreads();
-    }
-}
-
-// W: records to their final place; the voxel total; the next call's control block.
-__global__ __launch_bounds__(256)
-void pcs_vox_bkt_write_kernel(const int16_t* __restrict__ tmp_rec, const unsigned int* __restrict__ boff,
-                              const unsigned int* __restrict__ dcount, unsigned int* __restrict__ ctl, int16_t* __restrict__ out,
-                              int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next)
-{
-    __shared__ unsigned int base[kBkt];
-    __shared__ unsigned int wsum[4];
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const bool owner = 4u * threadIdx.x < kBkt;
-    const u32x4 d = owner ? reinterpret_cast<const u32x4*>(dcount)[threadIdx.x] : u32x4{0u, 0u, 0u, 0u};
-    const unsigned int s4 = d.x + d.y + d.z + d.w;
-    const unsigned int inc = wave_incl_scan(s4);
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    unsigned int run = inc - s4;
-    for (unsigned int w = 0; w < wave; w++) run += wsum[w];
-    if (owner) {
-        base[4u * threadIdx.x] = run; base[4u * threadIdx.x + 1u] = run + d.x;
-        base[4u * threadIdx.x + 2u] = run + d.x + d.y; base[4u * threadIdx.x + 3u] = run + d.x + d.y + d.z;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) {
-            const unsigned int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            ctl[1] = total;
-            if (out_points) *out_points = ctl[3] ? -1 : (int32_t)total;      // (ctl[3]: the reduce's never-taken way out)
-        } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kCtlWords) {
-            if (zero_next) zero_next[threadIdx.x - 64] = 0u;
-        }
-    }
-    for (unsigned int b = blockIdx.x * 4u + wave; b < kBkt; b += gridDim.x * 4u) {
-        const unsigned int n5 = dcount[b] * PCS_POINT_SHORTS;
-        const int16_t* __restrict__ src = tmp_rec + (size_t)boff[b] * PCS_POINT_SHORTS;
-        int16_t* __restrict__ dst = out + (size_t)base[b] * PCS_POINT_SHORTS;
-        for (unsigned int i = lane; i < n5; i += 64u) dst[i] = src[i];
     }
 }
 
@@ -1342,10 +1418,10 @@ inline Workspace carve(uint8_t* base, size_t n)
     auto take = [&](size_t bytes) { uint8_t* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
     w.ctl = (unsigned int*)take(2 * kCtlWords * sizeof(unsigned int));      // first: where they are must not depend on n
     w.ctl_next = w.ctl + kCtlWords;
+    w.dcount = (unsigned int*)take(kBkt * 4);                                // bucket tail: published voxel counts, cleared WITH the control blocks
     w.spl = (unsigned long long*)take(kBkt * 8);                             // (its place must not depend on n either)
     w.btotal = (unsigned int*)take(kBkt * 4);
     w.boff = (unsigned int*)take((kBkt + 1) * 4);
-    w.dcount = (unsigned int*)take(kBkt * 4);
     w.keys_a = (unsigned long long*)take(n * 8);
     w.keys_b = (unsigned long long*)take(n * 8);
     w.idx_a = (unsigned int*)take(n * 4);
@@ -1362,7 +1438,7 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.trail = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
     w.btable = (unsigned int*)take(((n + kBktChunk - 1) / kBktChunk + 1) * (size_t)kBkt * 4);
     w.part_s = (VoxelPartial*)take(n * sizeof(VoxelPartial));
-    w.tmp_rec = (int16_t*)take(n * (size_t)PCS_POINT_BYTES + 16);
+    w.tmp_rec = (int16_t*)take(n * (size_t)PCS_POINT_BYTES + 16);      // records of buckets that take several passes
     w.keys_s = w.keys_b;
     w.bucket_of = (unsigned short*)w.idx_a;
     w.bytes = (size_t)(p - base);
@@ -1383,6 +1459,7 @@ struct Plan {
     bool track_bits;      // have the pre-aggregation record which key bits vary, so that the sort can skip passes
     bool bucket = false;       // the bucket tail (5 launches) instead of the LSD sort + segmented mean (12)
     bool need_sample = false;  // bucket tail: the workspace holds no splitters for this leaf yet
+    unsigned int gen = 1;      // bucket tail: tag of this call's published bucket counts (1 .. 63, never the previous call's)
     RawKeys raw{nullptr, nullptr, 0u};      // exchange format: the first pass reads caller-held raw keys
 };
 
@@ -1397,7 +1474,7 @@ bool choose_bucket_tail(int leaf_mm)
         if (v[0] == 'b') return true;
         if (v[0] == 'l') return false;
     }
-    return leaf_mm >= 32;
+    return leaf_mm >= 40;      // 16 x 1080p synthetic scene, ms per call bucket / LSD: 32 mm 0.333 / 0.292, 40 mm 0.253 / 0.259, 50 mm 0.197 / 0.226
 }
 
 // The constants of floor(v / leaf) + bias for one leaf (pcs_voxel_agg.h: VoxelDiv) + the bits one axis takes.
@@ -1437,10 +1514,11 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     pl.w = carve(base, n_points);
     if (!ws.clean || ws.base != d_ws) {
         ws.clean = false;
-        const hipError_t e = hipMemsetAsync(pl.w.ctl, 0, 2 * kCtlWords * sizeof(unsigned int), st);
+        // (the control blocks and, right behind them, the bucket tail's published counts: their tags must not be garbage)
+        const hipError_t e = hipMemsetAsync(pl.w.ctl, 0, (size_t)((uint8_t*)(pl.w.dcount + kBkt) - (uint8_t*)pl.w.ctl), st);
         if (e != hipSuccess) return e;
         if (ws.base != d_ws) ws.spl_leaf = 0;                    // another workspace: whatever splitters it holds are not ours
-        ws.base = d_ws; ws.phase = 0; ws.clean = true;
+        ws.base = d_ws; ws.phase = 0; ws.bkt_calls = 0; ws.clean = true;
     }
     if (ws.phase & 1u) std::swap(pl.w.ctl, pl.w.ctl_next);
     {
@@ -1467,6 +1545,7 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
         pl.idx_bits = 0;              // raw keys, as in the exchange format: the bucket tail moves the partials themselves
         pl.track_bits = false;
         pl.need_sample = ws.spl_leaf != leaf_mm;
+        pl.gen = 1u + ws.bkt_calls % 63u;                 // differs from the previous bucket call's; a cleared workspace holds tag 0
     }
     return hipSuccess;
 }
@@ -1483,10 +1562,8 @@ hipError_t bucket_tail(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_
     hipLaunchKernelGGL(pcs_vox_bkt_colscan_kernel, dim3(kBkt / 4), dim3(256), 0, st, w.btable, w.ctl, w.btotal);
     hipLaunchKernelGGL(pcs_vox_bkt_scatter_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.part, w.bucket_of, w.ctl, pl.raw,
                        w.btable, w.btotal, w.keys_s, w.part_s, w.boff);
-    hipLaunchKernelGGL(pcs_vox_bkt_reduce_kernel, dim3(kBkt), dim3(kBktThreads), 0, st, w.keys_s, w.part_s, w.boff, w.ctl, w.tmp_rec,
-                       w.dcount, w.spl);
-    hipLaunchKernelGGL(pcs_vox_bkt_write_kernel, dim3(256), dim3(256), 0, st, w.tmp_rec, w.boff, w.dcount, w.ctl, d_out, d_out_points,
-                       w.ctl_next);
+    hipLaunchKernelGGL(pcs_vox_bkt_reduce_kernel, dim3(kBkt), dim3(kBktThreads), 0, st, w.keys_s, w.part_s, w.boff, w.ctl, d_out,
+                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next);
     return hipGetLastError();
 }
 
@@ -1532,7 +1609,7 @@ hipError_t finish_call(VoxelWsState& ws, hipError_t e, int bucket_leaf = 0)
 {
     if (e == hipSuccess) {
         ws.phase++;
-        if (bucket_leaf) ws.spl_leaf = bucket_leaf;      // the bucket tail leaves splitters for this leaf behind
+        if (bucket_leaf) { ws.spl_leaf = bucket_leaf; ws.bkt_calls++; }      // the bucket tail leaves splitters for this leaf behind
     } else {
         ws.clean = false;
         ws.spl_leaf = 0;

@@ -102,9 +102,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    build()
+    path = os.environ.get("PCS_LIB_PATH")      # lab: a variant build of the same ABI (tools/lab/variants); never a fallback
+    if not path:
+        build()
+        path = LIB_PATH
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:   # pragma: no cover - depends on the box
         raise PcsBuildError(f"cannot load {LIB_PATH}: {e} — the HIP extension is required, there is no fallback") from e
     for name, restype, argtypes in SYMBOLS:
