@@ -1244,26 +1244,62 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 #ifndef PCS_VOX_THREADS
 #define PCS_VOX_THREADS 512
 #endif
-// 512 lanes = 8 wavefronts, two workgroups per CU. (Round 5 tried 640 = 10 wavefronts for a fifth wavefront per SIMD at <= 96
-// VGPRs: 0.266 instead of 0.197 ms per 16 x 1080p frame-set — a workgroup's wavefronts are dealt to the SIMDs 3-3-2-2 and two such
-// workgroups would need six slots on two SIMDs, so only ONE fits a CU. A workgroup must be a multiple of four wavefronts.)
+#ifndef PCS_VOX_SLOTS
+#define PCS_VOX_SLOTS 2048
+#endif
+// Workgroup shape of the raster / payload readers: 512 lanes (8 wavefronts) and a 2048-slot table (72 KiB): two workgroups per
+// CU, 4 wavefronts per SIMD at ~105 VGPRs. Round 5 measured the two ways to a FIFTH wavefront per SIMD (<= 96 VGPRs), 16 x 1080p
+// at 50 mm, one call, A/B on one box:
+//   640 lanes x 2 workgroups           0.266 vs 0.197 ms — a workgroup's 10 wavefronts are dealt to the SIMDs 3-3-2-2 and two such
+//                                      workgroups need six slots on two SIMDs: only ONE fits a CU (a workgroup must be a multiple of
+//                                      four wavefronts);
+//   256 lanes x 5 workgroups, 896-slot 0.213 vs 0.205 ms — five wavefronts per SIMD are reached (96 VGPRs, no spill, 31.5 KiB per
+//   tables (-DPCS_VOX_THREADS=256      table, same 128 x 64 patch per table in four rounds), and the launch is slower: the kernel is
+//   -DPCS_VOX_SLOTS=896)               not short of wavefronts to issue from.
+// Both shapes still build (the code below is generic in the two constants); neither is used.
 constexpr int kVoxThreads = PCS_VOX_THREADS;
+constexpr int kVoxSlots = PCS_VOX_SLOTS;
 constexpr uint32_t kVoxRows = kVoxThreads / 8;    // a round = kVoxRows rows of 64 pixels (8 lanes x 8 pixels)
-constexpr int kVoxOwn = (kSlots + kVoxThreads - 1) / kVoxThreads;      // table slots a lane flushes
+constexpr int kVoxOwn = (kVoxSlots + kVoxThreads - 1) / kVoxThreads;      // table slots a lane flushes
 constexpr uint32_t kVoxRoundPoints = kVoxThreads * kPointsPerLane;      // 4096 points per round; `rounds` of them share one table
 
 // The workgroup's LDS table: slot = key + the seven sums in three 64-bit words and one 32-bit word: (x, y), (z, count),
 // (R, G), B — four LDS adds per run instead of seven. Coordinates are summed BIASED (+32768, so every term is
 // non-negative and a 64-bit add never carries between its halves: <= 32 768 points x 65 535 < 2^31); the bias leaves at
 // the output.
+// Probe sequence in a table of kVoxSlots slots (not a power of two): start = the hash's top 16 bits scaled into the table
+// with one 24-bit multiply, odd stride, wrap by a conditional subtract. A run that finds no slot within kProbe probes goes out
+// as a partial of its own, so the sequence need not visit every slot.
+struct VoxProbe {
+    unsigned int first, step;
+    __device__ __forceinline__ explicit VoxProbe(unsigned long long key)
+    {
+        const unsigned int lo = (unsigned int)key, hi = (unsigned int)(key >> 32);
+        const unsigned int m = __umul24(lo, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbit(hi, lo, 24), 0x85EBCBu);
+        if (kVoxSlots == kSlots) {                                         // the 2^11 table: VoxelProbe's sequence (pcs_voxel_agg.h)
+            first = m >> 21;
+            step = ((m >> 10) & (unsigned)(kSlots - 1)) | 1u;
+        } else {
+            first = __umul24(m >> 16, (unsigned int)kVoxSlots) >> 16;      // top 16 bits scaled into the table (the product stays below 2^32)
+            step = ((m >> 3) & 0x7Fu) | 1u;                                // odd, < 128
+        }
+    }
+    __device__ __forceinline__ unsigned int next(unsigned int h) const
+    {
+        if (kVoxSlots == kSlots) return (h + step) & (unsigned)(kSlots - 1);
+        h += step;
+        return h >= (unsigned int)kVoxSlots ? h - (unsigned int)kVoxSlots : h;
+    }
+};
+
 struct VoxTable {
     unsigned long long *skey, *sxy, *szn, *srg;
     unsigned int *sbl, *wtot, *base_s, *flag, *kor;       // kor[4]: OR of the keys written (lo, hi), OR of their complements
 };
 #define PCS_VOX_TABLE_DECL                                                                             \
-    __shared__ unsigned long long skey_[kSlots];                                                       \
-    __shared__ unsigned long long sxy_[kSlots], szn_[kSlots], srg_[kSlots];                            \
-    __shared__ unsigned int sbl_[kSlots];                                                              \
+    __shared__ unsigned long long skey_[kVoxSlots];                                                       \
+    __shared__ unsigned long long sxy_[kVoxSlots], szn_[kVoxSlots], srg_[kVoxSlots];                            \
+    __shared__ unsigned int sbl_[kVoxSlots];                                                              \
     __shared__ unsigned int wtot_[kVoxThreads / 64];                                                   \
     __shared__ unsigned int base_s_, flag_, kor_[4];                                                   \
     const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_, &flag_, kor_};                    \
@@ -1271,7 +1307,7 @@ struct VoxTable {
 
 __device__ __forceinline__ void vox_table_init(const VoxTable& T)
 {
-    for (int j = threadIdx.x; j < kSlots; j += kVoxThreads) {
+    for (int j = threadIdx.x; j < kVoxSlots; j += kVoxThreads) {
         T.skey[j] = kEmptyKey;
         T.sxy[j] = T.szn[j] = T.srg[j] = 0ull;
         T.sbl[j] = 0u;
@@ -1312,7 +1348,7 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
         const bool same_next = live_next && knext == kcur;
         const bool actor = live && !same_next;
         if (actor) {
-            const VoxelProbe pr(kcur);
+            const VoxProbe pr(kcur);
             unsigned int h = pr.first;
             // first probe straight-line (it succeeds for all but a few per cent of the runs), the rest in a loop
             unsigned long long old = atomicCAS(&skey[h], kEmptyKey, kcur);
@@ -1414,7 +1450,7 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
     // every lane owns four slots; one partial per occupied slot
     unsigned int c = 0;
 #pragma unroll
-    for (int q = 0; q < kVoxOwn; q++) { const int j = threadIdx.x * kVoxOwn + q; c += j < kSlots && skey[j] != kEmptyKey; }
+    for (int q = 0; q < kVoxOwn; q++) { const int j = threadIdx.x * kVoxOwn + q; c += j < kVoxSlots && skey[j] != kEmptyKey; }
     const unsigned int inc = wave_inclusive_scan(c);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
@@ -1428,7 +1464,7 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
 #pragma unroll
     for (int q = 0; q < kVoxOwn; q++) {
         const int j = threadIdx.x * kVoxOwn + q;
-        if (j < kSlots && skey[j] != kEmptyKey) {
+        if (j < kVoxSlots && skey[j] != kEmptyKey) {
             if (idx_bits) vs.keys[pos] = (skey[j] << idx_bits) | pos;
             else { vs.keys[pos] = skey[j]; if (vs.idx) vs.idx[pos] = pos; }
             const unsigned long long xy = sxy[j], zn = szn[j], rg = srg[j];
@@ -1980,7 +2016,10 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     // round fall roughly with the square of the leaf. A wrong guess costs speed, never correctness (runs that find no
     // slot go out as partials of their own). Capped so that the launch still fills the chip twice over. The packed sums
     // of the table hold at most 8 rounds.
-    const uint64_t launch_tiles = (uint64_t)((max_points + kVoxRoundPoints - 1) / kVoxRoundPoints) * (uint64_t)n_launch;
+    // (`rounds` below counts SQUARES of 4096 pixels, the unit these measurements were taken in; a workgroup of kVoxThreads lanes
+    // covers one in kSub rounds of kVoxRoundPoints pixels — converted just before the launch)
+    constexpr int kSub = 4096 / (int)kVoxRoundPoints;
+    const uint64_t launch_tiles = (uint64_t)((max_points + 4095u) / 4096u) * (uint64_t)n_launch;
     const uint64_t fill_cap = std::max<uint64_t>(1, launch_tiles / 1024);
     int rounds, rx = 0;
     if (patch_ok && env_patch) {
@@ -1999,6 +2038,7 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);
         if (env_rounds > 0) rounds = std::min(env_rounds, 8);
     }
+    rounds *= kSub;
     dim3 grid;
     if (rx) {
         const uint32_t ry = (uint32_t)rounds / (uint32_t)rx;
@@ -2028,10 +2068,11 @@ hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_po
     // 0.25). Below 30 mm the tables are crowded and runs are passed through per workgroup (vox_table_round): 10 mm 1.97 ms
     // with 2 rounds (that reader: 2.43), 15 mm 1.35 (1.56), 25 mm 0.72 with 3 rounds (0.81).
     static const int env_rounds = [] { const char* v = getenv("PCS_VOXEL_ROUNDS"); return v ? atoi(v) : 0; }();
-    const uint64_t tiles = (n_points + kVoxRoundPoints - 1) / kVoxRoundPoints;
+    const uint64_t tiles = (n_points + 4095u) / 4096u;                   // (rounds in units of 4096 records, as measured)
     const uint64_t by_leaf = vs.leaf >= 80 ? 6 : vs.leaf >= 44 ? 4 : vs.leaf >= 23 ? 3 : 2;
     int rounds = (int)std::min<uint64_t>(by_leaf, std::max<uint64_t>(1, tiles / 1024));
     if (env_rounds > 0) rounds = std::min(env_rounds, 8);
+    rounds *= 4096 / (int)kVoxRoundPoints;
     const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
     hipLaunchKernelGGL(pcs_payload_voxel_partials_kernel, dim3((n_points + tile_points - 1) / tile_points), dim3(kVoxThreads), 0, st,
                        d_payload, n_points, d_n_points, vs, rounds, vs.leaf < 30u ? 1 : 0);
