@@ -1138,36 +1138,120 @@ __device__ __forceinline__ unsigned int bkt_block_sum(unsigned int v, unsigned i
 template <unsigned int NRUNS>
 __device__ __forceinline__ unsigned int bkt_rank(const unsigned long long* runs, unsigned long long v, unsigned int my_run, unsigned int lane)
 {
-    unsigned int lo[NRUNS];
-#pragma unroll
-    for (unsigned int run = 0; run < NRUNS; run++) lo[run] = 0u;
-#pragma unroll
-    for (unsigned int step = 32; step; step >>= 1) {
-#pragma unroll
-        for (unsigned int run = 0; run < NRUNS; run++)
-            if (runs[run * 64u + lo[run] + step - 1u] < v) lo[run] += step;
-    }
+    constexpr unsigned int G = NRUNS < 8u ? NRUNS : 8u;       // searches side by side (more would only cost registers)
     unsigned int r = 0;
+    for (unsigned int g0 = 0; g0 < NRUNS; g0 += G) {
+        unsigned int lo[G];
 #pragma unroll
-    for (unsigned int run = 0; run < NRUNS; run++) {
-        if (lo[run] == 63u && runs[run * 64u + 63u] < v) lo[run] = 64u;
-        r += run == my_run ? lane : lo[run];
+        for (unsigned int q = 0; q < G; q++) lo[q] = 0u;
+#pragma unroll
+        for (unsigned int step = 32; step; step >>= 1) {
+#pragma unroll
+            for (unsigned int q = 0; q < G; q++)
+                if (runs[(g0 + q) * 64u + lo[q] + step - 1u] < v) lo[q] += step;
+        }
+#pragma unroll
+        for (unsigned int q = 0; q < G; q++) {
+            if (lo[q] == 63u && runs[(g0 + q) * 64u + 63u] < v) lo[q] = 64u;
+            r += g0 + q == my_run ? lane : lo[q];
+        }
     }
     return r;
 }
 
-__global__ __launch_bounds__(kBktThreads)
+// one wavefront's 64 words, ascending, in registers: bitonic network over cross-lane shuffles (21 steps)
+__device__ __forceinline__ unsigned long long bkt_wave_sort(unsigned long long v, unsigned int lane)
+{
+    // (the 21 lane masks are recomputed at every call: hoisted out of the bucket loop they occupy 42 SGPRs for the whole kernel,
+    // which then spills ~200 SGPRs and, through them, vector registers)
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (unsigned int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+            const bool keep_min = ((lane & j) == 0u) == ((lane & k) == 0u);
+            const unsigned long long o = __shfl_xor(v, (int)j);
+            v = ((v < o) == keep_min) ? v : o;
+        }
+    }
+    return v;
+}
+
+constexpr unsigned int kBktGiant = 8192, kBktSub = 256;       // a bucket beyond kBktGiant partials is first split into <= kBktSub key ranges
+
+// A GIANT bucket (stale splitters: the cloud moved into one of the previous call's key ranges; or far more voxels than 1024
+// tables hold). Passes over key sub-ranges would each re-read the whole bucket: n^2 / 768 partial reads, half a second for 400 k
+// partials. Instead the workgroup splits the bucket ONCE more — up to 255 splitters from a sorted sample of 256 of its keys, a
+// counting pass, a scatter into the (by now dead) pre-aggregation arrays — and the caller runs the ranges one after the other:
+// three reads of the bucket instead of hundreds. Returns the number of ranges; soff[0 .. n_sub] = their bounds (relative to o0).
+__device__ __forceinline__ unsigned int bkt_presplit(const unsigned long long* __restrict__ keys_s, const VoxelPartial* __restrict__ part_s,
+                                                  unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr,
+                                                  unsigned int o0, unsigned int n, unsigned long long* dl, unsigned long long* srt,
+                                                  unsigned int* scur, unsigned int* soff, unsigned int* wcnt)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // as many ranges as give ~1500 partials each (a range costs a fixed ~6 us on top of its partials): every
+    // (kBktSub / n_sub)-th of the 255 sample splitters
+    unsigned int n_sub = 1;
+    while (n_sub < kBktSub && n_sub * 1536u < n) n_sub <<= 1;
+    const unsigned int sstride = kBktSub / n_sub;
+    if (threadIdx.x < kBktSub) {
+        const unsigned long long k = keys_s[o0 + (unsigned int)(((unsigned long long)threadIdx.x * n) / kBktSub)];
+        const unsigned long long v = bkt_wave_sort((k << 8) | threadIdx.x, lane);      // (distinct words: the index rides below the key)
+        dl[wave * 64u + lane] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kBktSub) srt[bkt_rank<kBktSub / 64u>(dl, dl[threadIdx.x], wave, lane)] = dl[threadIdx.x];
+    if (threadIdx.x < kBktSub) scur[threadIdx.x] = 0u;
+    __syncthreads();
+    auto sub_of = [&](unsigned long long key) {            // number of splitters srt[sstride * (1 .. n_sub - 1)] (>> 8) that are <= key
+        unsigned int lo = 0;
+        for (unsigned int step = n_sub >> 1; step; step >>= 1)
+            if ((srt[(lo + step) * sstride] >> 8) <= key) lo += step;
+        return lo;
+    };
+    for (unsigned int e = threadIdx.x; e < n; e += kBktThreads) atomicAdd(&scur[sub_of(keys_s[o0 + e])], 1u);
+    __syncthreads();
+    {
+        const unsigned int c = threadIdx.x < kBktSub ? scur[threadIdx.x] : 0u;
+        const unsigned int inc = wave_incl_scan(c);
+        if (lane == 63) wcnt[wave] = inc;
+        __syncthreads();
+        unsigned int excl = inc - c;
+        for (unsigned int w = 0; w < wave; w++) excl += wcnt[w];
+        if (threadIdx.x < kBktSub) { soff[threadIdx.x] = excl; scur[threadIdx.x] = excl; }
+        if (threadIdx.x == 0) soff[n_sub] = n;
+    }
+    __syncthreads();
+    for (unsigned int e = threadIdx.x; e < n; e += kBktThreads) {
+        const unsigned long long key = keys_s[o0 + e];
+        const u32x4* p4 = reinterpret_cast<const u32x4*>(part_s + o0 + e);
+        const u32x4 pa = p4[0], pb = p4[1];
+        const unsigned int dst = o0 + atomicAdd(&scur[sub_of(key)], 1u);
+        kscr[dst] = key;
+        u32x4* o4 = reinterpret_cast<u32x4*>(pscr + dst);
+        o4[0] = pa; o4[1] = pb;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return n_sub;
+}
+
+__global__ __launch_bounds__(kBktThreads) __attribute__((amdgpu_waves_per_eu(4)))      // two workgroups per CU (LDS): <= 128 VGPRs
 void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, const VoxelPartial* __restrict__ part_s,
                                const unsigned int* __restrict__ boff, unsigned int* __restrict__ ctl,
                                int16_t* __restrict__ out, int16_t* __restrict__ tmp_rec, unsigned int* __restrict__ pub, unsigned int gen,
-                               unsigned long long* __restrict__ spl, int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next)
+                               unsigned long long* __restrict__ spl, int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next,
+                               unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr)
 {
     __shared__ unsigned long long tkey[kBktSlots];
     __shared__ unsigned long long tx[kBktSlots], ty[kBktSlots], tz[kBktSlots], tr[kBktSlots], tg[kBktSlots], tbn[kBktSlots];
-    __shared__ unsigned long long dl[kBktSlots];           // the occupied slots as (key << 10 | slot): dense, then in key order
-    __shared__ unsigned long long srt[kBktSlots];
+    __shared__ unsigned long long dl[kBktSlots];           // the occupied slots as (key << 10 | slot): dense, then sorted runs
+    __shared__ unsigned long long srt[kBktSlots];          // ... in key order
     __shared__ unsigned int wcnt[kBktThreads / 64];
     __shared__ unsigned long long smp[64];
+    __shared__ unsigned int soff[kBktSub + 1], scur[kBktSub];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const unsigned int m = ctl[0];
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1175,196 +1259,180 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
         const unsigned int o0 = boff[b], n = boff[b + 1u] - o0;
         unsigned int emitted = 0, base = 0, fed = 0;
         bool have_base = false, published = false;
-        unsigned long long L = 0ull, T = kBktInf;              // this pass takes the keys in [L, T)
-        bool more = n != 0u;
-        const bool big = n > 2u * kBktSlots;                    // far more partials than slots: the bucket will take several passes
-        if (big) {
-            // 64 evenly spaced keys, sorted by the first wavefront: every pass takes an upper bound T from them that lets about
-            // 3/4 of a table's worth of partials in, instead of finding out by overflowing (stale splitters, or a cloud with far
-            // more voxels than 1024 tables hold: the LSD tail's territory, but it must not be a cliff)
-            if (wave == 0) {
-                unsigned long long v = keys_s[o0 + (unsigned int)(((unsigned long long)lane * n) >> 6)];
-#pragma unroll
-                for (unsigned int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-                    for (unsigned int j = k >> 1; j > 0; j >>= 1) {
-                        const bool keep_min = ((lane & j) == 0u) == ((lane & k) == 0u);
-                        const unsigned long long o = __shfl_xor(v, (int)j);
-                        v = ((v < o) == keep_min) ? v : o;
-                    }
-                }
-                smp[lane] = v;
-            }
-            __syncthreads();
-        }
-        while (more) {                                          // workgroup-uniform
-            if (big && T == kBktInf) {
-                const unsigned int want = max(1u, (64u * 768u) / n);       // sample keys per pass
-                unsigned int below = 0;
-                for (unsigned int i = 0; i < 64u; i++) below += smp[i] < L;
-                if (below + want < 64u) { const unsigned long long t = smp[below + want]; if (t > L) T = t; }
-            }
-            // the first batch's loads go out before the table is cleared
-            unsigned long long key_n = 0ull;
-            u32x4 pa_n = u32x4{0u, 0u, 0u, 0u}, pb_n = pa_n;
-            if (threadIdx.x < n) {
-                key_n = keys_s[o0 + threadIdx.x];
-                const u32x4* p4 = reinterpret_cast<const u32x4*>(part_s + o0 + threadIdx.x);
-                pa_n = p4[0]; pb_n = p4[1];
-            }
-            {
-                u32x4* z4;
-                const u32x4 zero{0u, 0u, 0u, 0u}, ones{~0u, ~0u, ~0u, ~0u};
-                z4 = reinterpret_cast<u32x4*>(tkey); z4[threadIdx.x] = ones;                     // kEmptyKey = ~0
-                z4 = reinterpret_cast<u32x4*>(tx);  z4[threadIdx.x] = zero;
-                z4 = reinterpret_cast<u32x4*>(ty);  z4[threadIdx.x] = zero;
-                z4 = reinterpret_cast<u32x4*>(tz);  z4[threadIdx.x] = zero;
-                z4 = reinterpret_cast<u32x4*>(tr);  z4[threadIdx.x] = zero;
-                z4 = reinterpret_cast<u32x4*>(tg);  z4[threadIdx.x] = zero;
-                z4 = reinterpret_cast<u32x4*>(tbn); z4[threadIdx.x] = zero;
-            }
-            __syncthreads();
-            bool restart = false, over_any = false;
-            unsigned int my_in = 0;                              // partials this lane fed into the table in this pass
-            for (unsigned int i0 = 0; i0 < n; i0 += kBktThreads) {
-                const unsigned int e = i0 + threadIdx.x;
-                const bool live = e < n;
-                const unsigned long long key = key_n;
-                const u32x4 pa = pa_n, pb = pb_n;
-                {   // the next batch is requested before this one meets the table
-                    const unsigned int e2 = e + kBktThreads;
-                    if (e2 < n) {
-                        key_n = keys_s[o0 + e2];
-                        const u32x4* p4 = reinterpret_cast<const u32x4*>(part_s + o0 + e2);
-                        pa_n = p4[0]; pb_n = p4[1];
-                    }
-                }
-                const bool over = live && key >= T;
-                const bool in = live && key >= L && !over;
-                int slot = -1;
-                if (in) {
-                    unsigned int h, step;
-                    bkt_hash(key, h, step);
-                    // a key that finds no slot within kBktProbe probes calls the table crowded (at half load that happens to one
-                    // key in 2^24): the pass then restarts below the median. Probing a full table to the end cost 1024 dependent
-                    // LDS round trips per lane.
-                    for (unsigned int t = 0; t < kBktProbe; t++) {
-                        const unsigned long long old = atomicCAS(&tkey[h], kEmptyKey, key);
-                        if (old == kEmptyKey || old == key) { slot = (int)h; break; }
-                        h = (h + step) & (kBktSlots - 1u);
-                    }
-                }
-                over_any |= over;
-                my_in += in ? 1u : 0u;
-                if (__syncthreads_or((in && slot < 0) ? 1 : 0)) { restart = true; break; }     // somebody found the table crowded
-                if (in) {
-                    atomicAdd(&tx[slot], (unsigned long long)(long long)(int)pa.x);
-                    atomicAdd(&ty[slot], (unsigned long long)(long long)(int)pa.y);
-                    atomicAdd(&tz[slot], (unsigned long long)(long long)(int)pa.z);
-                    atomicAdd(&tr[slot], (unsigned long long)pa.w);
-                    atomicAdd(&tg[slot], (unsigned long long)pb.x);
-                    atomicAdd(&tbn[slot], (unsigned long long)pb.y | ((unsigned long long)pb.z << 34));
-                }
-            }
-            // did anybody meet a key at or above T? (also the barrier behind the last batch's adds)
-            const bool beyond = __syncthreads_or(over_any ? 1 : 0) != 0;
-            // the occupied slots, dense: every lane owns slots 2t, 2t + 1
-            const unsigned long long k0 = tkey[2u * threadIdx.x], k1 = tkey[2u * threadIdx.x + 1u];
-            const unsigned int c2 = (k0 != kEmptyKey) + (k1 != kEmptyKey);
-            const unsigned int inc = wave_incl_scan(c2);
-            if (lane == 63) wcnt[wave] = inc;
-            __syncthreads();
-            unsigned int pos = inc - c2, cnt = 0;
-            for (unsigned int w = 0; w < kBktThreads / 64; w++) { const unsigned int t = wcnt[w]; pos += w < wave ? t : 0u; cnt += t; }
-            if (k0 != kEmptyKey) dl[pos++] = (k0 << 10) | (2u * threadIdx.x);
-            if (k1 != kEmptyKey) dl[pos] = (k1 << 10) | (2u * threadIdx.x + 1u);
-            // a bucket that is done in this pass (almost all are) tells the later buckets its voxel count NOW, before it sorts
-            if (!restart && !beyond && !published) {
-                if (threadIdx.x == 0) __hip_atomic_store(pub + b, (gen << 26) | (emitted + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                published = true;
-            }
-            __syncthreads();
-            // Key order without a barrier-per-stage sort: a wavefront sorts its 64 entries in registers (bitonic network over
-            // cross-lane shuffles, 21 steps), parks the sorted run in LDS, and every entry then finds its rank by binary search
-            // in the other runs (6 + 1 LDS reads each, side by side). Entries are distinct words (the slot rides in the low
-            // bits). A lane holds entry t and, in a bucket with more than 512 voxels, entry t + 512 (runs 8..15). (A bitonic
-            // sort of the 1024 slots through LDS was 55 barrier stages and half of this kernel; ranking every entry by counting
-            // all others was worse.)
-            const unsigned int n_runs = cnt > kBktThreads ? 16u : 8u;
-            unsigned long long v0 = threadIdx.x < cnt ? dl[threadIdx.x] : kBktInf;
-            unsigned long long v1 = threadIdx.x + kBktThreads < cnt ? dl[threadIdx.x + kBktThreads] : kBktInf;
-            __syncthreads();                                    // dl is read; it becomes the runs' home
-#pragma unroll
-            for (unsigned int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-                for (unsigned int j = k >> 1; j > 0; j >>= 1) {
-                    const bool keep_min = ((lane & j) == 0u) == ((lane & k) == 0u);
-                    const unsigned long long o0v = __shfl_xor(v0, (int)j);
-                    v0 = ((v0 < o0v) == keep_min) ? v0 : o0v;
-                    if (n_runs == 16u) {                        // workgroup-uniform
-                        const unsigned long long o1v = __shfl_xor(v1, (int)j);
-                        v1 = ((v1 < o1v) == keep_min) ? v1 : o1v;
-                    }
-                }
-            }
-            dl[wave * 64u + lane] = v0;
-            if (n_runs == 16u) dl[kBktThreads + wave * 64u + lane] = v1;
-            __syncthreads();
-            auto rank_of = [&](unsigned long long v, unsigned int my_run) {
-                return n_runs == 16u ? bkt_rank<16>(dl, v, my_run, lane) : bkt_rank<8>(dl, v, my_run, lane);
-            };
-            if (v0 != kBktInf) srt[rank_of(v0, wave)] = v0;
-            if (n_runs == 16u && v1 != kBktInf) srt[rank_of(v1, 8u + wave)] = v1;
-            __syncthreads();
-            if (restart) {
-                // more distinct keys in [L, T) than the table takes gracefully: lower T to the median of those seen so far and
-                // start the pass again. The keys are distinct and cnt >= 2 (a lone key always finds its first slot), so the
-                // median is above the smallest of them and below T.
-                const unsigned long long t_new = srt[cnt / 2u] >> 10;
+
+        // ---- one key range of the bucket: the rn partials at K / P [r0, r0 + rn), in passes over key sub-ranges [L, T) ----------
+        auto run = [&](const unsigned long long* __restrict__ K, const VoxelPartial* __restrict__ P, const unsigned int r0,
+                       const unsigned int rn, const bool whole_bucket) {
+            unsigned long long L = 0ull, T = kBktInf;              // this pass takes the keys in [L, T)
+            bool more = rn != 0u;
+            const bool big = rn > 2u * kBktSlots;                   // far more partials than slots: several passes
+            if (big) {
+                // 64 evenly spaced keys, sorted by the first wavefront: every pass takes an upper bound T from them that lets
+                // about 3/4 of a table's worth of partials in, instead of finding out by overflowing
+                if (wave == 0) smp[lane] = bkt_wave_sort(K[r0 + (unsigned int)(((unsigned long long)lane * rn) >> 6)], lane);
                 __syncthreads();
-                if (t_new >= T || t_new <= L) {                // cannot happen (distinct keys, cnt >= 2): never loop on it
-                    if (threadIdx.x == 0) atomicOr(const_cast<unsigned int*>(ctl) + 3, 1u);
-                    more = false;
+            }
+            while (more) {                                          // workgroup-uniform
+                if (big && T == kBktInf) {
+                    const unsigned int want = max(1u, (64u * 768u) / rn);       // sample keys per pass
+                    unsigned int below = 0;
+                    for (unsigned int i = 0; i < 64u; i++) below += smp[i] < L;
+                    if (below + want < 64u) { const unsigned long long t = smp[below + want]; if (t > L) T = t; }
+                }
+                // the first batch's loads go out before the table is cleared
+                unsigned long long key_n = 0ull;
+                u32x4 pa_n = u32x4{0u, 0u, 0u, 0u}, pb_n = pa_n;
+                if (threadIdx.x < rn) {
+                    key_n = K[r0 + threadIdx.x];
+                    const u32x4* p4 = reinterpret_cast<const u32x4*>(P + r0 + threadIdx.x);
+                    pa_n = p4[0]; pb_n = p4[1];
+                }
+                {
+                    u32x4* z4;
+                    const u32x4 zero{0u, 0u, 0u, 0u}, ones{~0u, ~0u, ~0u, ~0u};
+                    z4 = reinterpret_cast<u32x4*>(tkey); z4[threadIdx.x] = ones;                     // kEmptyKey = ~0
+                    z4 = reinterpret_cast<u32x4*>(tx);  z4[threadIdx.x] = zero;
+                    z4 = reinterpret_cast<u32x4*>(ty);  z4[threadIdx.x] = zero;
+                    z4 = reinterpret_cast<u32x4*>(tz);  z4[threadIdx.x] = zero;
+                    z4 = reinterpret_cast<u32x4*>(tr);  z4[threadIdx.x] = zero;
+                    z4 = reinterpret_cast<u32x4*>(tg);  z4[threadIdx.x] = zero;
+                    z4 = reinterpret_cast<u32x4*>(tbn); z4[threadIdx.x] = zero;
+                }
+                __syncthreads();
+                bool restart = false, over_any = false;
+                unsigned int my_in = 0;                              // partials this lane fed into the table in this pass
+                for (unsigned int i0 = 0; i0 < rn; i0 += kBktThreads) {
+                    const unsigned int e = i0 + threadIdx.x;
+                    const bool live = e < rn;
+                    const unsigned long long key = key_n;
+                    const u32x4 pa = pa_n, pb = pb_n;
+                    {   // the next batch is requested before this one meets the table
+                        const unsigned int e2 = e + kBktThreads;
+                        if (e2 < rn) {
+                            key_n = K[r0 + e2];
+                            const u32x4* p4 = reinterpret_cast<const u32x4*>(P + r0 + e2);
+                            pa_n = p4[0]; pb_n = p4[1];
+                        }
+                    }
+                    const bool over = live && key >= T;
+                    const bool in = live && key >= L && !over;
+                    int slot = -1;
+                    if (in) {
+                        unsigned int h, step;
+                        bkt_hash(key, h, step);
+                        // a key that finds no slot within kBktProbe probes calls the table crowded (at half load that happens to
+                        // one key in 2^24): the pass then restarts below the median. Probing a full table to the end cost 1024
+                        // dependent LDS round trips per lane.
+                        for (unsigned int t = 0; t < kBktProbe; t++) {
+                            const unsigned long long old = atomicCAS(&tkey[h], kEmptyKey, key);
+                            if (old == kEmptyKey || old == key) { slot = (int)h; break; }
+                            h = (h + step) & (kBktSlots - 1u);
+                        }
+                    }
+                    over_any |= over;
+                    my_in += in ? 1u : 0u;
+                    if (__syncthreads_or((in && slot < 0) ? 1 : 0)) { restart = true; break; }     // somebody found the table crowded
+                    if (in) {
+                        atomicAdd(&tx[slot], (unsigned long long)(long long)(int)pa.x);
+                        atomicAdd(&ty[slot], (unsigned long long)(long long)(int)pa.y);
+                        atomicAdd(&tz[slot], (unsigned long long)(long long)(int)pa.z);
+                        atomicAdd(&tr[slot], (unsigned long long)pa.w);
+                        atomicAdd(&tg[slot], (unsigned long long)pb.x);
+                        atomicAdd(&tbn[slot], (unsigned long long)pb.y | ((unsigned long long)pb.z << 34));
+                    }
+                }
+                // did anybody meet a key at or above T? (also the barrier behind the last batch's adds)
+                const bool beyond = __syncthreads_or(over_any ? 1 : 0) != 0;
+                // the occupied slots, dense: every lane owns slots 2t, 2t + 1
+                const unsigned long long k0 = tkey[2u * threadIdx.x], k1 = tkey[2u * threadIdx.x + 1u];
+                const unsigned int c2 = (k0 != kEmptyKey) + (k1 != kEmptyKey);
+                const unsigned int inc = wave_incl_scan(c2);
+                if (lane == 63) wcnt[wave] = inc;
+                __syncthreads();
+                unsigned int pos = inc - c2, cnt = 0;
+                for (unsigned int w = 0; w < kBktThreads / 64; w++) { const unsigned int t = wcnt[w]; pos += w < wave ? t : 0u; cnt += t; }
+                if (k0 != kEmptyKey) dl[pos++] = (k0 << 10) | (2u * threadIdx.x);
+                if (k1 != kEmptyKey) dl[pos] = (k1 << 10) | (2u * threadIdx.x + 1u);
+                // A bucket that is done in ONE pass (almost all are) writes its voxels straight to their final place, behind those of
+                // all earlier buckets; it tells the later buckets its voxel count NOW, before it sorts. A bucket that takes several
+                // passes parks its records at its own offset and moves them when it is through — if it waited for the earlier
+                // buckets between its passes, the crowded buckets of a call would run one after the other.
+                const bool direct = whole_bucket && !restart && !beyond && emitted == 0u;
+                if (direct) {
+                    if (threadIdx.x == 0) __hip_atomic_store(pub + b, (gen << 26) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    published = true;
+                }
+                __syncthreads();
+                // Key order without a barrier-per-stage sort: a wavefront sorts its 64 entries in registers, parks the sorted run
+                // in LDS, and every entry then finds its rank by binary search in the other runs (6 + 1 LDS reads each, side by
+                // side). Entries are distinct words (the slot rides in the low bits). A lane holds entry t and, in a pass with
+                // more than 512 voxels, entry t + 512 (runs 8..15). (A bitonic sort of the 1024 slots through LDS was 55 barrier
+                // stages and half of this kernel; ranking every entry by counting all others was worse.)
+                const unsigned int n_runs = cnt > kBktThreads ? 16u : 8u;
+                unsigned long long v0 = threadIdx.x < cnt ? dl[threadIdx.x] : kBktInf;
+                unsigned long long v1 = threadIdx.x + kBktThreads < cnt ? dl[threadIdx.x + kBktThreads] : kBktInf;
+                __syncthreads();                                    // dl is read; it becomes the runs' home
+                v0 = bkt_wave_sort(v0, lane);
+                if (n_runs == 16u) v1 = bkt_wave_sort(v1, lane);    // workgroup-uniform
+                dl[wave * 64u + lane] = v0;
+                if (n_runs == 16u) dl[kBktThreads + wave * 64u + lane] = v1;
+                __syncthreads();
+                if (v0 != kBktInf) srt[n_runs == 16u ? bkt_rank<16>(dl, v0, wave, lane) : bkt_rank<8>(dl, v0, wave, lane)] = v0;
+                if (n_runs == 16u && v1 != kBktInf) srt[bkt_rank<16>(dl, v1, 8u + wave, lane)] = v1;
+                __syncthreads();
+                if (restart) {
+                    // more distinct keys in [L, T) than the table takes gracefully: lower T to the median of those seen so far and
+                    // start the pass again. The keys are distinct and cnt >= 2 (a lone key always finds its first slot), so the
+                    // median is above the smallest of them and below T.
+                    const unsigned long long t_new = srt[cnt / 2u] >> 10;
+                    __syncthreads();
+                    if (t_new >= T || t_new <= L) {                // cannot happen (distinct keys, cnt >= 2): never loop on it
+                        if (threadIdx.x == 0) atomicOr(ctl + 3, 1u);
+                        more = false;
+                        continue;
+                    }
+                    T = t_new;
                     continue;
                 }
-                T = t_new;
-                continue;
-            }
-            // A bucket that is done in ONE pass (almost all are) writes its voxels straight to their final place: behind those of
-            // all earlier buckets (their published counts; see bkt_base). A bucket that takes several passes parks its records
-            // at its own offset and moves them when it is through — if it waited for the earlier buckets between its passes,
-            // the crowded buckets of a call would run one after the other.
-            const bool direct = emitted == 0u && !beyond;
-            if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
-            int16_t* const rec = direct ? out : tmp_rec;
-            const unsigned int first = direct ? base : o0 + emitted;
-            for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
-                const unsigned int slot = (unsigned int)(srt[i] & (kBktSlots - 1u));
-                const unsigned long long bn = tbn[slot];
-                write_voxel(rec, first + i, (long long)tx[slot], (long long)ty[slot], (long long)tz[slot], tr[slot], tg[slot],
-                            bn & ((1ull << 34) - 1ull), (unsigned int)(bn >> 34));
-            }
-            // Next call's splitters: the quantile positions j * m / kBkt that fall into THIS PASS's share of the partials — the
-            // passes of a bucket are key ranges in ascending order, so the pass holds the partials of sorted rank
-            // [o0 + fed, o0 + fed + n_in) — read off the pass's sorted keys. Ascending within the pass, across the passes and
-            // across the buckets. (Taking all of a bucket's positions from its LAST pass squeezed its splitters into the top of
-            // its key range: the bucket grew from call to call.)
-            const unsigned int n_in = bkt_block_sum(my_in, wcnt);
-            if (m != 0u && n_in != 0u) {
-                for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
-                    const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
-                    if (q >= o0 + fed && q < o0 + fed + n_in) {
-                        const unsigned int i = (unsigned int)(((unsigned long long)(q - o0 - fed) * cnt) / n_in);
-                        spl[j - 1u] = srt[i < cnt ? i : cnt - 1u] >> 10;
+                if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
+                int16_t* const rec = direct ? out : tmp_rec;
+                const unsigned int first = direct ? base : o0 + emitted;
+                for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
+                    const unsigned int slot = (unsigned int)(srt[i] & (kBktSlots - 1u));
+                    const unsigned long long bn = tbn[slot];
+                    write_voxel(rec, first + i, (long long)tx[slot], (long long)ty[slot], (long long)tz[slot], tr[slot], tg[slot],
+                                bn & ((1ull << 34) - 1ull), (unsigned int)(bn >> 34));
+                }
+                // Next call's splitters: the quantile positions j * m / kBkt that fall into THIS PASS's share of the partials — the
+                // passes of a bucket (and the key ranges of a split bucket) come in ascending key order, so the pass holds the
+                // partials of sorted rank [o0 + fed, o0 + fed + n_in) — read off the pass's sorted keys. Ascending within the pass,
+                // across the passes and across the buckets. (Taking all of a bucket's positions from its LAST pass squeezed its
+                // splitters into the top of its key range: the bucket grew from call to call.)
+                const unsigned int n_in = bkt_block_sum(my_in, wcnt);
+                if (m != 0u && n_in != 0u) {
+                    for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
+                        const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
+                        if (q >= o0 + fed && q < o0 + fed + n_in) {
+                            const unsigned int i = (unsigned int)(((unsigned long long)(q - o0 - fed) * cnt) / n_in);
+                            spl[j - 1u] = srt[i < cnt ? i : cnt - 1u] >> 10;
+                        }
                     }
                 }
+                fed += n_in;
+                emitted += cnt;
+                // keys at or above T were left out: they are the next pass
+                if (beyond) { L = T; T = kBktInf; } else more = false;
+                __syncthreads();
             }
-            fed += n_in;
-            emitted += cnt;
-            // keys at or above T were left out: they are the next pass
-            if (beyond) { L = T; T = kBktInf; } else more = false;
-            if (more) __syncthreads();
+        };
+
+        const bool giant = n > kBktGiant;
+        const unsigned int n_sub = giant ? bkt_presplit(keys_s, part_s, kscr, pscr, o0, n, dl, srt, scur, soff, wcnt) : 1u;
+        for (unsigned int s = 0; s < n_sub; s++) {                 // (soff lives in LDS of its own: run() reuses dl / srt)
+            const unsigned int s0 = giant ? soff[s] : 0u, s1 = giant ? soff[s + 1u] : n;
+            run(giant ? kscr : keys_s, giant ? pscr : part_s, o0 + s0, s1 - s0, !giant);
         }
+
         if (!published && threadIdx.x == 0)                    // empty buckets, and buckets that took several passes
             __hip_atomic_store(pub + b, (gen << 26) | emitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!have_base && emitted != 0u) {                     // several passes: the parked records to their final place
@@ -1407,6 +1475,7 @@ struct Workspace {
     unsigned long long* keys_s;
     unsigned short* bucket_of;
     VoxelPartial* part_s;
+    VoxelPartial* part_ws;              // the workspace's own partial array (w.part may be redirected to a caller's)
     int16_t* tmp_rec;
     size_t bytes;
 };
@@ -1439,6 +1508,7 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.btable = (unsigned int*)take(((n + kBktChunk - 1) / kBktChunk + 1) * (size_t)kBkt * 4);
     w.part_s = (VoxelPartial*)take(n * sizeof(VoxelPartial));
     w.tmp_rec = (int16_t*)take(n * (size_t)PCS_POINT_BYTES + 16);      // records of buckets that take several passes
+    w.part_ws = w.part;
     w.keys_s = w.keys_b;
     w.bucket_of = (unsigned short*)w.idx_a;
     w.bytes = (size_t)(p - base);
@@ -1563,7 +1633,7 @@ hipError_t bucket_tail(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_
     hipLaunchKernelGGL(pcs_vox_bkt_scatter_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.part, w.bucket_of, w.ctl, pl.raw,
                        w.btable, w.btotal, w.keys_s, w.part_s, w.boff);
     hipLaunchKernelGGL(pcs_vox_bkt_reduce_kernel, dim3(kBkt), dim3(kBktThreads), 0, st, w.keys_s, w.part_s, w.boff, w.ctl, d_out,
-                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next);
+                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next, w.keys_a, w.part_ws);
     return hipGetLastError();
 }
 
