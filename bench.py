@@ -1550,13 +1550,18 @@ def main():
                 # software-pipelined loop (pcs_submit_frames / pcs_collect_frames): upload of k+1 overlaps download of k
                 po2 = ctx.host_array((2 + payload_shorts,), np.int16)
 
+                sub_host = []
+
                 def time_pipe(reps=8):
                     ta, tb = ctx.submit_frames(pd, pc), ctx.submit_frames(pd, pc)     # warm both slots
                     ctx.collect_frames(ta, po); ctx.collect_frames(tb, po2)
                     t0p = time.perf_counter()
                     t_prev = ctx.submit_frames(pd, pc)
                     for k in range(1, reps + 1):
+                        ts = time.perf_counter()
                         t_next = ctx.submit_frames(pd, pc) if k < reps else None
+                        if t_next is not None:
+                            sub_host.append(time.perf_counter() - ts)
                         ctx.collect_frames(t_prev, po if k & 1 else po2)
                         t_prev = t_next
                     return (time.perf_counter() - t0p) / reps
@@ -1583,6 +1588,15 @@ def main():
                 out["host_api"] = {"ms_per_step": round(th * 1e3, 3), "value": round(set_points / th / 1e6, 1),
                                    "pinned_ms_per_step": round(tp * 1e3, 3), "pinned_value": round(set_points / tp / 1e6, 1),
                                    "pipelined_ms_per_step": round(tpipe * 1e3, 3), "pipelined_value": round(set_points / tpipe / 1e6, 1),
+                                   "breakdown": {"d2h_alone_ms": round(t_dn * 1e3, 3), "h2d_alone_ms": round(t_up * 1e3, 3),
+                                                 "submit_host_enqueue_ms": round(float(np.median(sub_host)) * 1e3, 3) if sub_host else None,
+                                                 "rest_ms": round((tpipe - t_dn - (float(np.median(sub_host)) if sub_host else 0.0)) * 1e3, 3),
+                                                 "note": "a pipelined step = the download of frame-set k (the longer direction; the upload of k+1 "
+                                                         "runs beside it) + the host time of submit(k+1) — 2 x S hipMemcpyAsync + the launch — which "
+                                                         "passes before collect(k) can enqueue that download + rest (the link's duplex penalty, "
+                                                         "measured 1.42 vs 1.30 ms in tools/lab, event and synchronisation latency). Enqueueing the "
+                                                         "download at SUBMIT time (destination named early) was built and measured in round 5: "
+                                                         "2.02 instead of 1.63 ms — copies issued in that order run one after the other"},
                                    "h2d_ms": round(t_up * 1e3, 3), "h2d_GBps": round(up_bytes / t_up / 1e9, 1),
                                    "d2h_ms": round(t_dn * 1e3, 3), "d2h_GBps": round(pay.nbytes / t_dn / 1e9, 1),
                                    "unit": "Mpoints/s", "note": "pcs_process_frames, synchronous, per frame-set. ms_per_step: long-lived pageable "

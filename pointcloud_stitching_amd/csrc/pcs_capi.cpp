@@ -385,6 +385,21 @@ int ensure_rasters(pcs_ctx* c)
     return alloc_raster_slab(c, c->s_slab, c->s_depth, c->s_color);
 }
 
+// The voxel workspace. Growing it means: wait for the stream (the old one may be in use), free, allocate — a device-wide stall.
+// A caller whose sizes creep upwards (the node's root reduces a different number of partials every frame-set) must not pay that
+// at every new maximum: a workspace that has to grow takes a quarter more than asked.
+int ensure_voxel_ws(pcs_ctx* c, size_t need)
+{
+    if (need <= c->s_voxel_ws_cap && c->s_voxel_ws) return PCS_OK;
+    if (c->s_voxel_ws) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        need += need / 4;
+    }
+    c->vox_state.clean = false;                                                   // (a new one may land on the same address)
+    c->vox_state.spl_leaf = 0;
+    return ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
@@ -1531,11 +1546,7 @@ static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_po
                     out_shorts, (size_t)n_points * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
     const size_t need = voxel_workspace_bytes((uint32_t)n_points);
-    if (need > c->s_voxel_ws_cap) {                                               // the old workspace may be in use
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->vox_state.clean = false;                                               // (a new one may land on the same address)
-    }
-    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, d_n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out,
                                 d_out_points, c->stream));
@@ -1590,11 +1601,7 @@ try {
         return voxel_grid_device_impl(c, c->s_payload, (int)cap, c->d_counts + S, leaf_mm, d_out, out_shorts, d_out_points);
     }
     const size_t need = voxel_workspace_bytes((uint32_t)cap);
-    if (need > c->s_voxel_ws_cap) {                                               // the old workspace may be in use
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->vox_state.clean = false;                                               // (a new one may land on the same address)
-    }
-    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev{};
     if (c->kernel_timing) {
@@ -1706,11 +1713,7 @@ try {
                     out_shorts, (size_t)n_partials * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
     const size_t need = voxel_workspace_bytes((uint32_t)n_partials);
-    if (need > c->s_voxel_ws_cap) {                                               // the old workspace may be in use
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->vox_state.clean = false;                                               // (a new one may land on the same address)
-    }
-    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,
                                          d_n_partials, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
