@@ -16,7 +16,6 @@ export TMPDIR=/tmp
 BENCH="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-host-api --no-extra-legs"
 declare -A RUNS
 RUNS[dense]="$BENCH"
-RUNS[general_rotation]="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-host-api --no-cache-leg"
 RUNS[drop_invalid]="$BENCH --mode drop_invalid"
 RUNS[drop_invalid_single]="env PCS_COMPACT_PATH=single $BENCH --mode drop_invalid"
 RUNS[cutoff]="$BENCH --mode cutoff"
@@ -29,14 +28,20 @@ RUNS[config5]="python $PWD/bench.py --workload config5 --steps 60 --warmup 5 --n
 # the one-process node route (libpcs_node) on this box's one GPU: 8 virtual peers, the exchange = RCCL self send/recv pairs
 RUNS[node_stitch]="python $PWD/bench.py --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps $STEPS --warmup 20"
 RUNS[node_config5]="python $PWD/bench.py --workload config5 --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps 60 --warmup 5"
-ORDER="dense general_rotation drop_invalid drop_invalid_single cutoff pack pack_batch batch batch_drop_invalid voxel config5 node_stitch node_config5"
+# BASELINE configs[4] in ONE call from the rasters (pcs_process_frames_voxel_device, 50 mm): front end + the bucket tail; and with the LSD tail
+RUNS[voxel_one_call]="python $PWD/tools/voxel_probe.py 50 80"
+RUNS[voxel_one_call_lsd]="env PCS_VOXEL_TAIL=lsd python $PWD/tools/voxel_probe.py 50 80"
+# every leg of the default line (incl. centre_transform, config5_one_gpu, color_1080p): one row per kernel of the library
+RUNS[all_legs]="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-host-api"
+ORDER=${PROFILE_RUNS:-"dense all_legs drop_invalid cutoff pack pack_batch batch batch_drop_invalid voxel voxel_one_call voxel_one_call_lsd config5 node_stitch node_config5"}
+PMC_ORDER=${PROFILE_PMC_RUNS:-"dense all_legs voxel_one_call voxel_one_call_lsd config5"}
 cd /tmp
 for R in $ORDER; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -- ${RUNS[$R]} > $OUT/stats_$R.log 2>&1
   echo "stats $R rc=$?"
 done
 # PMC passes (their own runs, --pmc + --kernel-trace only): HBM traffic for every family, the instruction mix for the headline
-for R in dense drop_invalid pack pack_batch batch batch_drop_invalid voxel config5; do
+for R in $PMC_ORDER; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${R}_$C -- ${RUNS[$R]} > $OUT/pmc_${R}_$C.log 2>&1
     echo "pmc $R $C rc=$?"
@@ -44,7 +49,7 @@ for R in dense drop_invalid pack pack_batch batch batch_drop_invalid voxel confi
 done
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  for R in dense voxel; do      # the headline kernel (HBM-bound) and the voxel pre-aggregation (VALU-bound)
+  for R in dense voxel_one_call; do      # the headline kernel (HBM-bound) and the voxel pipeline (VALU-bound front end)
     timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${R}_$N -- ${RUNS[$R]} > $OUT/pmc_${R}_$N.log 2>&1
     echo "pmc $R $N rc=$?"
   done
