@@ -1408,7 +1408,8 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 // partials of sorted rank [o0 + fed, o0 + fed + n_in) — read off the pass's sorted keys. Ascending within the pass,
                 // across the passes and across the buckets. (Taking all of a bucket's positions from its LAST pass squeezed its
                 // splitters into the top of its key range: the bucket grew from call to call.)
-                const unsigned int n_in = bkt_block_sum(my_in, wcnt);
+                // (a pass that took the whole range — the common case — fed all of it: no need to count)
+                const unsigned int n_in = (L == 0ull && !beyond) ? rn : bkt_block_sum(my_in, wcnt);
                 if (m != 0u && n_in != 0u) {
                     for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
                         const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
