@@ -1347,15 +1347,41 @@ def main():
                 torch.cuda.synchronize(dev)
                 ms_o5 = timed(onecall5, 30, ctx5)
                 nvox5_one = int(nv5.item())
+                # the voxel cloud of the timed loop against the committed oracle digest (this IS the digest's workload)
+                import hashlib
+                dig5 = hashlib.sha256(vox5[:nvox5_one * POINT_SHORTS].cpu().numpy().tobytes()).hexdigest()
+                gold5 = json.load(open(os.path.join(ROOT, "tests", "golden", "config5_digests.json")))["voxel"].get(str(LEAF))
+                if gold5 and not (gold5["voxels"] == nvox5_one and gold5["sha256"] == dig5):
+                    raise RuntimeError("config5 one-call voxel cloud differs from the oracle digest")
+                # the same call with the LSD radix sort + segmented mean instead of the bucket tail (PCS_VOXEL_TAIL is read per call)
+                tail_default = os.environ.get("PCS_VOXEL_TAIL")
+                os.environ["PCS_VOXEL_TAIL"] = "lsd"
+                try:
+                    for _ in range(3):
+                        onecall5()
+                    torch.cuda.synchronize(dev)
+                    ms_o5_lsd = timed(onecall5, 30, ctx5)
+                finally:
+                    if tail_default is None:
+                        del os.environ["PCS_VOXEL_TAIL"]
+                    else:
+                        os.environ["PCS_VOXEL_TAIL"] = tail_default
                 out["config5_one_gpu"] = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
                                           "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
                                           "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
                                           "pipeline_ms_per_frame_set": round(ms_b5, 4),
                                           "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
                                           "one_call": {"ms_per_frame_set": round(ms_o5, 4), "value": round(S5 * n5 / ms_o5 / 1e3, 1),
-                                                       "voxels": nvox5_one,
+                                                       "voxels": nvox5_one, "oracle_digest_ok": bool(gold5 is not None),
+                                                       "kernels_per_call": 5 if tail_default in (None, "bucket") else 13,
+                                                       "lsd_tail_ms_per_frame_set": round(ms_o5_lsd, 4),
+                                                       "algorithmic_bytes": int(5 * S5 * n5 + 10 * nvox5_one),
+                                                       "frac": round((5 * S5 * n5 + 10 * nvox5_one) / (ms_o5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                        "note": "pcs_process_frames_voxel_device: the same voxel cloud straight from the "
-                                                               "rasters; the stitched cloud is never written to HBM"},
+                                                               "rasters; the stitched cloud is never written to HBM. Pre-aggregation + the bucket "
+                                                               "tail (partition histogram, column scan, scatter, per-bucket reduce: 5 kernels per "
+                                                               "call); lsd_tail_*: the round-4 tail (13 kernels) forced for the same call; the "
+                                                               "timed loop's cloud is hashed against the committed oracle digest"},
                                           "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                           "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
                                                   "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}

@@ -304,6 +304,20 @@ int pcs_voxel_grid_device(pcs_ctx* ctx, const int16_t* d_payload, int n_points, 
  * voxel grid — then is two asynchronous calls with no host round trip between them.                                */
 int pcs_voxel_grid_device_counted(pcs_ctx* ctx, const int16_t* d_payload, const int32_t* d_n_points, int max_points,
                                   int leaf_mm, int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
+/* Which tail the voxel calls of this context take behind the pre-aggregation. Both give the same bytes for every input:
+ *   PCS_VOXEL_TAIL_BUCKET  one partition of the partials into <= 1024 key ranges + one workgroup per range with an LDS table
+ *                          (4 launches; built for the ~1 M partials of BASELINE configs[4] at leaves of a few centimetres and up);
+ *   PCS_VOXEL_TAIL_LSD     LSD radix sort of (key, partial) + segmented mean (12 launches; the better tool for many millions of
+ *                          partials, and the lighter neighbour when the tail runs BESIDE another frame-set's pre-aggregation on the
+ *                          same GPU: libpcs_node picks it for its root when one GPU holds every camera);
+ *   PCS_VOXEL_TAIL_AUTO    (default) by the leaf: bucket from 40 mm.
+ * The environment variable PCS_VOXEL_TAIL=bucket|lsd, read at every call, overrides both (the test-suite runs every voxel
+ * test under each).                                                                                                      */
+#define PCS_VOXEL_TAIL_AUTO   0
+#define PCS_VOXEL_TAIL_BUCKET 1
+#define PCS_VOXEL_TAIL_LSD    2
+int pcs_set_voxel_tail(pcs_ctx* ctx, int tail);
+
 /* Rasters -> voxel grid in one asynchronous call, WITHOUT materialising the stitched cloud: the result (bytes and
  * *d_out_points) is exactly pcs_voxel_grid_device applied to the payload pcs_process_frames_device would write for the
  * same rasters under the context's flags (CUTOFF / DROP_INVALID honoured; the voxel sums are integers, so the order of

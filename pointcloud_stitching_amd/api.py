@@ -289,6 +289,10 @@ class PcsContext:
                                                             per, C.byref(total)))
         return [int(per[i]) for i in range(n)], total.value
 
+    def set_voxel_tail(self, tail: int) -> None:
+        """0 = by the leaf (default), 1 = bucket tail, 2 = LSD sort + segmented mean; see pcs_set_voxel_tail."""
+        self._check(self._lib.pcs_set_voxel_tail(self._h, int(tail)))
+
     # -- voxel grid (defined by this build; see include/pcs_hip.h) --------------------------------
     def voxel_grid(self, payload: np.ndarray, leaf_mm: int) -> np.ndarray:
         """Voxel-grid downsample of packed records (int16 [n,5]) -> int16 [n_voxels,5]."""

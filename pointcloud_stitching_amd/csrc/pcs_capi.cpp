@@ -1553,6 +1553,15 @@ static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_po
     return PCS_OK;
 }
 
+int pcs_set_voxel_tail(pcs_ctx* c, int tail)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (tail != PCS_VOXEL_TAIL_AUTO && tail != PCS_VOXEL_TAIL_BUCKET && tail != PCS_VOXEL_TAIL_LSD)
+        return fail(c, PCS_ERR_INVALID_ARG, "unknown voxel tail %d", tail);
+    c->vox_state.tail_pref = tail;
+    return PCS_OK;
+}
+
 int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, int leaf_mm, int16_t* d_out,
                           size_t out_shorts, int32_t* d_out_points)
 {

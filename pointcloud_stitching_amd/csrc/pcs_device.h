@@ -171,6 +171,7 @@ struct VoxelWsState {
     bool        clean = false;
     int         spl_leaf = 0;       // bucket tail: the leaf the workspace's splitters were made for (0: none)
     uint32_t    bkt_calls = 0;      // bucket-tail calls enqueued on this workspace (tags their published counts)
+    int         tail_pref = 0;      // pcs_set_voxel_tail: 0 by the leaf, 1 bucket, 2 LSD (the environment overrides)
 };
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
                              size_t ws_bytes, VoxelWsState* ws, int16_t* d_out, int32_t* d_out_points, hipStream_t st);

@@ -248,6 +248,11 @@ int ensure_voxel_buffers(pcs_node* n)
         // happened to share the kernel stream's queue: 0.248 ms per frame-set instead of 0.195. Streams are therefore tried until
         // one is SEEN to run beside the root's kernel stream (a no-op launched behind a 300 us spin on the kernel stream must
         // finish first); stream priorities proved erratic (0.20 - 0.33 ms depending on the queue count) and are not used.
+        // one GPU holds every camera: the tail of frame-set k runs beside the WHOLE pre-aggregation of k+1, and the lighter
+        // neighbour wins there (16 x 1080p, 50 mm, two in flight: 0.196 ms per frame-set with the LSD tail, 0.213 with the bucket
+        // tail, whose 72 KiB workgroups take table slots from the pre-aggregation). With the cameras spread over GPUs the root's own
+        // pre-aggregation is short and the tail is the critical path: the default (bucket: 0.088 vs 0.113 ms root phase at 8 peers).
+        if (n->gpus.size() == 1 && n->n_peers == 1) (void)pcs_set_voxel_tail(n->reduce_ctx, PCS_VOXEL_TAIL_LSD);
         int rc2 = pick_concurrent_stream(n, kstream(root), &n->reduce_stream);
         if (rc2 != PCS_OK) return rc2;
         if (n->reduce_stream) PCSCHK(n, n->reduce_ctx, pcs_set_stream(n->reduce_ctx, n->reduce_stream));

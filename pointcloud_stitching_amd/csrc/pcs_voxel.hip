@@ -1539,12 +1539,14 @@ struct Plan {
 // ~1000 partials. With many more partials its buckets outgrow the LDS table and are worked off in several passes — the LSD
 // sort is the better tool there. The host does not know the number of partials (nothing is read back), so the choice goes by
 // the leaf: PCS_VOXEL_TAIL=bucket / lsd overrides (read at every call: the tests run both).
-bool choose_bucket_tail(int leaf_mm)
+bool choose_bucket_tail(int leaf_mm, int pref)
 {
     if (const char* v = getenv("PCS_VOXEL_TAIL")) {
         if (v[0] == 'b') return true;
         if (v[0] == 'l') return false;
     }
+    if (pref == 1) return true;
+    if (pref == 2) return false;
     return leaf_mm >= 40;      // 16 x 1080p synthetic scene, ms per call bucket / LSD: 32 mm 0.333 / 0.292, 40 mm 0.253 / 0.259, 50 mm 0.197 / 0.226
 }
 
@@ -1611,7 +1613,7 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     static const int track_env = [] { const char* v = getenv("PCS_VOXEL_TRACK"); return v ? atoi(v) : -1; }();
     pl.track_bits = 3u * pl.bits > 3u * kRadixBits;
     if (track_env >= 0) pl.track_bits = track_env != 0;
-    pl.bucket = choose_bucket_tail(leaf_mm);
+    pl.bucket = choose_bucket_tail(leaf_mm, ws.tail_pref);
     if (pl.bucket) {
         pl.idx_bits = 0;              // raw keys, as in the exchange format: the bucket tail moves the partials themselves
         pl.track_bits = false;

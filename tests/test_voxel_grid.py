@@ -561,3 +561,21 @@ def test_bucket_tail_is_the_default_at_config5_leaf_and_counts_its_launches(orac
                 monkeypatch.setenv("PCS_VOXEL_TAIL", tail)
             got = _rasters_to_voxels(ctx, dd, dc, 50, n_max)
             assert got.shape == want.shape and (got == want).all(), tail
+
+
+@pytest.mark.gpu
+def test_voxel_tail_preference_per_context(oracle, monkeypatch):
+    """pcs_set_voxel_tail: a context's standing choice of tail (libpcs_node sets LSD for a root that holds every camera);
+    PCS_VOXEL_TAIL still overrides. Same bytes whatever is chosen; an unknown value is refused."""
+    monkeypatch.delenv("PCS_VOXEL_TAIL", raising=False)
+    p = random_payload(120000, 5, 2500)
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        for tail, leaf in ((1, 20), (2, 60), (0, 60), (1, 60), (2, 20)):
+            ctx.set_voxel_tail(tail)
+            got = ctx.voxel_grid(p, leaf)
+            want = oracle.voxel_grid(p, leaf)
+            assert got.shape == want.shape and (got == want).all(), (tail, leaf)
+        with pytest.raises(PcsError) as e:
+            ctx.set_voxel_tail(7)
+        assert e.value.status == -1
