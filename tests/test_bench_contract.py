@@ -237,3 +237,24 @@ def test_route_choice_never_depends_on_how_the_script_was_launched():
     assert b.choose_route("auto", 2, "0,0", "nccl", 2, {"HIP_VISIBLE_DEVICES": "0"}, one) == "node"
     assert b.choose_route("auto", 2, "", "gloo", 1, {}, one) == "ranks"
     assert b.choose_route("ranks", 8, "", "nccl", 1, {}, many) == "ranks" and b.choose_route("node", 1, "", "nccl", 1, {}, one) == "node"
+
+
+def test_readme_quotes_only_the_recorded_bench_line():
+    """README.md's results table is generated from ONE recorded `python bench.py` line (profiles/r05_bench.json) by
+    tools/readme_results.py; regenerating it must give the text README holds, and no other 'Mpoints/s' figure may stand in
+    README outside that block (round 4 had four different GPU/CPU ratios in four documents)."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("readme_results", os.path.join(ROOT, "tools", "readme_results.py"))
+    rr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rr)
+    src = os.path.join("profiles", "r05_bench.json")
+    want = rr.table(rr.load(os.path.join(ROOT, src)), src)
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    a, b = readme.index(rr.BEGIN), readme.index(rr.END) + len(rr.END)
+    assert readme[a:b] == want, "README's results block is stale: python tools/readme_results.py --write"
+    outside = readme[:a] + readme[b:]
+    assert not re.search(r"\d\s*k?\s*Mpoints/s", outside), "a throughput figure outside the generated block"
+    assert not re.search(r"GPU\s*=\s*\d+", outside)
+    d = rr.load(os.path.join(ROOT, src))
+    assert d["n_gpus"] == 1 and "configs[2]" in d["config"]["workload"] and "leg_errors" not in d

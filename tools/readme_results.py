@@ -37,7 +37,7 @@ def table(d, src):
          pct(d["general_rotation"]["frac"])),
         ("the geometry a D400 rig records (colour 1920×1080, rotation, colour distortion)", us(d["color_1080p"]["ms_per_step"]),
          f"{d['color_1080p']['value'] / 1e3:.0f} k Mpoints/s", f"{pct(d['color_1080p']['frac'])} (by the colour lines it must touch: {pct(d['color_1080p']['frac_touched_bytes'])})"),
-        ("a2 twin from resident `rs2::points` arrays, 8 cameras per launch / one launch each (33 B/point)",
+        ("a2 twin from resident `rs2::points` arrays, 8 cameras: one launch / one launch per camera (33 B/point)",
          f"{us(pk['batched_ms_per_frame_set'])} / {us(pk['per_stream_launches_ms_per_frame_set'])}", "", f"{pct(pk['batched_frac'])} / {pct(pk['per_stream_launches_frac'])}"),
         ("invalid-depth compaction, order-preserving (count + scan + emit) / per-tile counts handed in / 4 frame-sets per call ((5 + 10ρ) B/point)",
          f"{us(comp['ms_per_step'])} / {us(comp['caller_counts']['ms_per_step'])} / {us(comp['batched']['ms_per_frame_set'])}", "",
