@@ -293,7 +293,9 @@ int pcs_transform_payloads_device(pcs_ctx* ctx, int n_cams, const pcs_payload_de
  * NOT in the reference (it includes pcl/filters/voxel_grid.h but never instantiates it). Defined in the
  * payload's integer millimetre domain: voxel = floor(coord / leaf_mm) per axis; one output point per occupied
  * voxel = integer mean of x,y,z (truncating) and of R,G,B; output sorted by (z,y,x) voxel, x fastest.
- * The output needs room for n_points points in the worst case. *d_out_points / *out_points = voxels written.
+ * The output needs room for n_points points in the worst case. *d_out_points / *out_points = voxels written (the device forms
+ * write -1 there if the bucket tail gave up waiting for one of its own workgroups after ~0.5 s — a stalled device; the host form
+ * turns that into PCS_ERR_HIP. It has not been observed; the wait is bounded so that a launch can end wrong but never hang).
  * The device form is fully asynchronous on the context stream (pre-aggregation, radix sort and segmented mean are
  * hand-written kernels that read their sizes from device memory; no host round trip in the middle).            */
 int pcs_voxel_grid_device(pcs_ctx* ctx, const int16_t* d_payload, int n_points, int leaf_mm,
