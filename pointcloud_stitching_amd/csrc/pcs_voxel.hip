@@ -1093,31 +1093,21 @@ __device__ __forceinline__ void bkt_hash(unsigned long long key, unsigned int& f
 // generation: nobody clears the words) as soon as they know them. Waiting on LOWER-numbered workgroups only is safe on hardware
 // that starts workgroups in order (what rocPRIM's look-back scan relies on too); the wait is bounded all the same: after ~0.5 s
 // the workgroup gives up, flags the call (ctl[3] -> *out_points = -1) and carries on, so a launch can end wrong but never hang.
-__device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsigned int b, unsigned int gen, unsigned int* ctl, unsigned int* wsum,
-                                                 bool have_early = false, unsigned int early0 = 0u, unsigned int early1 = 0u)
+__device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsigned int b, unsigned int gen, unsigned int* ctl, unsigned int* wsum)
 {
-    static_assert(kBkt <= 2u * kBktThreads, "a lane reads at most two published counts");
-    // both words of a lane are requested together (or were requested earlier: right after this bucket published its own count,
-    // so that the answers travel while it sorts); a word whose tag is not this call's yet is polled
-    const unsigned int t0i = threadIdx.x, t1i = threadIdx.x + kBktThreads;
-    unsigned int v[2];
-    v[0] = t0i < b ? (have_early ? early0 : __hip_atomic_load(pub + t0i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : (gen << 26);
-    v[1] = t1i < b ? (have_early ? early1 : __hip_atomic_load(pub + t1i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : (gen << 26);
     unsigned int sum = 0;
     bool gave_up = false;
-#pragma unroll
-    for (unsigned int q = 0; q < 2u; q++) {
-        const unsigned int t = q ? t1i : t0i;
-        unsigned int w = v[q];
-        if ((w >> 26) != gen) {
+    for (unsigned int t = threadIdx.x; t < b; t += kBktThreads) {
+        unsigned int v = __hip_atomic_load(pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 26) != gen) {
             const long long t0 = wall_clock64();                           // 100 MHz
             do {
-                __builtin_amdgcn_s_sleep(2);
-                w = __hip_atomic_load(pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((w >> 26) != gen && wall_clock64() - t0 < 50000000ll);
-            if ((w >> 26) != gen) { gave_up = true; w = 0u; }
+                __builtin_amdgcn_s_sleep(4);
+                v = __hip_atomic_load(pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((v >> 26) != gen && wall_clock64() - t0 < 50000000ll);
+            if ((v >> 26) != gen) { gave_up = true; v = 0u; }
         }
-        sum += w & ((1u << 26) - 1u);
+        sum += v & ((1u << 26) - 1u);
     }
     if (gave_up) atomicOr(ctl + 3, 2u);
     const unsigned int inc = wave_incl_scan(sum);
@@ -1187,9 +1177,6 @@ __device__ __forceinline__ unsigned long long bkt_wave_sort(unsigned long long v
     return v;
 }
 
-#ifndef PCS_BKT_EARLY
-#define PCS_BKT_EARLY 1
-#endif
 constexpr unsigned int kBktGiant = 8192, kBktSub = 256;       // a bucket beyond kBktGiant partials is first split into <= kBktSub key ranges
 
 // A GIANT bucket (stale splitters: the cloud moved into one of the previous call's key ranges; or far more voxels than 1024
@@ -1371,15 +1358,9 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 // passes parks its records at its own offset and moves them when it is through — if it waited for the earlier
                 // buckets between its passes, the crowded buckets of a call would run one after the other.
                 const bool direct = whole_bucket && !restart && !beyond && emitted == 0u;
-                unsigned int early0 = 0u, early1 = 0u;
                 if (direct) {
                     if (threadIdx.x == 0) __hip_atomic_store(pub + b, (gen << 26) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     published = true;
-#if PCS_BKT_EARLY
-                    // ... and asks for the earlier buckets' counts: the answers travel while this bucket sorts
-                    if (threadIdx.x < b) early0 = __hip_atomic_load(pub + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (threadIdx.x + kBktThreads < b) early1 = __hip_atomic_load(pub + threadIdx.x + kBktThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
                 }
                 __syncthreads();
                 // Key order without a barrier-per-stage sort: a wavefront sorts its 64 entries in registers, parks the sorted run
@@ -1413,7 +1394,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                     T = t_new;
                     continue;
                 }
-                if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt, PCS_BKT_EARLY != 0, early0, early1); have_base = true; }
+                if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
                 int16_t* const rec = direct ? out : tmp_rec;
                 const unsigned int first = direct ? base : o0 + emitted;
                 for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
