@@ -1613,7 +1613,8 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     static const int track_env = [] { const char* v = getenv("PCS_VOXEL_TRACK"); return v ? atoi(v) : -1; }();
     pl.track_bits = 3u * pl.bits > 3u * kRadixBits;
     if (track_env >= 0) pl.track_bits = track_env != 0;
-    pl.bucket = choose_bucket_tail(leaf_mm, ws.tail_pref);
+    // (a bucket publishes its voxel count in 26 bits beside a 6-bit tag: clouds of 2^26 points and more take the LSD tail)
+    pl.bucket = choose_bucket_tail(leaf_mm, ws.tail_pref) && n_points < (1u << 26);
     if (pl.bucket) {
         pl.idx_bits = 0;              // raw keys, as in the exchange format: the bucket tail moves the partials themselves
         pl.track_bits = false;
