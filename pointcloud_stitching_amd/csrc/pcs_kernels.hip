@@ -1784,6 +1784,38 @@ void pcs_transform_payload_kernel(XformBatch xb)
     uint8_t* gdst = C.out + (size_t)tile0 * PCS_POINT_BYTES;
     const uint32_t ohead = (uint32_t)((uintptr_t)gdst & 15u);
     Record rec[kPointsPerLane];
+    if (DS1 && pts == kTilePoints && ohead == 0u &&
+        (((uintptr_t)C.in + (size_t)tile0 * PCS_POINT_BYTES) & 15u) == 0u) {
+        // FULL, 16-byte aligned tile (every tile but the last of a camera whose payload starts on a 16-byte boundary — what
+        // hipMalloc and the stitched offsets of standard rasters give): a lane reads its own 8 consecutive records, 80 contiguous
+        // bytes, as five 16-byte loads straight into registers (the a2 twin's reader: the L1 merges the wavefront's 64 x 5 pieces),
+        // transforms them there and parks 5 x 16 bytes at LDS[lane * 80] (conflict-free); one LDS trip and one barrier instead
+        // of two of each.
+        const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(C.in) + (size_t)tile0 * PCS_POINT_BYTES) +
+                         threadIdx.x * 5u;
+        uint32_t w[20];
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const uint4 v = q[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {                          // two records = five dwords: xy zc b|x' y'|z' c'|b'
+            uint32_t* o = w + (k >> 1) * 5;
+            Record a, b;
+            a.xy = o[0]; a.zc = o[1]; a.b = o[2] & 0xFFFFu;
+            b.xy = perm(o[3], o[2], kHiLo); b.zc = perm(o[4], o[3], kHiLo); b.b = o[4] >> 16;
+            a = retransform_record(C.M, a);
+            b = retransform_record(C.M, b);
+            o[0] = a.xy; o[1] = a.zc;
+            o[2] = perm(b.xy, a.b, kLoLo);
+            o[3] = perm(b.zc, b.xy, kHiLo);
+            o[4] = perm(b.b, b.zc, kHiLo);
+        }
+        uint4* mine = reinterpret_cast<uint4*>(stage) + threadIdx.x * 5u;
+#pragma unroll
+        for (int j = 0; j < 5; j++) mine[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+        __syncthreads();
+        store_staged(stage, 0u, kTilePoints * PCS_POINT_BYTES, gdst);
+        return;
+    }
     if (DS1) {
         const uint8_t* gsrc = reinterpret_cast<const uint8_t*>(C.in) + (size_t)tile0 * PCS_POINT_BYTES;
         const uint32_t ihead = (uint32_t)((uintptr_t)gsrc & 15u);
