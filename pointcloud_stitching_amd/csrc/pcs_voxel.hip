@@ -1177,6 +1177,16 @@ __device__ __forceinline__ unsigned long long bkt_wave_sort(unsigned long long v
     return v;
 }
 
+// lab only (-DPCS_BKT_TRACE): thread 0 of every reduce workgroup stamps wall_clock64 (100 MHz) at phase boundaries into the
+// buffer whose address is in PCS_BKT_TRACE_PTR (tools/lab/bkt_trace.py); compiled out of the product
+#ifndef PCS_BKT_TRACE
+#define PCS_BKT_TRACE 0
+#endif
+#if PCS_BKT_TRACE
+#define BKT_STAMP(i) do { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16u + (i)] = wall_clock64(); } while (0)
+#else
+#define BKT_STAMP(i) do { } while (0)
+#endif
 constexpr unsigned int kBktGiant = 8192, kBktSub = 256;       // a bucket beyond kBktGiant partials is first split into <= kBktSub key ranges
 
 // A GIANT bucket (stale splitters: the cloud moved into one of the previous call's key ranges; or far more voxels than 1024
@@ -1243,7 +1253,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                                const unsigned int* __restrict__ boff, unsigned int* __restrict__ ctl,
                                int16_t* __restrict__ out, int16_t* __restrict__ tmp_rec, unsigned int* __restrict__ pub, unsigned int gen,
                                unsigned long long* __restrict__ spl, int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next,
-                               unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr)
+                               unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr, long long* __restrict__ trace)
 {
     __shared__ unsigned long long tkey[kBktSlots];
     __shared__ unsigned long long tx[kBktSlots], ty[kBktSlots], tz[kBktSlots], tr[kBktSlots], tg[kBktSlots], tbn[kBktSlots];
@@ -1256,6 +1266,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
     const unsigned int m = ctl[0];
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (unsigned int b = blockIdx.x; b < kBkt; b += gridDim.x) {
+        BKT_STAMP(0);
         const unsigned int o0 = boff[b], n = boff[b + 1u] - o0;
         unsigned int emitted = 0, base = 0, fed = 0;
         bool have_base = false, published = false;
@@ -1299,6 +1310,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                     z4 = reinterpret_cast<u32x4*>(tbn); z4[threadIdx.x] = zero;
                 }
                 __syncthreads();
+                BKT_STAMP(1);      // boff + first batch requested, table cleared
                 bool restart = false, over_any = false;
                 unsigned int my_in = 0;                              // partials this lane fed into the table in this pass
                 for (unsigned int i0 = 0; i0 < rn; i0 += kBktThreads) {
@@ -1343,6 +1355,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 }
                 // did anybody meet a key at or above T? (also the barrier behind the last batch's adds)
                 const bool beyond = __syncthreads_or(over_any ? 1 : 0) != 0;
+                BKT_STAMP(2);      // all partials in the table
                 // the occupied slots, dense: every lane owns slots 2t, 2t + 1
                 const unsigned long long k0 = tkey[2u * threadIdx.x], k1 = tkey[2u * threadIdx.x + 1u];
                 const unsigned int c2 = (k0 != kEmptyKey) + (k1 != kEmptyKey);
@@ -1372,11 +1385,14 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 unsigned long long v0 = threadIdx.x < cnt ? dl[threadIdx.x] : kBktInf;
                 unsigned long long v1 = threadIdx.x + kBktThreads < cnt ? dl[threadIdx.x + kBktThreads] : kBktInf;
                 __syncthreads();                                    // dl is read; it becomes the runs' home
+                BKT_STAMP(3);      // dense list, count published
                 v0 = bkt_wave_sort(v0, lane);
                 if (n_runs == 16u) v1 = bkt_wave_sort(v1, lane);    // workgroup-uniform
+                BKT_STAMP(7);      // runs sorted in registers
                 dl[wave * 64u + lane] = v0;
                 if (n_runs == 16u) dl[kBktThreads + wave * 64u + lane] = v1;
                 __syncthreads();
+                BKT_STAMP(8);      // runs parked
                 if (v0 != kBktInf) srt[n_runs == 16u ? bkt_rank<16>(dl, v0, wave, lane) : bkt_rank<8>(dl, v0, wave, lane)] = v0;
                 if (n_runs == 16u && v1 != kBktInf) srt[bkt_rank<16>(dl, v1, 8u + wave, lane)] = v1;
                 __syncthreads();
@@ -1394,7 +1410,9 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                     T = t_new;
                     continue;
                 }
+                BKT_STAMP(4);      // ranked: key order known
                 if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
+                BKT_STAMP(5);      // base known
                 int16_t* const rec = direct ? out : tmp_rec;
                 const unsigned int first = direct ? base : o0 + emitted;
                 for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
@@ -1419,6 +1437,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                         }
                     }
                 }
+                BKT_STAMP(6);      // records written, splitters refreshed
                 fed += n_in;
                 emitted += cnt;
                 // keys at or above T were left out: they are the next pass
@@ -1637,7 +1656,8 @@ hipError_t bucket_tail(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_
     hipLaunchKernelGGL(pcs_vox_bkt_scatter_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.part, w.bucket_of, w.ctl, pl.raw,
                        w.btable, w.btotal, w.keys_s, w.part_s, w.boff);
     hipLaunchKernelGGL(pcs_vox_bkt_reduce_kernel, dim3(kBkt), dim3(kBktThreads), 0, st, w.keys_s, w.part_s, w.boff, w.ctl, d_out,
-                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next, w.keys_a, w.part_ws);
+                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next, w.keys_a, w.part_ws,
+                       (long long*)(PCS_BKT_TRACE && getenv("PCS_BKT_TRACE_PTR") ? strtoull(getenv("PCS_BKT_TRACE_PTR"), nullptr, 0) : 0ull));
     return hipGetLastError();
 }
 
