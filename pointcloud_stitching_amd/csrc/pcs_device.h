@@ -186,6 +186,18 @@ struct VoxelStage {
     uint32_t            leaf, bits, idx_bits;
     float               div_inv, div_c;   // voxel index of a coordinate: (unsigned)fmaf(v, div_inv, div_c) (pcs_voxel_agg.h: VoxelDiv)
     uint32_t            track_bits;    // record which key bits vary (the sort may then skip a pass); 0: the host declared all of them varying
+    // Warm bucket tail (pcs_voxel.hip, "regions"): the workgroup finds each partial's bucket itself (the previous call's splitters)
+    // and appends it to that bucket's REGION — reg[0] buckets of reg[1] slots each, filled through cursor[bucket] — so the
+    // partition kernels (histogram, column scan, scatter) are not launched. A partial whose region is full goes to keys / part as
+    // before, with its bucket id in bucket_of: the tail's first workgroup sorts those few in.
+    uint32_t                  regions;       // 0: every partial to keys / part
+    uint32_t                  region_slots;  // capacity of keys_r / part_r (a call whose reg[] asks for more uses no regions)
+    const unsigned long long* spl;           // kVoxBuckets - 1 ascending splitters (+ one unused word)
+    const unsigned int*       reg;           // {buckets in use, slots per region}: written by the previous call's tail
+    unsigned int*             cursor;        // [kVoxBuckets] partials offered to each bucket so far (zero at launch)
+    unsigned long long*       keys_r;
+    void*                     part_r;
+    unsigned short*           bucket_of;
 };
 hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws, VoxelStage* stage,
                        hipStream_t st);

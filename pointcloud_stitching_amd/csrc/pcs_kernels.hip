@@ -1305,6 +1305,50 @@ struct VoxTable {
     const VoxTable T{skey_, sxy_, szn_, srg_, sbl_, wtot_, &base_s_, &flag_, kor_};                    \
     unsigned long long key_or = 0ull, key_orn = 0ull
 
+// Warm bucket tail (vs.regions): the geometry of this call's regions, and one partial put into its bucket's region by a lane on
+// its own (a run that found no slot in the workgroup's table: a few dozen per frame-set) — the bucket by binary search in
+// the global splitters (ten dependent trips to L2: a few dozen lanes per frame-set take them), the slot by a returning add on
+// the bucket's cursor. The workgroup's flush does the same for all the table's partials at once (vox_table_flush_regions).
+struct VoxRegions {
+    unsigned int B, cap, stride;
+    __device__ __forceinline__ explicit VoxRegions(const VoxelStage& vs)
+    {
+        B = vs.reg[0]; cap = vs.reg[1];
+        if (B == 0u || B > kVoxBuckets) B = kVoxBuckets;
+        // (the tail applies the same rule. The regions hold any cloud of THIS call's capacity; the sizes come from the previous
+        // call, which may have had a larger one: then nothing fits and everything goes to the general list)
+        if ((unsigned long long)B * cap > vs.region_slots) cap = 0u;
+        stride = kVoxBuckets / B;
+    }
+    // bucket j ends below splitter j (the last one is open)
+    __device__ __forceinline__ unsigned long long splitter(const VoxelStage& vs, unsigned int j) const
+    {
+        return (j + 1u < B) ? vs.spl[(j + 1u) * stride - 1u] : kEmptyKey;
+    }
+};
+__device__ __forceinline__ void vox_region_put(const VoxelStage& vs, unsigned long long key, const VoxelPartial& v)
+{
+    // (Measured and not kept: half of the splitters in LDS for this search — 4 KiB per workgroup, stored behind a barrier before the
+    // first round — and one returning add per wavefront and bucket instead of one per run: +4 .. 7 us on every 16 x 1080p
+    // frame-set for 0.3 ms off a call on a cloud of scattered points, whose runs mostly fail.)
+    const VoxRegions R(vs);
+    unsigned int b = 0;
+#pragma unroll 1
+    for (unsigned int step = kVoxBuckets / 2; step; step >>= 1)
+        if (R.splitter(vs, b + step - 1u) <= key) b += step;
+    const unsigned int at = atomicAdd(&vs.cursor[b], 1u);
+    if (at < R.cap) {
+        const size_t dst = (size_t)b * R.cap + at;
+        vs.keys_r[dst] = key;
+        static_cast<VoxelPartial*>(vs.part_r)[dst] = v;
+    } else {
+        const unsigned int e = atomicAdd(vs.n_runs, 1u);
+        vs.keys[e] = key;
+        static_cast<VoxelPartial*>(vs.part)[e] = v;
+        vs.bucket_of[e] = (unsigned short)b;
+    }
+}
+
 __device__ __forceinline__ void vox_table_init(const VoxTable& T)
 {
     for (int j = threadIdx.x; j < kVoxSlots; j += kVoxThreads) {
@@ -1383,7 +1427,10 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
     const unsigned long long any_failed = __ballot(failed != 0u);    // (all lanes: not inside a short-circuit)
     unsigned int pos = 0;
     bool emit = false;
-    if (crowded) {                                                    // uniform over the launch
+    const bool to_regions = vs.regions != 0u;                         // uniform over the launch: every failed run finds its own place
+    if (to_regions) {
+        emit = any_failed != 0ull;
+    } else if (crowded) {                                             // uniform over the launch
         if (lane == 0 && any_failed) *T.flag = 1u;
         __syncthreads();
         if (*T.flag) {                                                // workgroup-uniform
@@ -1425,21 +1472,108 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
             sx += x; sy += y; sz += z; r += col & 0xFFu; g += col >> 8; b += blue; cnt += 1u;
             kprev = key;
             if ((failed >> k) & 1u) {
-                if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
-                else { vs.keys[pos] = key; if (vs.idx) vs.idx[pos] = pos; }
-                part[pos] = VoxelPartial{sx, sy, sz, r, g, b, cnt, 0u};
-                key_or |= key; key_orn |= ~key;
-                pos++;
+                const VoxelPartial v{sx, sy, sz, r, g, b, cnt, 0u};
+                if (to_regions) {
+                    vox_region_put(vs, key, v);
+                } else {
+                    if (idx_bits) vs.keys[pos] = (key << idx_bits) | pos;
+                    else { vs.keys[pos] = key; if (vs.idx) vs.idx[pos] = pos; }
+                    part[pos] = v;
+                    key_or |= key; key_orn |= ~key;
+                    pos++;
+                }
             }
         }
     }
     if (crowded) __syncthreads();         // wtot / base_s are free again before the next round (or the flush) uses them
 }
 
+// End of the workgroup on a WARM bucket tail (vs.regions): every partial straight into its bucket's region. The key array of the
+// table is dead once each lane holds its slots' keys, and becomes: this call's splitters (8 KiB) | the workgroup's count per
+// bucket (4 KiB) | where its partials start in each region (4 KiB). Ten dependent LDS reads per key find the bucket (the lane's
+// keys side by side), a returning LDS add ranks the partial among the workgroup's for that bucket, ONE returning global add per
+// bucket the workgroup touches (a 128 x 64-pixel patch touches a few dozen) reserves the slots. A partial that finds its region
+// full goes to the general list (keys / part / bucket_of) with a returning add of its own.
+__device__ __forceinline__ void vox_table_flush_regions(const VoxTable& T, const VoxelStage& vs)
+{
+    if (kVoxSlots < 2 * (int)kVoxBuckets) __builtin_trap();                 // (the lab shapes with small tables: no room for the arrays below)
+    unsigned long long* const spl = T.skey;
+    unsigned int* const hist = reinterpret_cast<unsigned int*>(T.skey + kVoxBuckets);
+    unsigned int* const rbase = hist + kVoxBuckets;
+    VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
+    VoxelPartial* __restrict__ part_r = static_cast<VoxelPartial*>(vs.part_r);
+    const VoxRegions R(vs);
+    const unsigned int cap = R.cap;
+    // (requesting the splitters when the workgroup starts — two dependent trips to L2 that the rounds would hide — costs four
+    // registers through the rounds and measured no gain at 40 / 50 mm, 2 us more at 100 / 200 mm)
+    constexpr int kSplPer = ((int)kVoxBuckets + kVoxThreads - 1) / kVoxThreads;
+    unsigned long long sp[kSplPer];
+#pragma unroll
+    for (int i = 0; i < kSplPer; i++) sp[i] = R.splitter(vs, threadIdx.x + (unsigned int)(i * kVoxThreads));
+    __syncthreads();                                                        // the last round's adds are in
+    unsigned long long key[kVoxOwn];
+#pragma unroll
+    for (int q = 0; q < kVoxOwn; q++) { const int j = threadIdx.x * kVoxOwn + q; key[q] = j < kVoxSlots ? T.skey[j] : kEmptyKey; }
+    __syncthreads();                                                        // every key is in a register: the array is free
+#pragma unroll
+    for (int i = 0; i < kSplPer; i++) {
+        const unsigned int j = threadIdx.x + (unsigned int)(i * kVoxThreads);
+        if (j < kVoxBuckets) { spl[j] = sp[i]; hist[j] = 0u; }
+    }
+    __syncthreads();
+    unsigned int bk[kVoxOwn], rk[kVoxOwn];
+#pragma unroll
+    for (int q = 0; q < kVoxOwn; q++) bk[q] = 0u;
+#pragma unroll
+    for (unsigned int step = kVoxBuckets / 2; step; step >>= 1) {
+#pragma unroll
+        for (int q = 0; q < kVoxOwn; q++)
+            if (spl[bk[q] + step - 1u] <= key[q]) bk[q] += step;
+    }
+#pragma unroll
+    for (int q = 0; q < kVoxOwn; q++) {
+        rk[q] = 0u;
+        if (key[q] != kEmptyKey) rk[q] = atomicAdd(&hist[bk[q]], 1u);
+    }
+    __syncthreads();
+    for (unsigned int j = threadIdx.x; j < kVoxBuckets; j += kVoxThreads) {
+        const unsigned int c = hist[j];
+        rbase[j] = c ? atomicAdd(&vs.cursor[j], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kVoxOwn; q++) {
+        const int j = threadIdx.x * kVoxOwn + q;
+        if (key[q] == kEmptyKey) continue;
+        const unsigned long long xy = T.sxy[j], zn = T.szn[j], rg = T.srg[j];
+        const unsigned int cnt = (unsigned int)(zn >> 32);
+        const int bias = (int)(cnt << 15);
+        const VoxelPartial v{(int)(unsigned int)xy - bias, (int)(unsigned int)(xy >> 32) - bias, (int)(unsigned int)zn - bias,
+                             (unsigned int)rg, (unsigned int)(rg >> 32), T.sbl[j], cnt, 0u};
+        const unsigned int at = rbase[bk[q]] + rk[q];
+        if (at < cap) {
+            const size_t dst = (size_t)bk[q] * cap + at;
+            vs.keys_r[dst] = key[q];
+            part_r[dst] = v;
+        } else {
+            // (the region is full: one returning add for all the lanes of the wavefront that are here)
+            const unsigned long long peers = __ballot(1);
+            const unsigned int rank = (unsigned int)__popcll(peers & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            unsigned int e = 0;
+            if (rank == 0u) e = atomicAdd(vs.n_runs, (unsigned int)__popcll(peers));
+            e = (unsigned int)__shfl((int)e, __ffsll((long long)peers) - 1) + rank;
+            vs.keys[e] = key[q];
+            part[e] = v;
+            vs.bucket_of[e] = (unsigned short)bk[q];
+        }
+    }
+}
+
 // End of the workgroup: one partial per occupied slot, one returning global atomic for all of them.
 __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelStage& vs, unsigned long long key_or,
                                                 unsigned long long key_orn)
 {
+    if (vs.regions) { vox_table_flush_regions(T, vs); return; }            // (uniform over the launch)
     unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
     unsigned long long* const srg = T.srg; unsigned int* const sbl = T.sbl; unsigned int* const wtot = T.wtot;
     unsigned int& base_s = *T.base_s;

@@ -842,9 +842,10 @@ void pcs_voxel_fixup_kernel(unsigned int* __restrict__ ctl, const BlockPiece* __
 #define PCS_BKT 1024
 #endif
 constexpr unsigned int kBkt = PCS_BKT, kBktSample = 4096;      // buckets: 256 .. 1024, a power of two
+static_assert(kBkt == kVoxBuckets, "the pre-aggregation's region flush (pcs_kernels.hip) partitions into kVoxBuckets ranges");
 constexpr unsigned int kBktChunk = 4096, kBktThreads = 512, kBktPer = kBktChunk / kBktThreads;     // 8 elements per lane
 constexpr unsigned int kBktGrid = 512;
-constexpr unsigned int kBktSlots = 1024, kBktProbe = 24;           // G1's LDS table
+constexpr unsigned int kBktSlots = 1024, kBktProbe = 48;           // G1's LDS table
 constexpr unsigned long long kBktInf = ~0ull;
 
 template <unsigned int N, unsigned int THREADS>
@@ -1133,6 +1134,18 @@ __device__ __forceinline__ unsigned int bkt_block_sum(unsigned int v, unsigned i
     return total;
 }
 
+// two sums at once (both below 2^32): low and high half of one 64-bit word per lane
+__device__ __forceinline__ unsigned long long bkt_block_sum2(unsigned int lo, unsigned int hi, unsigned long long* wsum2)
+{
+    const unsigned int slo = wave_incl_scan(lo), shi = wave_incl_scan(hi);      // (DPP: lane 63 holds the wavefront's sums)
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 63u) wsum2[threadIdx.x >> 6] = (unsigned long long)slo | ((unsigned long long)shi << 32);
+    __syncthreads();
+    unsigned long long total = 0;
+    for (unsigned int w = 0; w < kBktThreads / 64; w++) total += wsum2[w];
+    return total;
+}
+
 // rank of v among NRUNS sorted runs of 64 words (padded with the sentinel) = its place in its own run + the words below it in
 // every other run: the binary searches run side by side
 template <unsigned int NRUNS>
@@ -1194,9 +1207,63 @@ constexpr unsigned int kBktGiant = 8192, kBktSub = 256;       // a bucket beyond
 // partials. Instead the workgroup splits the bucket ONCE more — up to 255 splitters from a sorted sample of 256 of its keys, a
 // counting pass, a scatter into the (by now dead) pre-aggregation arrays — and the caller runs the ranges one after the other:
 // three reads of the bucket instead of hundreds. Returns the number of ranges; soff[0 .. n_sub] = their bounds (relative to o0).
+// The bucket's partials are keys_s / part_s [o0, o0 + n_a) and, on a warm call whose region overflowed, a second stretch
+// ov.keys / ov.part [ov.r0, ov.r0 + ov.n) (bkt_gather); the ranges go to kscr / pscr [t0, t0 + n).
+struct BktOverflow {
+    const unsigned long long* keys;
+    const VoxelPartial* part;
+    unsigned int r0, n;
+};
+// A warm call's bucket whose region was full (its share of the cloud more than doubled since the previous call — the cloud moved):
+// the partials that did not fit sit in the general list, in no order, tagged with their bucket. The workgroup copies its own
+// to gk / gp [g0, g0 + expect): eight tags per lane and step (one 16-byte load), places by a returning LDS add. Every
+// overflowing bucket reads all tags — a stale call pays for that once, like the cold path's split of a giant bucket.
+__device__ __forceinline__ void bkt_gather(const unsigned long long* __restrict__ lk, const VoxelPartial* __restrict__ lp,
+                                        const unsigned short* __restrict__ ids, unsigned int n_list, unsigned int b,
+                                        unsigned long long* __restrict__ gk, VoxelPartial* __restrict__ gp, unsigned int g0,
+                                        unsigned int expect, unsigned int* cur)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (threadIdx.x == 0) *cur = 0u;
+    __syncthreads();
+    for (unsigned int base = 0; base < n_list; base += kBktThreads * 8u) {
+        const unsigned int e0 = base + threadIdx.x * 8u;
+        unsigned int match = 0;
+        if (e0 + 8u <= n_list) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(ids + e0);      // (the list starts 256-byte aligned, e0 is a multiple of 8)
+            const unsigned int w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (unsigned int k = 0; k < 4; k++) {
+                match |= ((w[k] & 0xFFFFu) == b ? 1u : 0u) << (2u * k);
+                match |= ((w[k] >> 16) == b ? 1u : 0u) << (2u * k + 1u);
+            }
+        } else {
+            for (unsigned int k = 0; k < 8u; k++)
+                if (e0 + k < n_list && ids[e0 + k] == b) match |= 1u << k;
+        }
+        if (match) {
+            unsigned int dst = g0 + atomicAdd(cur, (unsigned int)__popc(match));
+            while (match) {
+                const unsigned int k = (unsigned int)__ffs((int)match) - 1u;
+                match &= match - 1u;
+                const unsigned int e = e0 + k;
+                const u32x4* p4 = reinterpret_cast<const u32x4*>(lp + e);
+                const u32x4 pa = p4[0], pb = p4[1];
+                gk[dst] = lk[e];
+                u32x4* o4 = reinterpret_cast<u32x4*>(gp + dst);
+                o4[0] = pa; o4[1] = pb;
+                dst++;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    (void)expect;
+}
 __device__ __forceinline__ unsigned int bkt_presplit(const unsigned long long* __restrict__ keys_s, const VoxelPartial* __restrict__ part_s,
                                                   unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr,
-                                                  unsigned int o0, unsigned int n, unsigned long long* dl, unsigned long long* srt,
+                                                  unsigned int o0, unsigned int n_a, const BktOverflow ov, unsigned int t0, unsigned int n,
+                                                  unsigned long long* dl, unsigned long long* srt,
                                                   unsigned int* scur, unsigned int* soff, unsigned int* wcnt)
 {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1207,7 +1274,8 @@ __device__ __forceinline__ unsigned int bkt_presplit(const unsigned long long* _
     while (n_sub < kBktSub && n_sub * 1536u < n) n_sub <<= 1;
     const unsigned int sstride = kBktSub / n_sub;
     if (threadIdx.x < kBktSub) {
-        const unsigned long long k = keys_s[o0 + (unsigned int)(((unsigned long long)threadIdx.x * n) / kBktSub)];
+        const unsigned int at = (unsigned int)(((unsigned long long)threadIdx.x * n) / kBktSub);      // (over both stretches)
+        const unsigned long long k = at < n_a ? keys_s[o0 + at] : ov.keys[ov.r0 + (at - n_a)];
         const unsigned long long v = bkt_wave_sort((k << 8) | threadIdx.x, lane);      // (distinct words: the index rides below the key)
         dl[wave * 64u + lane] = v;
     }
@@ -1221,7 +1289,8 @@ __device__ __forceinline__ unsigned int bkt_presplit(const unsigned long long* _
             if ((srt[(lo + step) * sstride] >> 8) <= key) lo += step;
         return lo;
     };
-    for (unsigned int e = threadIdx.x; e < n; e += kBktThreads) atomicAdd(&scur[sub_of(keys_s[o0 + e])], 1u);
+    for (unsigned int e = threadIdx.x; e < n_a; e += kBktThreads) atomicAdd(&scur[sub_of(keys_s[o0 + e])], 1u);
+    for (unsigned int e = threadIdx.x; e < ov.n; e += kBktThreads) atomicAdd(&scur[sub_of(ov.keys[ov.r0 + e])], 1u);
     __syncthreads();
     {
         const unsigned int c = threadIdx.x < kBktSub ? scur[threadIdx.x] : 0u;
@@ -1234,11 +1303,12 @@ __device__ __forceinline__ unsigned int bkt_presplit(const unsigned long long* _
         if (threadIdx.x == 0) soff[n_sub] = n;
     }
     __syncthreads();
-    for (unsigned int e = threadIdx.x; e < n; e += kBktThreads) {
-        const unsigned long long key = keys_s[o0 + e];
-        const u32x4* p4 = reinterpret_cast<const u32x4*>(part_s + o0 + e);
+    for (unsigned int e = threadIdx.x; e < n_a + ov.n; e += kBktThreads) {
+        const bool a = e < n_a;
+        const unsigned long long key = a ? keys_s[o0 + e] : ov.keys[ov.r0 + (e - n_a)];
+        const u32x4* p4 = reinterpret_cast<const u32x4*>(a ? part_s + o0 + e : ov.part + ov.r0 + (e - n_a));
         const u32x4 pa = p4[0], pb = p4[1];
-        const unsigned int dst = o0 + atomicAdd(&scur[sub_of(key)], 1u);
+        const unsigned int dst = t0 + atomicAdd(&scur[sub_of(key)], 1u);
         kscr[dst] = key;
         u32x4* o4 = reinterpret_cast<u32x4*>(pscr + dst);
         o4[0] = pa; o4[1] = pb;
@@ -1253,7 +1323,13 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                                const unsigned int* __restrict__ boff, unsigned int* __restrict__ ctl,
                                int16_t* __restrict__ out, int16_t* __restrict__ tmp_rec, unsigned int* __restrict__ pub, unsigned int gen,
                                unsigned long long* __restrict__ spl, int32_t* __restrict__ out_points, unsigned int* __restrict__ zero_next,
-                               unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr, long long* __restrict__ trace)
+                               unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr, long long* __restrict__ trace,
+                               const unsigned int regions, const unsigned long long* __restrict__ keys_r, const VoxelPartial* __restrict__ part_r,
+                               const unsigned int region_slots, const unsigned int* __restrict__ reg, unsigned int* __restrict__ reg_next,
+                               const unsigned int* __restrict__ cursor, unsigned int* __restrict__ cursor_next,
+                               const unsigned long long* __restrict__ kscr_list, const VoxelPartial* __restrict__ pscr_list,
+                               const unsigned short* __restrict__ ov_ids, unsigned long long* __restrict__ gath_k,
+                               VoxelPartial* __restrict__ gath_p)
 {
     __shared__ unsigned long long tkey[kBktSlots];
     __shared__ unsigned long long tx[kBktSlots], ty[kBktSlots], tz[kBktSlots], tr[kBktSlots], tg[kBktSlots], tbn[kBktSlots];
@@ -1262,25 +1338,71 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
     __shared__ unsigned int wcnt[kBktThreads / 64];
     __shared__ unsigned long long smp[64];
     __shared__ unsigned int soff[kBktSub + 1], scur[kBktSub];
+    __shared__ unsigned long long wsum2[kBktThreads / 64];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned int m = ctl[0];
+    unsigned int m = ctl[0];
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // WARM call (regions): the pre-aggregation put bucket b's partials into region b — reg[1] slots at b * reg[1], cursor[b] of them
+    // offered — and ctl[0] counts the partials that found their region full. Every workgroup sums the counts for itself (1024
+    // words): the partials before its bucket are what the splitter refresh needs, their total what the next call is sized by.
+    unsigned int reg_cap = 0, m_over = 0;
+    if (regions) {
+        reg_cap = reg[1];
+        unsigned int reg_b = reg[0];
+        if (reg_b == 0u || reg_b > kBkt) reg_b = kBkt;
+        if ((unsigned long long)reg_b * reg_cap > region_slots) reg_cap = 0u;      // (as the pre-aggregation decided)
+        m_over = m;
+    }
+    const unsigned long long* __restrict__ Kb = regions ? keys_r : keys_s;
+    const VoxelPartial* __restrict__ Pb = regions ? part_r : part_s;
     for (unsigned int b = blockIdx.x; b < kBkt; b += gridDim.x) {
         BKT_STAMP(0);
-        const unsigned int o0 = boff[b], n = boff[b + 1u] - o0;
+        // o0: where the bucket's partials lie, n_a of them; n: all of the bucket's partials (a warm call: + those that found the
+        // region full and sit in the general list); rank0: the partials of the buckets before it — also where, in the scratch
+        // arrays, its parked records and split ranges go
+        unsigned int o0, n_a, n, rank0, over_here = 0;
+        if (regions) {
+            constexpr unsigned int kPer = kBkt / kBktThreads;
+            unsigned int below = 0, all = 0, over_below = 0;
+#pragma unroll
+            for (unsigned int q = 0; q < kPer; q++) {
+                const unsigned int j = threadIdx.x * kPer + q, c = cursor[j];
+                all += min(c, reg_cap);
+                below += j < b ? min(c, reg_cap) : 0u;
+                over_below += j < b ? c - min(c, reg_cap) : 0u;
+            }
+            const unsigned int cb = cursor[b];
+            const unsigned long long t = bkt_block_sum2(below, all, wsum2);
+            if (m_over) over_below = (unsigned int)bkt_block_sum2(over_below, 0u, wsum2);      // (uniform)
+            o0 = b * reg_cap;
+            n_a = min(cb, reg_cap);
+            n = cb;
+            rank0 = (unsigned int)t + over_below;
+            over_here = over_below;
+            m = (unsigned int)(t >> 32) + m_over;
+        } else {
+            o0 = boff[b]; n_a = n = boff[b + 1u] - o0; rank0 = o0;
+        }
+        // (over_below: the overflow of the buckets before this one = where, in the gather space, its own goes)
+        if (n > n_a) bkt_gather(kscr_list, pscr_list, ov_ids, m_over, b, gath_k, gath_p, over_here, n - n_a, scur);      // (uniform)
+        const BktOverflow ov{gath_k, gath_p, over_here, n - n_a};
         unsigned int emitted = 0, base = 0, fed = 0;
         bool have_base = false, published = false;
 
         // ---- one key range of the bucket: the rn partials at K / P [r0, r0 + rn), in passes over key sub-ranges [L, T) ----------
+        // (+ a second stretch ovr; rn counts both)
         auto run = [&](const unsigned long long* __restrict__ K, const VoxelPartial* __restrict__ P, const unsigned int r0,
-                       const unsigned int rn, const bool whole_bucket) {
+                       const unsigned int rn_a, const BktOverflow ovr, const unsigned int rn, const bool whole_bucket) {
             unsigned long long L = 0ull, T = kBktInf;              // this pass takes the keys in [L, T)
             bool more = rn != 0u;
             const bool big = rn > 2u * kBktSlots;                   // far more partials than slots: several passes
             if (big) {
                 // 64 evenly spaced keys, sorted by the first wavefront: every pass takes an upper bound T from them that lets
                 // about 3/4 of a table's worth of partials in, instead of finding out by overflowing
-                if (wave == 0) smp[lane] = bkt_wave_sort(K[r0 + (unsigned int)(((unsigned long long)lane * rn) >> 6)], lane);
+                if (wave == 0) {
+                    const unsigned int at = (unsigned int)(((unsigned long long)lane * rn) >> 6);
+                    smp[lane] = bkt_wave_sort(at < rn_a ? K[r0 + at] : ovr.keys[ovr.r0 + (at - rn_a)], lane);
+                }
                 __syncthreads();
             }
             while (more) {                                          // workgroup-uniform
@@ -1293,7 +1415,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 // the first batch's loads go out before the table is cleared
                 unsigned long long key_n = 0ull;
                 u32x4 pa_n = u32x4{0u, 0u, 0u, 0u}, pb_n = pa_n;
-                if (threadIdx.x < rn) {
+                if (threadIdx.x < rn_a) {
                     key_n = K[r0 + threadIdx.x];
                     const u32x4* p4 = reinterpret_cast<const u32x4*>(P + r0 + threadIdx.x);
                     pa_n = p4[0]; pb_n = p4[1];
@@ -1313,28 +1435,19 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 BKT_STAMP(1);      // boff + first batch requested, table cleared
                 bool restart = false, over_any = false;
                 unsigned int my_in = 0;                              // partials this lane fed into the table in this pass
-                for (unsigned int i0 = 0; i0 < rn; i0 += kBktThreads) {
-                    const unsigned int e = i0 + threadIdx.x;
-                    const bool live = e < rn;
-                    const unsigned long long key = key_n;
-                    const u32x4 pa = pa_n, pb = pb_n;
-                    {   // the next batch is requested before this one meets the table
-                        const unsigned int e2 = e + kBktThreads;
-                        if (e2 < rn) {
-                            key_n = K[r0 + e2];
-                            const u32x4* p4 = reinterpret_cast<const u32x4*>(P + r0 + e2);
-                            pa_n = p4[0]; pb_n = p4[1];
-                        }
-                    }
+                // one batch (a partial per lane) meets the table; true (workgroup-uniform): somebody found the table crowded
+                auto feed = [&](const bool live, const unsigned long long key, const u32x4 pa, const u32x4 pb) -> bool {
                     const bool over = live && key >= T;
                     const bool in = live && key >= L && !over;
                     int slot = -1;
                     if (in) {
                         unsigned int h, step;
                         bkt_hash(key, h, step);
-                        // a key that finds no slot within kBktProbe probes calls the table crowded (at half load that happens to
-                        // one key in 2^24): the pass then restarts below the median. Probing a full table to the end cost 1024
-                        // dependent LDS round trips per lane.
+                        // a key that finds no slot within kBktProbe probes calls the table crowded: the pass then restarts below
+                        // the median. (Probing a full table to the end cost 1024 dependent LDS round trips per lane. With 24 probes
+                        // a bucket of ~850 distinct voxels — one or two of 1024 on the config-5 scene, a different one every call —
+                        // gave up, took two passes and published its count 10 us late, which every later bucket waits for: 48 probes
+                        // took 6 us off the call at 50 mm and 24 us at 40 mm.)
                         for (unsigned int t = 0; t < kBktProbe; t++) {
                             const unsigned long long old = atomicCAS(&tkey[h], kEmptyKey, key);
                             if (old == kEmptyKey || old == key) { slot = (int)h; break; }
@@ -1343,7 +1456,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                     }
                     over_any |= over;
                     my_in += in ? 1u : 0u;
-                    if (__syncthreads_or((in && slot < 0) ? 1 : 0)) { restart = true; break; }     // somebody found the table crowded
+                    if (__syncthreads_or((in && slot < 0) ? 1 : 0)) return true;
                     if (in) {
                         atomicAdd(&tx[slot], (unsigned long long)(long long)(int)pa.x);
                         atomicAdd(&ty[slot], (unsigned long long)(long long)(int)pa.y);
@@ -1352,6 +1465,34 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                         atomicAdd(&tg[slot], (unsigned long long)pb.x);
                         atomicAdd(&tbn[slot], (unsigned long long)pb.y | ((unsigned long long)pb.z << 34));
                     }
+                    return false;
+                };
+                for (unsigned int i0 = 0; i0 < rn_a; i0 += kBktThreads) {
+                    const unsigned int e = i0 + threadIdx.x;
+                    const unsigned long long key = key_n;
+                    const u32x4 pa = pa_n, pb = pb_n;
+                    {   // the next batch is requested before this one meets the table
+                        const unsigned int e2 = e + kBktThreads;
+                        if (e2 < rn_a) {
+                            key_n = K[r0 + e2];
+                            const u32x4* p4 = reinterpret_cast<const u32x4*>(P + r0 + e2);
+                            pa_n = p4[0]; pb_n = p4[1];
+                        }
+                    }
+                    if (feed(e < rn_a, key, pa, pb)) { restart = true; break; }
+                }
+                // the second stretch (a region that overflowed: rare)
+                for (unsigned int i0 = 0; !restart && i0 < ovr.n; i0 += kBktThreads) {
+                    const unsigned int e = i0 + threadIdx.x;
+                    const bool live = e < ovr.n;
+                    unsigned long long key = 0ull;
+                    u32x4 pa = u32x4{0u, 0u, 0u, 0u}, pb = pa;
+                    if (live) {
+                        key = ovr.keys[ovr.r0 + e];
+                        const u32x4* p4 = reinterpret_cast<const u32x4*>(ovr.part + ovr.r0 + e);
+                        pa = p4[0]; pb = p4[1];
+                    }
+                    if (feed(live, key, pa, pb)) restart = true;
                 }
                 // did anybody meet a key at or above T? (also the barrier behind the last batch's adds)
                 const bool beyond = __syncthreads_or(over_any ? 1 : 0) != 0;
@@ -1414,7 +1555,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
                 BKT_STAMP(5);      // base known
                 int16_t* const rec = direct ? out : tmp_rec;
-                const unsigned int first = direct ? base : o0 + emitted;
+                const unsigned int first = direct ? base : rank0 + emitted;
                 for (unsigned int i = threadIdx.x; i < cnt; i += kBktThreads) {
                     const unsigned int slot = (unsigned int)(srt[i] & (kBktSlots - 1u));
                     const unsigned long long bn = tbn[slot];
@@ -1431,8 +1572,8 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 if (m != 0u && n_in != 0u) {
                     for (unsigned int j = threadIdx.x + 1u; j < kBkt; j += kBktThreads) {
                         const unsigned int q = (unsigned int)(((unsigned long long)j * m) / kBkt);
-                        if (q >= o0 + fed && q < o0 + fed + n_in) {
-                            const unsigned int i = (unsigned int)(((unsigned long long)(q - o0 - fed) * cnt) / n_in);
+                        if (q >= rank0 + fed && q < rank0 + fed + n_in) {
+                            const unsigned int i = (unsigned int)(((unsigned long long)(q - rank0 - fed) * cnt) / n_in);
                             spl[j - 1u] = srt[i < cnt ? i : cnt - 1u] >> 10;
                         }
                     }
@@ -1447,10 +1588,11 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
         };
 
         const bool giant = n > kBktGiant;
-        const unsigned int n_sub = giant ? bkt_presplit(keys_s, part_s, kscr, pscr, o0, n, dl, srt, scur, soff, wcnt) : 1u;
+        const unsigned int n_sub = giant ? bkt_presplit(Kb, Pb, kscr, pscr, o0, n_a, ov, rank0, n, dl, srt, scur, soff, wcnt) : 1u;
+        const BktOverflow ov_run{ov.keys, ov.part, ov.r0, giant ? 0u : ov.n};      // (a split bucket's ranges hold everything already)
         for (unsigned int s = 0; s < n_sub; s++) {                 // (soff lives in LDS of its own: run() reuses dl / srt)
             const unsigned int s0 = giant ? soff[s] : 0u, s1 = giant ? soff[s + 1u] : n;
-            run(giant ? kscr : keys_s, giant ? pscr : part_s, o0 + s0, s1 - s0, !giant);
+            run(giant ? kscr : Kb, giant ? pscr : Pb, giant ? rank0 + s0 : o0, giant ? s1 - s0 : n_a, ov_run, s1 - s0, !giant);
         }
 
         if (!published && threadIdx.x == 0)                    // empty buckets, and buckets that took several passes
@@ -1459,10 +1601,11 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
             base = bkt_base(pub, b, gen, ctl, wcnt);
             have_base = true;
             __threadfence_block();
-            const int16_t* __restrict__ src = tmp_rec + (size_t)o0 * PCS_POINT_SHORTS;
+            const int16_t* __restrict__ src = tmp_rec + (size_t)rank0 * PCS_POINT_SHORTS;
             int16_t* __restrict__ dst = out + (size_t)base * PCS_POINT_SHORTS;
             for (unsigned int i = threadIdx.x; i < emitted * PCS_POINT_SHORTS; i += kBktThreads) dst[i] = src[i];
         }
+        if (threadIdx.x == 0) cursor_next[b] = 0u;             // the next bucket call's cursors (nobody reads them in this launch)
         if (b == kBkt - 1u) {
             // the last bucket knows the total; it also clears the next call's control block (plan_for)
             if (!have_base) base = bkt_base(pub, b, gen, ctl, wcnt);
@@ -1471,6 +1614,12 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 const bool failed = __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                 ctl[1] = total;
                 if (out_points) *out_points = failed ? -1 : (int32_t)total;
+                // what a warm next call partitions by: as many buckets as P1 would take for this many partials, regions of twice
+                // a bucket's share (the splitters are quantiles; sensor noise and motion move the shares by far less)
+                unsigned int bn = kBkt;
+                while (bn > 32u && (unsigned long long)bn * 700ull > m) bn >>= 1;
+                reg_next[0] = bn;
+                reg_next[1] = 2u * (m / bn) + 64u;
             } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kCtlWords) {
                 if (zero_next) zero_next[threadIdx.x - 64] = 0u;
             }
@@ -1497,6 +1646,12 @@ struct Workspace {
     VoxelPartial* part_s;
     VoxelPartial* part_ws;              // the workspace's own partial array (w.part may be redirected to a caller's)
     int16_t* tmp_rec;
+    // warm calls ("regions"): per-bucket cursors and {buckets, slots per region}, two of each (bucket call k uses k & 1 and
+    // prepares the other for k + 1), and the regions themselves
+    unsigned int *cursor, *reg;
+    unsigned long long* keys_r;
+    VoxelPartial* part_r;
+    size_t region_slots, region_tail;
     size_t bytes;
 };
 
@@ -1508,6 +1663,8 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.ctl = (unsigned int*)take(2 * kCtlWords * sizeof(unsigned int));      // first: where they are must not depend on n
     w.ctl_next = w.ctl + kCtlWords;
     w.dcount = (unsigned int*)take(kBkt * 4);                                // bucket tail: published voxel counts, cleared WITH the control blocks
+    w.cursor = (unsigned int*)take(2 * kBkt * 4);                            // ... and so are the region cursors and sizes
+    w.reg = (unsigned int*)take(2 * 64 * 4);
     w.spl = (unsigned long long*)take(kBkt * 8);                             // (its place must not depend on n either)
     w.btotal = (unsigned int*)take(kBkt * 4);
     w.boff = (unsigned int*)take((kBkt + 1) * 4);
@@ -1528,6 +1685,13 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.btable = (unsigned int*)take(((n + kBktChunk - 1) / kBktChunk + 1) * (size_t)kBkt * 4);
     w.part_s = (VoxelPartial*)take(n * sizeof(VoxelPartial));
     w.tmp_rec = (int16_t*)take(n * (size_t)PCS_POINT_BYTES + 16);      // records of buckets that take several passes
+    // any cloud's regions fit: B x (2 (m / B) + 64) slots with m <= n partials in B <= kBkt buckets; behind them (region_tail) a
+    // stretch of n slots: a warm call's scratch for the ranges of split buckets (the cold chain's is keys_a / part, where a warm
+    // call keeps the partials that found their region full)
+    w.region_slots = 2 * n + 64 * (size_t)kBkt + 64;
+    w.region_tail = w.region_slots;
+    w.keys_r = (unsigned long long*)take((w.region_slots + n) * 8);
+    w.part_r = (VoxelPartial*)take((w.region_slots + n) * sizeof(VoxelPartial));
     w.part_ws = w.part;
     w.keys_s = w.keys_b;
     w.bucket_of = (unsigned short*)w.idx_a;
@@ -1550,6 +1714,8 @@ struct Plan {
     bool bucket = false;       // the bucket tail (5 launches) instead of the LSD sort + segmented mean (12)
     bool need_sample = false;  // bucket tail: the workspace holds no splitters for this leaf yet
     unsigned int gen = 1;      // bucket tail: tag of this call's published bucket counts (1 .. 63, never the previous call's)
+    bool regions = false;      // bucket tail, warm: the pre-aggregation fills the buckets' regions, the tail is ONE launch
+    unsigned int bpar = 0;     // bucket tail: which of the two cursor / region-size blocks this call uses
     RawKeys raw{nullptr, nullptr, 0u};      // exchange format: the first pass reads caller-held raw keys
 };
 
@@ -1604,10 +1770,13 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     uint8_t* base = static_cast<uint8_t*>(d_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
     pl.w = carve(base, n_points);
+#if PCS_BKT_TRACE
+    { char buf[32]; snprintf(buf, sizeof buf, "%llu", (unsigned long long)(uintptr_t)base); setenv("PCS_BKT_WS_BASE", buf, 1); }      // lab: tools/lab/bkt_regions.py
+#endif
     if (!ws.clean || ws.base != d_ws) {
         ws.clean = false;
         // (the control blocks and, right behind them, the bucket tail's published counts: their tags must not be garbage)
-        const hipError_t e = hipMemsetAsync(pl.w.ctl, 0, (size_t)((uint8_t*)(pl.w.dcount + kBkt) - (uint8_t*)pl.w.ctl), st);
+        const hipError_t e = hipMemsetAsync(pl.w.ctl, 0, (size_t)((uint8_t*)(pl.w.reg + 2 * 64) - (uint8_t*)pl.w.ctl), st);
         if (e != hipSuccess) return e;
         if (ws.base != d_ws) ws.spl_leaf = 0;                    // another workspace: whatever splitters it holds are not ours
         ws.base = d_ws; ws.phase = 0; ws.bkt_calls = 0; ws.clean = true;
@@ -1639,6 +1808,11 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
         pl.track_bits = false;
         pl.need_sample = ws.spl_leaf != leaf_mm;
         pl.gen = 1u + ws.bkt_calls % 63u;                 // differs from the previous bucket call's; a cleared workspace holds tag 0
+        pl.bpar = ws.bkt_calls & 1u;
+        // warm: the previous bucket call on this workspace left splitters for this leaf, region sizes and zeroed cursors behind
+        // (PCS_VOXEL_REGIONS=0: every bucket call takes the cold chain — read at every call, the tests run both)
+        const char* regions_env = getenv("PCS_VOXEL_REGIONS");
+        pl.regions = !(regions_env && regions_env[0] == '0') && !pl.need_sample && ws.bkt_calls > 0;
     }
     return hipSuccess;
 }
@@ -1651,13 +1825,19 @@ hipError_t bucket_tail(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_
     const unsigned int grid = std::max(1u, std::min(max_chunks, kBktGrid));
     if (pl.need_sample)
         hipLaunchKernelGGL(pcs_vox_bkt_sample_kernel, dim3(1), dim3(1024), 0, st, w.keys_a, w.ctl, pl.raw, w.spl);
+    if (!pl.regions) {
     hipLaunchKernelGGL(pcs_vox_bkt_hist_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.ctl, pl.raw, w.spl, w.btable, w.bucket_of);
     hipLaunchKernelGGL(pcs_vox_bkt_colscan_kernel, dim3(kBkt / 4), dim3(256), 0, st, w.btable, w.ctl, w.btotal);
     hipLaunchKernelGGL(pcs_vox_bkt_scatter_kernel, dim3(grid), dim3(kBktThreads), 0, st, w.keys_a, w.part, w.bucket_of, w.ctl, pl.raw,
                        w.btable, w.btotal, w.keys_s, w.part_s, w.boff);
+    }
     hipLaunchKernelGGL(pcs_vox_bkt_reduce_kernel, dim3(kBkt), dim3(kBktThreads), 0, st, w.keys_s, w.part_s, w.boff, w.ctl, d_out,
-                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next, w.keys_a, w.part_ws,
-                       (long long*)(PCS_BKT_TRACE && getenv("PCS_BKT_TRACE_PTR") ? strtoull(getenv("PCS_BKT_TRACE_PTR"), nullptr, 0) : 0ull));
+                       w.tmp_rec, w.dcount, pl.gen, w.spl, d_out_points, w.ctl_next, pl.regions ? w.keys_r + w.region_tail : w.keys_a,
+                       pl.regions ? w.part_r + w.region_tail : w.part_ws,
+                       (long long*)(PCS_BKT_TRACE && getenv("PCS_BKT_TRACE_PTR") ? strtoull(getenv("PCS_BKT_TRACE_PTR"), nullptr, 0) : 0ull),
+                       pl.regions ? 1u : 0u, w.keys_r, w.part_r, (unsigned int)std::min<size_t>(w.region_slots, 0xFFFFFFFFu),
+                       w.reg + 64 * pl.bpar, w.reg + 64 * (pl.bpar ^ 1u), w.cursor + kBkt * pl.bpar, w.cursor + kBkt * (pl.bpar ^ 1u),
+                       w.keys_a, w.part, w.bucket_of, w.keys_s, w.part_s);
     return hipGetLastError();
 }
 
@@ -1695,6 +1875,16 @@ hipError_t sort_and_reduce(const Plan& pl, uint32_t n_points, int16_t* d_out, in
     hipLaunchKernelGGL(pcs_voxel_fixup_kernel, dim3(fix_grid), dim3(256), 0, st, w.ctl, w.lead, w.trail, d_out, w.super, d_out_points,
                        w.ctl_next);
     return hipGetLastError();
+}
+
+// What a pre-aggregation needs to fill the buckets' regions itself (warm bucket tail).
+void stage_regions(const Plan& pl, VoxelStage& vs)
+{
+    const Workspace& w = pl.w;
+    vs.regions = pl.regions ? 1u : 0u;
+    vs.region_slots = (uint32_t)std::min<size_t>(w.region_slots, 0xFFFFFFFFu);
+    vs.spl = w.spl; vs.reg = w.reg + 64 * pl.bpar; vs.cursor = w.cursor + kBkt * pl.bpar;
+    vs.keys_r = w.keys_r; vs.part_r = w.part_r; vs.bucket_of = w.bucket_of;
 }
 
 // A call that was enqueued completely hands the other control block to the next one; anything else leaves the workspace
@@ -1736,12 +1926,14 @@ hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const 
         vs.keys = w.keys_a; vs.idx = pl.bucket ? nullptr : w.idx_a; vs.part = w.part; vs.n_runs = w.ctl;
         vs.leaf = (uint32_t)leaf_mm; vs.div_inv = pl.dv.inv; vs.div_c = pl.dv.c; vs.bits = pl.bits; vs.idx_bits = pl.idx_bits;
         vs.track_bits = pl.track_bits ? 1u : 0u;
+        stage_regions(pl, vs);
         e = launch_payload_voxel_partials(d_payload, n_points, d_n_points, vs, st);
         if (e != hipSuccess) return finish_call(*ws, e);
     } else {
         // the 1024-lane readers (payloads that are only 2- or 4-byte aligned) do not record which key bits vary: every bit
-        // counts, no pass is skipped
+        // counts, no pass is skipped; nor do they fill regions
         pl.track_bits = false;
+        pl.regions = false;
         if (wide_ok && n_points >= 2 && ((uintptr_t)d_payload & 3u) == 0u)
             hipLaunchKernelGGL(pcs_voxel_partials_kernel<true>, agg_grid, dim3(kAggThreads), 0, st, d_payload, n_points, d_n_points, pl.dv,
                                pl.bits, pl.idx_bits, w.keys_a, w.idx_a, w.part, w.ctl);
@@ -1764,6 +1956,7 @@ hipError_t voxel_begin(uint32_t capacity_points, int leaf_mm, void* d_ws, size_t
     stage->leaf = (uint32_t)leaf_mm; stage->div_inv = pl.dv.inv; stage->div_c = pl.dv.c;
     stage->bits = pl.bits; stage->idx_bits = pl.idx_bits;
     stage->track_bits = pl.track_bits ? 1u : 0u;
+    stage_regions(pl, *stage);
     return hipSuccess;
 }
 
@@ -1793,6 +1986,7 @@ hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d
     stage->keys = d_keys; stage->idx = nullptr; stage->part = d_partials; stage->n_runs = d_count;
     stage->leaf = (uint32_t)leaf_mm; stage->div_inv = dv.inv; stage->div_c = dv.c;
     stage->bits = bits; stage->idx_bits = 0u; stage->track_bits = 0u;
+    stage->regions = 0u;
     return hipSuccess;
 }
 
@@ -1810,6 +2004,7 @@ hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const vo
     if (e != hipSuccess) return e;
     pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
     pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place
+    pl.regions = false;                    // caller-held partials: nobody filled regions
     pl.raw = RawKeys{d_keys, d_n_partials, n_partials};
     return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st), pl.bucket ? leaf_mm : 0);
 }

@@ -45,6 +45,9 @@ constexpr int kSlots = 2048, kProbe = 12;
 // voxel keys written, [34..35] OR of their complements (which key bits vary at all: pcs_voxel.hip's sort drops the others)
 constexpr unsigned int kVoxCtlOr = 32, kVoxCtlOrn = 34;
 constexpr unsigned long long kEmptyKey = ~0ull;
+// The bucket tail's partition (pcs_voxel.hip): at most kVoxBuckets key ranges. The pre-aggregation kernels know the number because,
+// on a warm workspace, they place their partials into the buckets' regions themselves (VoxelStage::regions).
+constexpr unsigned int kVoxBuckets = 1024;
 
 // Probe sequence of a key: double hashing (start and an odd stride from one multiplicative hash), so a crowded table
 // costs 1/(1 - load) probes on average instead of linear probing's clusters — at 2/3 load a key fails to find a slot

@@ -9,12 +9,15 @@ from pointcloud_stitching_amd.api import PcsContext, PcsError
 from pointcloud_stitching_amd.types import FLAG_CUTOFF, FLAG_CUTOFF_COMPAT, FLAG_DROP_INVALID, FLAG_FORCE_IEEE
 
 
-@pytest.fixture(autouse=True, params=["bucket", "lsd"])
+@pytest.fixture(autouse=True, params=["bucket", "bucket-cold", "lsd"])
 def voxel_tail(request, monkeypatch):
-    """Every test of this file runs with each of the two tails of the voxel pipeline forced (PCS_VOXEL_TAIL is read at every
-    call): the bucket tail (one partition by key splitters + per-bucket LDS tables, 5 launches) and the LSD radix sort +
-    segmented mean (12 launches). Same bytes, whatever the leaf and the input."""
-    monkeypatch.setenv("PCS_VOXEL_TAIL", request.param)
+    """Every test of this file runs with each tail of the voxel pipeline forced (PCS_VOXEL_TAIL / PCS_VOXEL_REGIONS are read at
+    every call): the bucket tail as it runs by default — its first call on a context partitions the partials by key splitters
+    (histogram, column scan, scatter: 5 launches), every later one has the pre-aggregation fill the buckets' regions itself (2
+    launches) —, the bucket tail held to the cold chain, and the LSD radix sort + segmented mean (12 launches). Same bytes,
+    whatever the leaf and the input."""
+    monkeypatch.setenv("PCS_VOXEL_TAIL", "bucket" if request.param.startswith("bucket") else request.param)
+    monkeypatch.setenv("PCS_VOXEL_REGIONS", "0" if request.param == "bucket-cold" else "1")
     return request.param
 
 
@@ -541,6 +544,33 @@ def test_bucket_tail_stale_splitters_and_crowded_buckets(oracle, voxel_tail):
             got = ctx.voxel_grid(p, lf)
             want = oracle.voxel_grid(p, lf)
             assert got.shape == want.shape and (got == want).all(), (name, lf, voxel_tail)
+
+
+@pytest.mark.gpu
+def test_bucket_regions_that_overflow_or_do_not_fit(oracle, voxel_tail):
+    """Warm bucket calls: the pre-aggregation puts every partial into its bucket's region — sized, like the splitters, by the
+    PREVIOUS call on the context. What can go wrong with that, on one context, every result against the oracle: (1) the regions
+    the previous (larger) cloud asked for do not fit this call's smaller workspace carve: nothing goes to a region, every partial
+    takes the general list and every bucket gathers its own; (2) part of the cloud grows more than twofold — a dense slab of
+    distinct voxels appears inside the old key range: those buckets' regions fill up, the rest overflows to the list, is
+    gathered, and the buckets (beyond 8192 partials) are split into key ranges over both stretches; (3) the slab disappears again
+    (regions mostly empty); (4) the same cloud twice (steady state)."""
+    rng = np.random.default_rng(4242)
+    def cloud(n, lo, hi):
+        p = np.zeros((n, 5), np.int16)
+        p[:, :3] = rng.integers(lo, hi, (n, 3))
+        p[:, 3] = rng.integers(0, 65536, n).astype(np.uint16).view(np.int16)
+        p[:, 4] = rng.integers(0, 256, n)
+        return p
+    base = cloud(300000, -2000, 2000)
+    slab = np.concatenate([base, cloud(300000, -600, 600)])
+    leaf = 16
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        for name, p in (("slab", slab), ("base", base), ("base", base), ("slab", slab), ("slab", slab), ("base", base)):
+            got = ctx.voxel_grid(p, leaf)
+            want = oracle.voxel_grid(p, leaf)
+            assert got.shape == want.shape and (got == want).all(), (name, voxel_tail)
 
 
 @pytest.mark.gpu

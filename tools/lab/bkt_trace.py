@@ -31,4 +31,10 @@ for r, sel in (("first round (b < 512)", slice(0, 512)), ("second round (b >= 51
         print(f"   {n:50s} median {np.median(d[:, i]):6.2f}  p90 {np.percentile(d[:, i], 90):6.2f} us")
     print("   inside 'sorted': wave sort %.2f, park + barrier %.2f, rank + srt + barrier %.2f us" % (
         np.median(t[sel, 7] - t[sel, 3]), np.median(t[sel, 8] - t[sel, 7]), np.median(t[sel, 4] - t[sel, 8])))
+# who holds the others up: a bucket's first voxel is known once every lower-numbered bucket has published its count (stamp 3)
+pub = t[:, 3] - t0
+late = np.argsort(-pub[:512])[:6]
+print("latest publishers of the first round:", [(int(b), round(float(t[b, 0] - t0), 1), round(float(pub[b]), 1)) for b in late], "(bucket, start, published at: us)")
+st = t[:, 0] - t0
+print("start time by bucket: b=0 %.1f, 63 %.1f, 127 %.1f, 255 %.1f, 383 %.1f, 511 %.1f, 512 %.1f, 767 %.1f, 1023 %.1f us" % tuple(st[[0, 63, 127, 255, 383, 511, 512, 767, 1023]]))
 ctx.close()
