@@ -1366,6 +1366,20 @@ def main():
                         del os.environ["PCS_VOXEL_TAIL"]
                     else:
                         os.environ["PCS_VOXEL_TAIL"] = tail_default
+                # ... and with the bucket tail held to its cold chain (every call partitions: histogram, column scan, scatter, reduce)
+                regions_default = os.environ.get("PCS_VOXEL_REGIONS")
+                os.environ["PCS_VOXEL_REGIONS"] = "0"
+                try:
+                    for _ in range(3):
+                        onecall5()
+                    torch.cuda.synchronize(dev)
+                    ms_o5_cold = timed(onecall5, 30, ctx5)
+                finally:
+                    if regions_default is None:
+                        del os.environ["PCS_VOXEL_REGIONS"]
+                    else:
+                        os.environ["PCS_VOXEL_REGIONS"] = regions_default
+                bucket_default = tail_default in (None, "bucket")
                 out["config5_one_gpu"] = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
                                           "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
                                           "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
@@ -1373,15 +1387,19 @@ def main():
                                           "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
                                           "one_call": {"ms_per_frame_set": round(ms_o5, 4), "value": round(S5 * n5 / ms_o5 / 1e3, 1),
                                                        "voxels": nvox5_one, "oracle_digest_ok": bool(gold5 is not None),
-                                                       "kernels_per_call": 5 if tail_default in (None, "bucket") else 13,
+                                                       "kernels_per_call": (2 if regions_default != "0" else 5) if bucket_default else 13,
+                                                       "cold_chain_ms_per_frame_set": round(ms_o5_cold, 4),
                                                        "lsd_tail_ms_per_frame_set": round(ms_o5_lsd, 4),
                                                        "algorithmic_bytes": int(5 * S5 * n5 + 10 * nvox5_one),
                                                        "frac": round((5 * S5 * n5 + 10 * nvox5_one) / (ms_o5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                        "note": "pcs_process_frames_voxel_device: the same voxel cloud straight from the "
-                                                               "rasters; the stitched cloud is never written to HBM. Pre-aggregation + the bucket "
-                                                               "tail (partition histogram, column scan, scatter, per-bucket reduce: 5 kernels per "
-                                                               "call); lsd_tail_*: the round-4 tail (13 kernels) forced for the same call; the "
-                                                               "timed loop's cloud is hashed against the committed oracle digest"},
+                                                               "rasters; the stitched cloud is never written to HBM. Warm bucket tail: the "
+                                                               "pre-aggregation puts every partial into its bucket's region (the previous "
+                                                               "call's splitters), one reduce launch follows: 2 kernels per call. "
+                                                               "cold_chain_*: PCS_VOXEL_REGIONS=0, every call partitions (histogram, column "
+                                                               "scan, scatter, reduce: 5 kernels); lsd_tail_*: the round-4 tail (13 kernels) "
+                                                               "forced for the same call; the timed loop's cloud is hashed against the "
+                                                               "committed oracle digest"},
                                           "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                           "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
                                                   "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}

@@ -308,11 +308,16 @@ int pcs_voxel_grid_device_counted(pcs_ctx* ctx, const int16_t* d_payload, const 
                                   int leaf_mm, int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
 /* Which tail the voxel calls of this context take behind the pre-aggregation. Both give the same bytes for every input:
  *   PCS_VOXEL_TAIL_BUCKET  one partition of the partials into <= 1024 key ranges + one workgroup per range with an LDS table
- *                          (4 launches; built for the ~1 M partials of BASELINE configs[4] at leaves of a few centimetres and up);
+ *                          (built for the ~1 M partials of BASELINE configs[4] at leaves of a few centimetres and up). The first
+ *                          call of a context for a leaf partitions in launches of its own (4 in all); every later call of
+ *                          pcs_voxel_grid_device[_counted] / pcs_process_frames_voxel_device has the pre-aggregation put its
+ *                          partials into the ranges' regions itself — sized, like the splitters, by the call before — and the tail
+ *                          is ONE launch. A cloud that moved costs that call speed (regions overflow into a list that is gathered),
+ *                          never bytes. PCS_VOXEL_REGIONS=0 (read at every call) keeps every call on the first call's chain;
  *   PCS_VOXEL_TAIL_LSD     LSD radix sort of (key, partial) + segmented mean (12 launches; the better tool for many millions of
  *                          partials, and the lighter neighbour when the tail runs BESIDE another frame-set's pre-aggregation on the
  *                          same GPU: libpcs_node picks it for its root when one GPU holds every camera);
- *   PCS_VOXEL_TAIL_AUTO    (default) by the leaf: bucket from 40 mm.
+ *   PCS_VOXEL_TAIL_AUTO    (default) by the leaf: bucket from 34 mm.
  * The environment variable PCS_VOXEL_TAIL=bucket|lsd, read at every call, overrides both (the test-suite runs every voxel
  * test under each).                                                                                                      */
 #define PCS_VOXEL_TAIL_AUTO   0

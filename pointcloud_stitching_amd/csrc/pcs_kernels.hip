@@ -2194,7 +2194,11 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         // 0.28 / 0.33, 100 mm 0.26 / 0.23 / 0.23 / 0.25, 200 mm 0.26 / 0.23 / 0.23 / 0.24: two squares (128 x 64) per table
         // from 30 mm up, one below. (Voxels per 128 x 64 patch on the synthetic scene: 780 / 240 / 80 / 30 at 25 / 50 /
         // 100 / 200 mm.)
-        const uint64_t by_leaf = vs.leaf >= 30 ? 2 : 1;
+        // A warm bucket call (vs.regions) ends every workgroup with a dearer flush (bucket search, a returning add per bucket it
+        // touches, scattered writes) and hands its partials to a tail that is one launch: twice the patch per table pays from
+        // 45 mm up — 16 x 1080p, ms per call with 2 / 4 / 8 squares: 40 mm 0.224 / 0.228 / -, 50 mm 0.188 / 0.185 / 0.236,
+        // 100 mm 0.164 / 0.156 / 0.168, 200 mm 0.151 / 0.155 / 0.155.
+        const uint64_t by_leaf = vs.leaf >= 30 ? ((vs.regions && vs.leaf >= 45 && vs.leaf < 150) ? 4 : 2) : 1;
         rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);
         rounds = rounds >= 8 ? 8 : rounds >= 4 ? 4 : rounds >= 2 ? 2 : 1;
         if (env_rounds > 0) rounds = env_rounds >= 8 ? 8 : env_rounds >= 4 ? 4 : env_rounds >= 2 ? 2 : 1;

@@ -1732,7 +1732,9 @@ bool choose_bucket_tail(int leaf_mm, int pref)
     }
     if (pref == 1) return true;
     if (pref == 2) return false;
-    return leaf_mm >= 40;      // 16 x 1080p synthetic scene, ms per call bucket / LSD: 32 mm 0.333 / 0.292, 40 mm 0.253 / 0.259, 50 mm 0.197 / 0.226
+    // 16 x 1080p synthetic scene, ms per warm call bucket / LSD: 20 mm 0.601 / 0.567, 25 mm 0.443 / 0.458, 28 mm 0.391 / 0.430,
+    // 32 mm 0.303 / 0.291, 36 mm 0.233 / 0.272, 40 mm 0.220 / 0.257, 50 mm 0.184 / 0.230, 100 mm 0.156 / 0.194
+    return leaf_mm >= 34;
 }
 
 // The constants of floor(v / leaf) + bias for one leaf (pcs_voxel_agg.h: VoxelDiv) + the bits one axis takes.

@@ -28,13 +28,15 @@ RUNS[config5]="python $PWD/bench.py --workload config5 --steps 60 --warmup 5 --n
 # the one-process node route (libpcs_node) on this box's one GPU: 8 virtual peers, the exchange = RCCL self send/recv pairs
 RUNS[node_stitch]="python $PWD/bench.py --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps $STEPS --warmup 20"
 RUNS[node_config5]="python $PWD/bench.py --workload config5 --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps 60 --warmup 5"
-# BASELINE configs[4] in ONE call from the rasters (pcs_process_frames_voxel_device, 50 mm): front end + the bucket tail; and with the LSD tail
+# BASELINE configs[4] in ONE call from the rasters (pcs_process_frames_voxel_device, 50 mm): front end + the warm bucket tail (2 launches
+# per call); the bucket tail held to its cold chain (5); the LSD tail (13)
 RUNS[voxel_one_call]="python $PWD/tools/voxel_probe.py 50 80"
+RUNS[voxel_one_call_cold]="env PCS_VOXEL_REGIONS=0 python $PWD/tools/voxel_probe.py 50 80"
 RUNS[voxel_one_call_lsd]="env PCS_VOXEL_TAIL=lsd python $PWD/tools/voxel_probe.py 50 80"
 # every leg of the default line (incl. centre_transform, config5_one_gpu, color_1080p): one row per kernel of the library
 RUNS[all_legs]="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-host-api"
-ORDER=${PROFILE_RUNS:-"dense all_legs drop_invalid cutoff pack pack_batch batch batch_drop_invalid voxel voxel_one_call voxel_one_call_lsd config5 node_stitch node_config5"}
-PMC_ORDER=${PROFILE_PMC_RUNS:-"dense all_legs voxel_one_call voxel_one_call_lsd config5"}
+ORDER=${PROFILE_RUNS:-"dense all_legs drop_invalid cutoff pack pack_batch batch batch_drop_invalid voxel voxel_one_call voxel_one_call_cold voxel_one_call_lsd config5 node_stitch node_config5"}
+PMC_ORDER=${PROFILE_PMC_RUNS:-"dense all_legs voxel_one_call voxel_one_call_cold voxel_one_call_lsd config5"}
 cd /tmp
 for R in $ORDER; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -- ${RUNS[$R]} > $OUT/stats_$R.log 2>&1
