@@ -833,6 +833,12 @@ void pcs_voxel_fixup_kernel(unsigned int* __restrict__ ctl, const BlockPiece* __
 // previous call on this workspace: G1 has every bucket's sorted keys and rewrites, in place, the splitters that fall into
 // its share of the partials — consecutive frame-sets of a camera rig differ by sensor noise. A workspace without splitters
 // for this leaf runs a one-workgroup sample sort first (S0: 4096 evenly spaced keys, bitonic in LDS).
+// WARM CALLS: the splitters of a call are the previous call's, known before it starts. From a workspace's second bucket call on
+// the pre-aggregation (pcs_kernels.hip: vox_table_flush_regions) therefore does P1 - P3 itself: every workgroup finds its
+// partials' buckets and appends them to the buckets' REGIONS (B regions of `cap` slots in keys_r / part_r, filled through one
+// cursor per bucket; B and cap left behind by the previous call's G1 together with zeroed cursors — two sets, used alternately).
+// The tail is then G1 alone. A partial that finds its region full goes to the general list (keys_a / part, tagged with its bucket
+// in bucket_of), and the bucket's workgroup gathers its own from there first (bkt_gather): regions only ever cost speed.
 // SKEW / STALE SPLITTERS cost speed, never bits: a bucket whose distinct voxels do not fit the 1024-slot table is worked
 // off in several passes over key sub-ranges [L, T): when the table fills up, T drops to the median of the keys seen so far
 // and the pass restarts; every pass emits its voxels in key order behind the previous pass's. A hot voxel (thousands of
@@ -1216,12 +1222,12 @@ struct BktOverflow {
 };
 // A warm call's bucket whose region was full (its share of the cloud more than doubled since the previous call — the cloud moved):
 // the partials that did not fit sit in the general list, in no order, tagged with their bucket. The workgroup copies its own
-// to gk / gp [g0, g0 + expect): eight tags per lane and step (one 16-byte load), places by a returning LDS add. Every
+// to gk / gp from g0 on (cursor[b] - cap of them): eight tags per lane and step (one 16-byte load), places by a returning LDS add. Every
 // overflowing bucket reads all tags — a stale call pays for that once, like the cold path's split of a giant bucket.
 __device__ __forceinline__ void bkt_gather(const unsigned long long* __restrict__ lk, const VoxelPartial* __restrict__ lp,
                                         const unsigned short* __restrict__ ids, unsigned int n_list, unsigned int b,
                                         unsigned long long* __restrict__ gk, VoxelPartial* __restrict__ gp, unsigned int g0,
-                                        unsigned int expect, unsigned int* cur)
+                                        unsigned int* cur)
 {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     if (threadIdx.x == 0) *cur = 0u;
@@ -1258,7 +1264,6 @@ __device__ __forceinline__ void bkt_gather(const unsigned long long* __restrict_
     }
     __threadfence_block();
     __syncthreads();
-    (void)expect;
 }
 __device__ __forceinline__ unsigned int bkt_presplit(const unsigned long long* __restrict__ keys_s, const VoxelPartial* __restrict__ part_s,
                                                   unsigned long long* __restrict__ kscr, VoxelPartial* __restrict__ pscr,
@@ -1384,7 +1389,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
             o0 = boff[b]; n_a = n = boff[b + 1u] - o0; rank0 = o0;
         }
         // (over_below: the overflow of the buckets before this one = where, in the gather space, its own goes)
-        if (n > n_a) bkt_gather(kscr_list, pscr_list, ov_ids, m_over, b, gath_k, gath_p, over_here, n - n_a, scur);      // (uniform)
+        if (n > n_a) bkt_gather(kscr_list, pscr_list, ov_ids, m_over, b, gath_k, gath_p, over_here, scur);      // (uniform)
         const BktOverflow ov{gath_k, gath_p, over_here, n - n_a};
         unsigned int emitted = 0, base = 0, fed = 0;
         bool have_base = false, published = false;
