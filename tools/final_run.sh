@@ -24,11 +24,14 @@ python bench.py --workload config5 --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --ste
 python bench.py --gpus 8 --node-devices 0,0,0,0,0,0,0,0 --steps 100 --warmup 10 > $OUT/bench_node8v.json 2>/dev/null
 python bench.py --route node --gpus 1 --steps 200 --warmup 20 > $OUT/bench_node1.json 2>/dev/null
 python bench.py --gpus 3 --steps 20 --warmup 5 > $OUT/bench_gpus3_folded.json 2>/dev/null
-for t in default lsd; do
+# the voxel pipeline by leaf: as shipped (warm bucket tail from 34 mm, LSD below), the bucket tail held to its cold chain, the LSD tail
+for t in default cold lsd; do
+  unset PCS_VOXEL_TAIL PCS_VOXEL_REGIONS
   if [ $t = lsd ]; then export PCS_VOXEL_TAIL=lsd; fi
-  python tools/voxel_probe.py 20,32,40,50,100,200 60 | grep leaf
+  if [ $t = cold ]; then export PCS_VOXEL_REGIONS=0; fi
+  python tools/voxel_probe.py 20,32,36,40,50,100,200 60 | grep leaf
 done > $OUT/voxel_by_leaf.txt 2>&1
-unset PCS_VOXEL_TAIL
-PCS_VOXEL_TAIL=bucket python tools/lab/bkt_cliff.py > $OUT/bkt_cliff.txt 2>&1; PCS_VOXEL_TAIL=lsd python tools/lab/bkt_cliff.py >> $OUT/bkt_cliff.txt 2>&1
+unset PCS_VOXEL_TAIL PCS_VOXEL_REGIONS
+{ PCS_VOXEL_TAIL=bucket python tools/lab/bkt_cliff.py; PCS_VOXEL_TAIL=bucket PCS_VOXEL_REGIONS=0 python tools/lab/bkt_cliff.py | sed 's/\[bucket\]/[bucket, cold chain]/'; PCS_VOXEL_TAIL=lsd python tools/lab/bkt_cliff.py; } > $OUT/bkt_cliff.txt 2>&1
 bash tools/profile_gpu.sh $TAG 200 > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log
 echo final_run done
