@@ -65,17 +65,35 @@ while time.time() - t0 < budget:
         d_nv = ctx.device_malloc(4)
         for leaf in rng.choice([1, 2, 5, 13, 29, 30, 36, 50, 77, 200, 1000, 32767], 3, replace=False):
             leaf = int(leaf)
-            ctx.process_frames_voxel_device(dd, dc, leaf, d_vox, n_max * 5, d_nv)
-            ctx.synchronize()
-            nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
-            got = np.empty(max(int(nv[0]), 1) * 5, np.int16); ctx.memcpy_d2h(got, d_vox)
-            got = got[:int(nv[0]) * 5].reshape(-1, 5)
-            want = O.voxel_grid(stitched, leaf)
-            runs += 1
-            patch_runs += int(patch and stride == 1)
-            if got.shape != want.shape or (got != want).any():
-                bad += 1
-                print("MISMATCH", shapes, flags, stride, leaf, got.shape, want.shape, flush=True)
+            # the leaf's first call is the bucket tail's cold chain; then (two times in three) one camera sees something else —
+            # another scene, noise, a wall — and the same leaf is called again: a WARM call on a cloud that moved, and once more
+            # on the same rasters (steady state)
+            scenes = [(stitched, None)]
+            if rng.random() < 0.67:
+                s2 = int(rng.integers(0, n))
+                w2, h2 = shapes[s2]
+                kind = rng.random()
+                d2 = (S.synth_depth(w2, h2, s2, seed=int(rng.integers(1, 1 << 30))) if kind < 0.5 else
+                      rng.integers(0, 65536, w2 * h2, dtype=np.uint16) if kind < 0.75 else np.full(w2 * h2, int(rng.integers(0, 6000)), np.uint16))
+                depth2 = list(depth); depth2[s2] = np.ascontiguousarray(d2, np.uint16).reshape(-1)
+                st2, _ = O.process_frames(cfgs, depth2, color, flags, stride)
+                scenes += [(st2, (s2, depth2[s2])), (st2, None)]
+            for want_cloud, change in scenes:
+                if change is not None:
+                    ctx.memcpy_h2d(dd[change[0]], change[1])
+                ctx.process_frames_voxel_device(dd, dc, leaf, d_vox, n_max * 5, d_nv)
+                ctx.synchronize()
+                nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
+                got = np.empty(max(int(nv[0]), 1) * 5, np.int16); ctx.memcpy_d2h(got, d_vox)
+                got = got[:int(nv[0]) * 5].reshape(-1, 5)
+                want = O.voxel_grid(want_cloud, leaf)
+                runs += 1
+                patch_runs += int(patch and stride == 1)
+                if got.shape != want.shape or (got != want).any():
+                    bad += 1
+                    print("MISMATCH", shapes, flags, stride, leaf, got.shape, want.shape, flush=True)
+            if len(scenes) > 1:      # back to the first scene for the next leaf (and for the sharded merge below)
+                ctx.memcpy_h2d(dd[s2], depth[s2])
     # the exchange format (config 5 sharded): the same cameras split over 1..n contexts, every shard's partials appended to the
     # root's arrays in a random shard order, one sort + segmented mean over all of them
     if n >= 1:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak of the voxel-grid pipeline on the GPU box: random payloads (uniform clouds, image-like surfaces with
-long runs, clustered blobs, extreme coordinates), random sizes up to 400 k points, leaves from 1 mm to 32767 mm, host and
-counted-device entry points, aligned and 2-byte-skewed payloads — every result compared bit for bit with the oracle.
+long runs, clustered blobs, extreme coordinates), random sizes up to 400 k points, leaves from 1 mm to 32767 mm (half of the calls
+with the leaf of the call before: warm calls of the bucket tail on an unrelated cloud), host and counted-device entry points,
+aligned and 2-byte-skewed payloads — every result compared bit for bit with the oracle.
 
     python tools/voxel_soak.py [seconds=120] [seed=1]
 """
@@ -58,6 +59,9 @@ with PcsContext(cfgs) as ctx:
     while time.time() - t0 < budget:
         n = int(rng.integers(1, cap)) if rng.random() < 0.5 else int(rng.choice([1, 2, 3, 255, 256, 257, 8191, 8192, 8193]))
         leaf = int(rng.choice([1, 2, 7, 10, 50, 64, 200, 1000, 5000, 32767, int(rng.integers(1, 32768))]))
+        if trials and rng.random() < 0.5:
+            leaf = prev_leaf            # the same leaf as the call before: a WARM call of the bucket tail (regions sized and split by
+        prev_leaf = leaf                # the previous, unrelated cloud: overflow into the general list, gathers, split buckets)
         p = payload(n)
         want = O.voxel_grid(p, leaf)
         mode = rng.integers(0, 3)
