@@ -1244,6 +1244,12 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 #ifndef PCS_VOX_THREADS
 #define PCS_VOX_THREADS 512
 #endif
+#ifndef PCS_VOX_SKIP
+#define PCS_VOX_SKIP 1
+#endif
+#ifndef PCS_VOX_REMAP
+#define PCS_VOX_REMAP 1
+#endif
 #ifndef PCS_VOX_SLOTS
 #define PCS_VOX_SLOTS 2048
 #endif
@@ -1645,10 +1651,21 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
 template <bool DD, bool CD, class Mth>
 __global__ __launch_bounds__(kVoxThreads)
 void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
-                                     VoxelStage vs, int rounds, int rx, int crowded)
+                                     VoxelStage vs, int rounds, int rx, int crowded, int gx, int gy)
 {
     PCS_VOX_TABLE_DECL;
-    const int s = blockIdx.y;
+    // Which stream and which patch of it. Workgroups start in the order of their linear id and the LAST row of patches of a
+    // raster whose height is no multiple of the patch is short work (1080 rows = 8 patches of 128 rows + 56 rows): all the
+    // streams' full rows come first, the short rows of all streams at the very end, where they level the chip's last round
+    // of workgroups instead of holding up a full patch each (gx x gy = the launch's patch grid, from the largest raster).
+    int s = blockIdx.y;
+    uint32_t patch = blockIdx.x;
+    if (PCS_VOX_REMAP && rx && gy > 1) {
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t head = (uint32_t)gx * (uint32_t)(gy - 1), n_head = head * gridDim.y;
+        if (lin < n_head) { s = (int)(lin / head); patch = lin % head; }
+        else { const uint32_t r = lin - n_head; s = (int)(r / (uint32_t)gx); patch = head + r % (uint32_t)gx; }
+    }
     const StreamParams& P = params[stream0 + s];
     request_constants(P, fp.depth[s], fp.color[s]);
     const uint32_t n = P.n_points;
@@ -1660,8 +1677,8 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     const uint32_t W = (uint32_t)P.W, Hh = n / W;
     const uint32_t patches_x = rx ? (W + 64u * (uint32_t)rx - 1u) / (64u * (uint32_t)rx) : 1u;
     const uint32_t ry = rx ? (uint32_t)rounds / (uint32_t)rx : 1u;
-    const uint32_t px = rx ? blockIdx.x % patches_x : 0u, py = rx ? blockIdx.x / patches_x : 0u;
-    const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
+    const uint32_t px = rx ? patch % patches_x : 0u, py = rx ? patch / patches_x : 0u;
+    const uint32_t tile0 = patch * (kVoxRoundPoints * (uint32_t)rounds);
     if (rx ? (py * kVoxRows * ry >= Hh) : (tile0 >= n)) return;
     const uint8_t* __restrict__ color = fp.color[s];
     DepthSource<DD, CD, Mth> src{fp.depth[s]};
@@ -1670,8 +1687,19 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     for (int round = 0; round < rounds; round++) {
         uint32_t i0;
         if (rx) {
-            const uint32_t row = (py * ry + (uint32_t)round / (uint32_t)rx) * kVoxRows + (threadIdx.x >> 3);
-            const uint32_t col = (px * (uint32_t)rx + (uint32_t)round % (uint32_t)rx) * 64u + (threadIdx.x & 7u) * 8u;
+            const uint32_t row0 = (py * ry + (uint32_t)round / (uint32_t)rx) * kVoxRows;
+            const uint32_t col0 = (px * (uint32_t)rx + (uint32_t)round % (uint32_t)rx) * 64u;
+            if (PCS_VOX_SKIP) {
+                // A square below the raster ends the workgroup (the rounds go down the patch), one beside it is passed over:
+                // without this its 512 lanes deproject, pack and hash nothing at the full price (two of the four rounds of
+                // every workgroup in the last patch row of a 1080-row raster). Uniform over the workgroup, so the barriers of
+                // a crowded round stay matched; a WAVEFRONT whose 8 rows lie below the raster passes where there are none.
+                if (row0 >= Hh) break;
+                if (col0 >= W) continue;
+                if (!crowded && row0 + ((threadIdx.x >> 6) << 3) >= Hh) continue;
+            }
+            const uint32_t row = row0 + (threadIdx.x >> 3);
+            const uint32_t col = col0 + (threadIdx.x & 7u) * 8u;
             i0 = (row < Hh && col < W) ? row * W + col : n;        // W % 8 == 0: a lane is inside the row or outside it
         } else {
             i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
@@ -2210,16 +2238,19 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     }
     rounds *= kSub;
     dim3 grid;
+    int gx = 1, gy = 1;
     if (rx) {
         const uint32_t ry = (uint32_t)rounds / (uint32_t)rx;
-        grid = dim3(((max_w + 64u * rx - 1) / (64u * rx)) * ((max_h + kVoxRows * ry - 1) / (kVoxRows * ry)), (unsigned)n_launch, 1);
+        gx = (int)((max_w + 64u * rx - 1) / (64u * rx));
+        gy = (int)((max_h + kVoxRows * ry - 1) / (kVoxRows * ry));
+        grid = dim3((unsigned)gx * (unsigned)gy, (unsigned)n_launch, 1);
     } else {
         const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
         grid = dim3((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
     }
     // no stream of the context has a distortion model (or the half-pixel texture convention): the instantiation without
     // their (uniform, but not free in a VALU-bound kernel) tests
-#define L(D, M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<D, D, M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx, vs.leaf < 30u ? 1 : 0)
+#define L(D, M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<D, D, M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx, vs.leaf < 30u ? 1 : 0, gx, gy)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
     if (math == MathSel::Ieee) L(true, IeeeMath);
     else if (any_dist) { if (ident) L(true, CertMath<true>); else L(true, CertMath<false>); }
