@@ -83,6 +83,7 @@ __device__ __forceinline__ int32_t cvt_sat(float f)
 // ignores NaN); the tile code re-does a lane's points with ExactCvt in the (practically never taken)
 // case that the maximum reached 2^31.
 struct ExactCvt {
+    [[maybe_unused]] static constexpr bool kCoordsInShort = false;       // a converted coordinate may lie outside int16: the record keeps its low 16 bits
     __device__ __forceinline__ void note(float, float, float, float, float) {}
     __device__ __forceinline__ int32_t cvt(float f) const { return cvtt_x86(f); }
     // colour column / row: clamp(cvttss2si(f), 0, dim-1)   (:438-444)
@@ -105,6 +106,7 @@ struct ExactCvt {
 // (pcs_capi.cpp: certify_no_overflow): then the running maximum is not needed at all.
 template <bool TRACK>
 struct FastCvt {
+    [[maybe_unused]] static constexpr bool kCoordsInShort = false;
     float    hi = 0.0f;
     uint32_t max_idx = 0;
     uint32_t lim = 0xFFFFFFFFu;
@@ -136,6 +138,24 @@ struct FastCvt {
     __device__ __forceinline__ bool redo() const { return (TRACK && hi >= 2147483648.0f) || max_idx > lim; }
 };
 using LazyCvt = FastCvt<true>;
+
+// The voxel readers consume a point's coordinates as numbers, not as the record's 16-bit fields: when every converted
+// coordinate of the lane lies inside int16 the converted value IS the record's field (no pack, no sign extension per point).
+// This policy keeps a second running maximum, of |x|, |y|, |z| in millimetres (the same three instructions as FastCvt<true>'s
+// one maximum over five values), and sends the lane through the exact path — whose values are then wrapped like the record's —
+// when it reached 2^15. The colour coordinates keep their 2^31 check (TRACK) as in FastCvt.
+template <bool TRACK>
+struct VoxCvt : FastCvt<TRACK> {
+    static constexpr bool kCoordsInShort = true;
+    float hc = 0.0f;
+    __device__ __forceinline__ void note(float a, float b, float c, float d, float e)
+    {
+        hc = __builtin_fmaxf(__builtin_fmaxf(hc, __builtin_fabsf(a)), __builtin_fabsf(b));
+        hc = __builtin_fmaxf(hc, __builtin_fabsf(c));
+        if (TRACK) this->hi = __builtin_fmaxf(__builtin_fmaxf(this->hi, d), e);
+    }
+    __device__ __forceinline__ bool redo() const { return hc >= 32768.0f || FastCvt<TRACK>::redo(); }
+};
 
 // Arithmetic policy of the depth->colour projection. Every policy the product launches is bit-identical
 // to IeeeMath on the inputs it is launched for (see "certification" in pcs_capi.cpp and DESIGN.md);
@@ -1244,12 +1264,6 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 #ifndef PCS_VOX_THREADS
 #define PCS_VOX_THREADS 512
 #endif
-#ifndef PCS_VOX_SKIP
-#define PCS_VOX_SKIP 1
-#endif
-#ifndef PCS_VOX_REMAP
-#define PCS_VOX_REMAP 1
-#endif
 #ifndef PCS_VOX_SLOTS
 #define PCS_VOX_SLOTS 2048
 #endif
@@ -1263,6 +1277,49 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 //   tables (-DPCS_VOX_THREADS=256      table, same 128 x 64 patch per table in four rounds), and the launch is slower: the kernel is
 //   -DPCS_VOX_SLOTS=896)               not short of wavefronts to issue from.
 // Both shapes still build (the code below is generic in the two constants); neither is used.
+// The same point for the voxel readers: coordinates as sign-correct integers (the record's int16 fields, widened), the colour
+// dword as fetched (R | G<<8 | B<<16 | don't care). Cvt::kCoordsInShort: the policy vouches that the converted values lie in
+// int16 (VoxCvt); otherwise the low 16 bits are sign-extended here, as the record would hold them.
+struct VoxPoint {
+    int32_t x, y, z;
+    uint32_t w;
+};
+template <class Cvt>
+__device__ __forceinline__ VoxPoint make_vox_point(const StreamParams& P, const uint8_t* __restrict__ color,
+                                                   const PointIn& p, Cvt& cv)
+{
+    const float ax = world_mm(P.M + 0, p.X, p.Y, p.Z);
+    const float ay = world_mm(P.M + 4, p.X, p.Y, p.Z);
+    const float az = world_mm(P.M + 8, p.X, p.Y, p.Z);
+    float xf, yf;
+    color_coords(P, p.u, p.v, xf, yf);
+    cv.note(ax, ay, az, xf, yf);
+    const int32_t x = cv.cvt(ax), y = cv.cvt(ay), z = cv.cvt(az);
+    const uint32_t w = color_fetch(P, color, cv.pixel(xf, P.cW - 1, P.c_wm1_f), cv.pixel(yf, P.cH - 1, P.c_hm1_f), cv);
+    if (Cvt::kCoordsInShort) return VoxPoint{x, y, z, w};
+    return VoxPoint{(int32_t)(int16_t)x, (int32_t)(int16_t)y, (int32_t)(int16_t)z, w};
+}
+// what vox_table_round reads of a point, for both forms
+__device__ __forceinline__ int pt_x(const Record& r) { return (int)(short)(r.xy & 0xFFFFu); }
+__device__ __forceinline__ int pt_y(const Record& r) { return (int)(short)(r.xy >> 16); }
+__device__ __forceinline__ int pt_z(const Record& r) { return (int)(short)(r.zc & 0xFFFFu); }
+__device__ __forceinline__ unsigned int pt_red(const Record& r) { return (r.zc >> 16) & 0xFFu; }
+__device__ __forceinline__ unsigned int pt_green(const Record& r) { return r.zc >> 24; }
+__device__ __forceinline__ unsigned int pt_blue(const Record& r) { return r.b & 0xFFu; }
+__device__ __forceinline__ int pt_x(const VoxPoint& r) { return r.x; }
+__device__ __forceinline__ int pt_y(const VoxPoint& r) { return r.y; }
+__device__ __forceinline__ int pt_z(const VoxPoint& r) { return r.z; }
+__device__ __forceinline__ unsigned int pt_red(const VoxPoint& r) { return r.w & 0xFFu; }
+__device__ __forceinline__ unsigned int pt_green(const VoxPoint& r) { return (r.w >> 8) & 0xFFu; }
+__device__ __forceinline__ unsigned int pt_blue(const VoxPoint& r) { return (r.w >> 16) & 0xFFu; }
+
+// Which of a lane's 8 points take part. (Eight predicates held in the condition registers instead of the mask's bits, for the
+// reader without the -c test, measured: 4 % fewer VALU instructions with the wide points below, no faster — and the round's code twice.)
+struct KeepBits {
+    uint32_t m;
+    __device__ __forceinline__ bool operator()(int k) const { return (m >> k) & 1u; }
+};
+
 constexpr int kVoxThreads = PCS_VOX_THREADS;
 constexpr int kVoxSlots = PCS_VOX_SLOTS;
 constexpr uint32_t kVoxRows = kVoxThreads / 8;    // a round = kVoxRows rows of 64 pixels (8 lanes x 8 pixels)
@@ -1368,7 +1425,8 @@ __device__ __forceinline__ void vox_table_init(const VoxTable& T)
 }
 
 // One round: a lane's 8 consecutive records (bit k of `keep`: record k takes part) -> the table.
-__device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelStage& vs, const Record (&rec)[8], uint32_t keep,
+template <class Pt, class Keep>
+__device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelStage& vs, const Pt (&rec)[8], const Keep& keep,
                                                 bool crowded, unsigned long long& key_or, unsigned long long& key_orn)
 {
     unsigned long long* const skey = T.skey; unsigned long long* const sxy = T.sxy; unsigned long long* const szn = T.szn;
@@ -1377,9 +1435,7 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
     const unsigned int bits = vs.bits, idx_bits = vs.idx_bits;
     VoxelPartial* __restrict__ part = static_cast<VoxelPartial*>(vs.part);
     const int lane = threadIdx.x & 63;
-    auto key_of = [&](const Record& r) {
-        return voxel_key(dv, (int)(short)(r.xy & 0xFFFFu), (int)(short)(r.xy >> 16), (int)(short)(r.zc & 0xFFFFu), bits);
-    };
+    auto key_of = [&](const Pt& r) { return voxel_key(dv, pt_x(r), pt_y(r), pt_z(r), bits); };
     // runs of equal keys among the lane's 8 pixels: summed in registers, the run's LAST point adds them to the table
     unsigned int ax = 0, ay = 0, az = 0;                     // biased: sums of (coordinate + 32768)
     unsigned int ar = 0, ag = 0, ab = 0, an = 0, failed = 0;
@@ -1387,14 +1443,13 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
     unsigned long long kcur = key_of(rec[0]);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const bool live = (keep >> k) & 1u;
-        const bool live_next = k < 7 && ((keep >> (k + 1)) & 1u);
+        const bool live = keep(k);
+        const bool live_next = k < 7 && keep(k < 7 ? k + 1 : 7);
         const unsigned long long knext = k < 7 ? key_of(rec[k + 1]) : 0ull;
-        const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
-        const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
+        const int x = pt_x(rec[k]), y = pt_y(rec[k]), z = pt_z(rec[k]);
         if (!cont) { ax = ay = az = 0u; ar = ag = ab = an = 0u; }
         ax += (unsigned int)(x + 32768); ay += (unsigned int)(y + 32768); az += (unsigned int)(z + 32768);
-        ar += col & 0xFFu; ag += col >> 8; ab += blue; an += 1u;
+        ar += pt_red(rec[k]); ag += pt_green(rec[k]); ab += pt_blue(rec[k]); an += 1u;
         const bool same_next = live_next && knext == kcur;
         const bool actor = live && !same_next;
         if (actor) {
@@ -1469,13 +1524,12 @@ __device__ __forceinline__ void vox_table_round(const VoxTable& T, const VoxelSt
         unsigned long long kprev = 0ull;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const bool live = (keep >> k) & 1u;
-            const int x = (int)(short)(rec[k].xy & 0xFFFFu), y = (int)(short)(rec[k].xy >> 16), z = (int)(short)(rec[k].zc & 0xFFFFu);
-            const unsigned int col = rec[k].zc >> 16, blue = rec[k].b & 0xFFu;
+            const bool live = keep(k);
+            const int x = pt_x(rec[k]), y = pt_y(rec[k]), z = pt_z(rec[k]);
             const unsigned long long key = voxel_key(dv, x, y, z, bits);
-            const bool joins = k > 0 && live && ((keep >> (k - 1)) & 1u) && key == kprev;
+            const bool joins = k > 0 && live && keep(k > 0 ? k - 1 : 0) && key == kprev;
             if (!joins) { sx = sy = sz = 0; r = g = b = cnt = 0u; }
-            sx += x; sy += y; sz += z; r += col & 0xFFu; g += col >> 8; b += blue; cnt += 1u;
+            sx += x; sy += y; sz += z; r += pt_red(rec[k]); g += pt_green(rec[k]); b += pt_blue(rec[k]); cnt += 1u;
             kprev = key;
             if ((failed >> k) & 1u) {
                 const VoxelPartial v{sx, sy, sz, r, g, b, cnt, 0u};
@@ -1645,87 +1699,102 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
     }
 }
 
-// 512 lanes x several rounds rather than 1024 x 1: the raster reader needs ~100 VGPRs (the stitch kernels' 8 points in
+// How a launch of the raster reader cuts the rasters into workgroups, in SQUARES of 64 x 64 pixels (one round of the 512
+// lanes: 8 lanes x 8 pixels per row, 64 rows; a wavefront's loads cover 8 full 128-byte lines of Z16). A voxel of a few dozen
+// pixels across lies inside one square patch but in three or four 8-row strips, so square patches leave 2.2x (50 mm) to 4x
+// (200 mm) fewer partials behind than runs of consecutive pixels; more squares per table, fewer still. Two tiers:
+//   head: square-rows [0, ya) of every stream in patches of rx x ry squares (one table each),
+//   tail: square-rows [ya, ..) in patches of rxb x 1 squares — smaller work items, dealt LAST.
+// Workgroups start in the order of their linear id: all streams' head patches come first, all tail patches after them. The
+// kernel is VALU-bound and a head workgroup lives for a fifth of the launch, so the chip's last round of workgroups decides
+// when the launch ends: short items dealt last level it, short items in the middle of the order (where each stream's remainder
+// row used to sit, and at the price of a full patch: its two rounds below the raster ran on nothing) do not. 16 x 1080p at
+// 50 mm, one call: 0.184 -> 0.178 ms; passing over the empty rounds alone, in the old order: 0.185.
+struct VoxTiling {
+    int rx, ry;          // head patch, in squares (rx == 0: consecutive pixels, `rounds` x 4096 per workgroup; any raster)
+    int rxb;             // tail patch: rxb x 1 squares
+    int ya;              // first square-row of the tail (a multiple of ry)
+    int gxa, gxb;        // patches per square-row in the head / tail (from the launch's widest raster)
+    int na, nb;          // head / tail patches per stream; gridDim.x == na + nb
+};
+
+// 512 lanes x several rounds rather than 1024 x 1: the raster reader needs > 100 VGPRs (the stitch kernels' 8 points in
 // flight plus the table phase), which leaves room for one 1024-lane workgroup per CU — its load phase and its LDS phase
 // then have nothing to overlap with. Two 512-lane workgroups fit, and there is no barrier between the rounds.
 template <bool DD, bool CD, class Mth>
-__global__ __launch_bounds__(kVoxThreads)
+__global__ __launch_bounds__(kVoxThreads) __attribute__((amdgpu_waves_per_eu(4)))     // two workgroups per CU: <= 128 VGPRs
 void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp, uint32_t flags,
-                                     VoxelStage vs, int rounds, int rx, int crowded, int gx, int gy)
+                                     VoxelStage vs, int rounds, VoxTiling tl, int crowded)
 {
     PCS_VOX_TABLE_DECL;
-    // Which stream and which patch of it. Workgroups start in the order of their linear id and the LAST row of patches of a
-    // raster whose height is no multiple of the patch is short work (1080 rows = 8 patches of 128 rows + 56 rows): all the
-    // streams' full rows come first, the short rows of all streams at the very end, where they level the chip's last round
-    // of workgroups instead of holding up a full patch each (gx x gy = the launch's patch grid, from the largest raster).
     int s = blockIdx.y;
-    uint32_t patch = blockIdx.x;
-    if (PCS_VOX_REMAP && rx && gy > 1) {
-        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const uint32_t head = (uint32_t)gx * (uint32_t)(gy - 1), n_head = head * gridDim.y;
-        if (lin < n_head) { s = (int)(lin / head); patch = lin % head; }
-        else { const uint32_t r = lin - n_head; s = (int)(r / (uint32_t)gx); patch = head + r % (uint32_t)gx; }
+    uint32_t sq_x0 = 0, sq_y0 = 0, nrx = 1, nry = (uint32_t)rounds;          // rx == 0: `rounds` runs of 4096 consecutive pixels
+    if (tl.rx) {
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, head = (uint32_t)tl.na * gridDim.y;
+        if (lin < head) {
+            s = (int)(lin / (uint32_t)tl.na);
+            const uint32_t q = lin % (uint32_t)tl.na;
+            sq_x0 = (q % (uint32_t)tl.gxa) * (uint32_t)tl.rx; sq_y0 = (q / (uint32_t)tl.gxa) * (uint32_t)tl.ry;
+            nrx = (uint32_t)tl.rx; nry = (uint32_t)tl.ry;
+        } else {
+            const uint32_t r = lin - head;
+            s = (int)(r / (uint32_t)tl.nb);
+            const uint32_t q = r % (uint32_t)tl.nb;
+            sq_x0 = (q % (uint32_t)tl.gxb) * (uint32_t)tl.rxb; sq_y0 = (uint32_t)tl.ya + q / (uint32_t)tl.gxb;
+            nrx = (uint32_t)tl.rxb; nry = 1u;
+        }
     }
     const StreamParams& P = params[stream0 + s];
     request_constants(P, fp.depth[s], fp.color[s]);
     const uint32_t n = P.n_points;
-    // Which pixels a round takes. rx == 0: 4096 consecutive pixels (any raster). rx > 0 (rasters whose width is a
-    // multiple of 8): a 64 x 64-pixel SQUARE — 8 lanes x 8 pixels per row, 64 rows; a wavefront's loads still cover
-    // 8 full 128-byte lines of Z16 — and the workgroup's rounds tile an (rx x rounds/rx) block of such squares. A
-    // voxel of a few dozen pixels across lies inside ONE square patch but in three or four 8-row strips, so the same
-    // pixels leave 2.2x (50 mm) to 4x (200 mm) fewer partials behind for the sort.
     const uint32_t W = (uint32_t)P.W, Hh = n / W;
-    const uint32_t patches_x = rx ? (W + 64u * (uint32_t)rx - 1u) / (64u * (uint32_t)rx) : 1u;
-    const uint32_t ry = rx ? (uint32_t)rounds / (uint32_t)rx : 1u;
-    const uint32_t px = rx ? patch % patches_x : 0u, py = rx ? patch / patches_x : 0u;
-    const uint32_t tile0 = patch * (kVoxRoundPoints * (uint32_t)rounds);
-    if (rx ? (py * kVoxRows * ry >= Hh) : (tile0 >= n)) return;
+    const uint32_t tile0 = blockIdx.x * (kVoxRoundPoints * (uint32_t)rounds);
+    if (tl.rx ? (sq_y0 * kVoxRows >= Hh || sq_x0 * 64u >= W) : (tile0 >= n)) return;      // (a smaller raster than the launch's largest)
     const uint8_t* __restrict__ color = fp.color[s];
     DepthSource<DD, CD, Mth> src{fp.depth[s]};
     vox_table_init(T);
 
-    for (int round = 0; round < rounds; round++) {
-        uint32_t i0;
-        if (rx) {
-            const uint32_t row0 = (py * ry + (uint32_t)round / (uint32_t)rx) * kVoxRows;
-            const uint32_t col0 = (px * (uint32_t)rx + (uint32_t)round % (uint32_t)rx) * 64u;
-            if (PCS_VOX_SKIP) {
-                // A square below the raster ends the workgroup (the rounds go down the patch), one beside it is passed over:
-                // without this its 512 lanes deproject, pack and hash nothing at the full price (two of the four rounds of
-                // every workgroup in the last patch row of a 1080-row raster). Uniform over the workgroup, so the barriers of
-                // a crowded round stay matched; a WAVEFRONT whose 8 rows lie below the raster passes where there are none.
-                if (row0 >= Hh) break;
-                if (col0 >= W) continue;
+    for (uint32_t yy = 0; yy < nry; yy++) {
+        const uint32_t row0 = (sq_y0 + yy) * kVoxRows;
+        // A square-row below the raster ends the workgroup, a square beside the raster is passed over — uniform over the
+        // workgroup, so the barriers of a crowded round stay matched. Where a round has no barrier, a WAVEFRONT whose 8 rows
+        // lie below the raster (the last 8 of 1080 = 16 x 64 + 56) passes too.
+        if (tl.rx && row0 >= Hh) break;
+        for (uint32_t xx = 0; xx < nrx; xx++) {
+            uint32_t i0;
+            if (tl.rx) {
+                const uint32_t col0 = (sq_x0 + xx) * 64u;
+                if (col0 >= W) break;
                 if (!crowded && row0 + ((threadIdx.x >> 6) << 3) >= Hh) continue;
+                const uint32_t row = row0 + (threadIdx.x >> 3);
+                const uint32_t col = col0 + (threadIdx.x & 7u) * 8u;
+                i0 = (row < Hh && col < W) ? row * W + col : n;        // W % 8 == 0: a lane is inside the row or outside it
+            } else {
+                i0 = tile0 + yy * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
             }
-            const uint32_t row = row0 + (threadIdx.x >> 3);
-            const uint32_t col = col0 + (threadIdx.x & 7u) * 8u;
-            i0 = (row < Hh && col < W) ? row * W + col : n;        // W % 8 == 0: a lane is inside the row or outside it
-        } else {
-            i0 = tile0 + round * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
-        }
-        PointIn p[8];
-        src.load8(P, i0, n, p);
-        const uint32_t keep = keep_mask8(p, i0, n, flags);
+            PointIn p[8];
+            src.load8(P, i0, n, p);
+            const KeepBits keep{keep_mask8(p, i0, n, flags)};
 
-        Record rec[8];
-        auto fill = [&](auto& cv) {
+            VoxPoint rec[8];
+            auto fill = [&](auto& cv) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) rec[k] = make_record(P, color, p[k], cv);
-        };
-        if (Mth::kCvtMode == 2) {
-            FastCvt<false> fast;
-            fill(fast);
-            if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
-        } else if (Mth::kCvtMode == 1) {
-            FastCvt<true> fast;
-            fill(fast);
-            if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
-        } else {
-            ExactCvt exact;
-            fill(exact);
+                for (int k = 0; k < 8; k++) rec[k] = make_vox_point(P, color, p[k], cv);
+            };
+            if (Mth::kCvtMode == 2) {
+                VoxCvt<false> fast;
+                fill(fast);
+                if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+            } else if (Mth::kCvtMode == 1) {
+                VoxCvt<true> fast;
+                fill(fast);
+                if (__builtin_expect(fast.redo(), 0)) { ExactCvt exact; fill(exact); }
+            } else {
+                ExactCvt exact;
+                fill(exact);
+            }
+            vox_table_round(T, vs, rec, keep, crowded != 0, key_or, key_orn);
         }
-        vox_table_round(T, vs, rec, keep, crowded != 0, key_or, key_orn);
     }
     vox_table_flush(T, vs, key_or, key_orn);
 }
@@ -1768,7 +1837,7 @@ void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint
         uint32_t keep = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) keep |= (uint32_t)(i0 + k < n) << k;
-        vox_table_round(T, vs, rec, keep, crowded != 0, key_or, key_orn);
+        vox_table_round(T, vs, rec, KeepBits{keep}, crowded != 0, key_or, key_orn);
     }
     vox_table_flush(T, vs, key_or, key_orn);
 }
@@ -2238,19 +2307,32 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     }
     rounds *= kSub;
     dim3 grid;
-    int gx = 1, gy = 1;
+    VoxTiling tl{};
     if (rx) {
+        // Two tiers (VoxTiling): the head in (rx x ry) patches; the square-rows that do not fill a head patch (1080 rows = 16
+        // square-rows + 56 rows: one of 17 with ry = 2) in (rxb x 1) patches, dealt after all the head patches. Moving MORE of
+        // the raster into the tail of small items does not pay — every workgroup costs a table clear and a flush — 16 x 1080p,
+        // one warm call, ms with 0 / 25 / 40 / 60 / 100 % of the square-rows in the tail (one box): 50 mm 0.174 / 0.176 / 0.178 /
+        // 0.183 / 0.187, 100 mm 0.146 / 0.149 / 0.151 / 0.155 / 0.161; PCS_VOXEL_TAILPCT keeps the knob for the lab.
+        static const int env_tail = [] { const char* v = getenv("PCS_VOXEL_TAILPCT"); return v ? atoi(v) : 0; }();
         const uint32_t ry = (uint32_t)rounds / (uint32_t)rx;
-        gx = (int)((max_w + 64u * rx - 1) / (64u * rx));
-        gy = (int)((max_h + kVoxRows * ry - 1) / (kVoxRows * ry));
-        grid = dim3((unsigned)gx * (unsigned)gy, (unsigned)n_launch, 1);
+        const uint32_t sx = (max_w + 63u) / 64u, sy = (max_h + kVoxRows - 1) / kVoxRows;
+        const uint32_t rxb = ry >= 2 ? (uint32_t)rx : std::max<uint32_t>(1u, (uint32_t)rx / 2u);
+        uint32_t tail_rows = sy % ry;
+        const uint32_t want = std::min<uint32_t>(sy, (sy * (uint32_t)std::max(0, std::min(env_tail, 100)) + 50u) / 100u);
+        while (tail_rows < want && tail_rows + ry <= sy) tail_rows += ry;
+        if (ry == 1 && rxb == (uint32_t)rx) tail_rows = 0;                 // (one square per table: nothing smaller to deal)
+        tl.rx = rx; tl.ry = (int)ry; tl.rxb = (int)rxb; tl.ya = (int)(sy - tail_rows);
+        tl.gxa = (int)((sx + (uint32_t)rx - 1) / (uint32_t)rx); tl.gxb = (int)((sx + rxb - 1) / rxb);
+        tl.na = tl.gxa * (tl.ya / (int)ry); tl.nb = tl.gxb * (int)tail_rows;
+        grid = dim3((unsigned)(tl.na + tl.nb), (unsigned)n_launch, 1);
     } else {
         const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;
         grid = dim3((max_points + tile_points - 1) / tile_points, (unsigned)n_launch, 1);
     }
     // no stream of the context has a distortion model (or the half-pixel texture convention): the instantiation without
     // their (uniform, but not free in a VALU-bound kernel) tests
-#define L(D, M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<D, D, M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, rx, vs.leaf < 30u ? 1 : 0, gx, gy)
+#define L(D, M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<D, D, M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, tl, vs.leaf < 30u ? 1 : 0)
     const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
     if (math == MathSel::Ieee) L(true, IeeeMath);
     else if (any_dist) { if (ident) L(true, CertMath<true>); else L(true, CertMath<false>); }
