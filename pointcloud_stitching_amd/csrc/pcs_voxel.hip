@@ -851,6 +851,10 @@ constexpr unsigned int kBkt = PCS_BKT, kBktSample = 4096;      // buckets: 256 .
 static_assert(kBkt == kVoxBuckets, "the pre-aggregation's region flush (pcs_kernels.hip) partitions into kVoxBuckets ranges");
 constexpr unsigned int kBktChunk = 4096, kBktThreads = 512, kBktPer = kBktChunk / kBktThreads;     // 8 elements per lane
 constexpr unsigned int kBktGrid = 512;
+#ifndef PCS_BKT_MIN_PER
+#define PCS_BKT_MIN_PER 700
+#endif
+constexpr unsigned long long kBktMinPer = PCS_BKT_MIN_PER;       // fewest partials per bucket before a call halves its bucket count
 constexpr unsigned int kBktSlots = 1024, kBktProbe = 48;           // G1's LDS table
 constexpr unsigned long long kBktInf = ~0ull;
 
@@ -911,7 +915,7 @@ void pcs_vox_bkt_hist_kernel(const unsigned long long* __restrict__ keys, unsign
     // splitters (the 1/1024 quantiles); a call with B buckets takes every (kBkt / B)-th. Buckets B .. kBkt - 1 stay empty:
     // every later kernel sees zero counts for them and needs no special case.
     unsigned int B = kBkt;
-    while (B > 32u && (unsigned long long)B * 700ull > m) B >>= 1;
+    while (B > 32u && (unsigned long long)B * kBktMinPer > m) B >>= 1;
     const unsigned int stride = kBkt / B;
     for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) spl[j] = j + 1u < B ? spl_g[(j + 1u) * stride - 1u] : kBktInf;
     __syncthreads();
@@ -1622,7 +1626,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                 // what a warm next call partitions by: as many buckets as P1 would take for this many partials, regions of twice
                 // a bucket's share (the splitters are quantiles; sensor noise and motion move the shares by far less)
                 unsigned int bn = kBkt;
-                while (bn > 32u && (unsigned long long)bn * 700ull > m) bn >>= 1;
+                while (bn > 32u && (unsigned long long)bn * kBktMinPer > m) bn >>= 1;
                 reg_next[0] = bn;
                 reg_next[1] = 2u * (m / bn) + 64u;
             } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kCtlWords) {

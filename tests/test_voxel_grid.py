@@ -307,6 +307,29 @@ def test_rasters_to_voxel_grid_full_table_passes_points_through(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [FLAG_DROP_INVALID, FLAG_DROP_INVALID | FLAG_FORCE_IEEE])
+def test_rasters_to_voxel_grid_coordinates_that_leave_int16(oracle, flags):
+    """A smooth wall whose depth ramps across 32.768 m along every row: inside one lane's 8 pixels some world coordinates (in mm) still fit
+    int16 and the next ones do not — the record keeps their low 16 bits, so they wrap to -32768 and land in voxels at the other end of
+    the grid. The raster reader works on widened coordinates and must send exactly those lanes through its exact path."""
+    w, h = 640, 136
+    cfgs = [S.synth_stream_config(w, h, 0)]
+    ramp = (32600 + (np.arange(w) * 400) // w).astype(np.uint16)                 # 32 600 .. 32 999 mm at depth_scale 0.001
+    depth = [np.ascontiguousarray(np.tile(ramp, h))]
+    depth[0][::97] = 0
+    color = [S.synth_color(w, h, 0)]
+    stitched, _ = oracle.process_frames(cfgs, depth, color, flags)
+    xyz = stitched.reshape(-1, 5)[:, :3]
+    assert ((xyz < -30000).any(0) & (xyz > 30000).any(0)).any()                  # the scene does straddle the wrap
+    with PcsContext(cfgs, flags=flags) as ctx:
+        dd, dc = _upload_rasters(ctx, depth, color)
+        for leaf in (5, 50, 300):
+            got = _rasters_to_voxels(ctx, dd, dc, leaf, cfgs[0].n_points)
+            want = oracle.voxel_grid(stitched, leaf)
+            assert got.shape == want.shape and (got == want).all(), leaf
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("leaf", [12, 60])
 def test_rasters_to_voxel_grid_more_streams_than_one_launch(oracle, leaf):
     """20 cameras = two launches of the raster reader (16 + 4) appending to the same partial arrays."""
