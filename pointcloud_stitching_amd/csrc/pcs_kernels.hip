@@ -2283,7 +2283,7 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     // covers one in kSub rounds of kVoxRoundPoints pixels — converted just before the launch)
     constexpr int kSub = 4096 / (int)kVoxRoundPoints;
     const uint64_t launch_tiles = (uint64_t)((max_points + 4095u) / 4096u) * (uint64_t)n_launch;
-    const uint64_t fill_cap = std::max<uint64_t>(1, launch_tiles / 1024);
+    const uint64_t fill_cap = std::max<uint64_t>(1, (launch_tiles + launch_tiles / 32) / 1024);   // (3 % slack: 16 x 1080p = 8112 squares, 8 per table still fill the chip twice)
     int rounds, rx = 0;
     if (patch_ok && env_patch) {
         // square patches: 64 x 64 per round, (rx x ry) rounds per workgroup. 16 x 1080p, ms per frame-set with 1 / 2 / 4 /
@@ -2291,11 +2291,15 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         // 0.28 / 0.33, 100 mm 0.26 / 0.23 / 0.23 / 0.25, 200 mm 0.26 / 0.23 / 0.23 / 0.24: two squares (128 x 64) per table
         // from 30 mm up, one below. (Voxels per 128 x 64 patch on the synthetic scene: 780 / 240 / 80 / 30 at 25 / 50 /
         // 100 / 200 mm.)
-        // A warm bucket call (vs.regions) ends every workgroup with a dearer flush (bucket search, a returning add per bucket it
-        // touches, scattered writes) and hands its partials to a tail that is one launch: twice the patch per table pays from
-        // 45 mm up — 16 x 1080p, ms per call with 2 / 4 / 8 squares: 40 mm 0.224 / 0.228 / -, 50 mm 0.188 / 0.185 / 0.236,
-        // 100 mm 0.164 / 0.156 / 0.168, 200 mm 0.151 / 0.155 / 0.155.
-        const uint64_t by_leaf = vs.leaf >= 30 ? ((vs.regions && vs.leaf >= 45 && vs.leaf < 150) ? 4 : 2) : 1;
+        // Re-measured after the workgroups were re-ordered (VoxTiling: the chip's last round no longer waits for full patches
+        // behind short ones, which is what had made more squares per table lose), 16 x 1080p, ms per call with 2 / 4 / 8 squares:
+        //   warm bucket tail   36 mm 0.230 / 0.236 / -, 40 mm 0.217 / 0.210 / -, 45 mm 0.199 / 0.183 / 0.250, 50 mm 0.187 / 0.174 / 0.216,
+        //                      100 mm 0.160 / 0.144 / 0.159, 150 mm 0.149 / 0.138 / 0.135, 200 mm 0.147 / 0.136 / 0.135, 300 mm 0.147 / 0.137 / 0.133
+        //   its cold chain     40 mm 0.243 / 0.246 / 0.309, 50 mm 0.197 / 0.193 / 0.221, 100 mm 0.167 / 0.158 / 0.163, 200 mm 0.154 / 0.148 / 0.149
+        //   LSD tail           30 mm 0.378 / 0.402, 36 mm 0.269 / 0.277, 50 mm 0.227 / 0.222, 100 mm 0.193 / 0.183, 200 mm 0.176 / 0.169
+        // (25 mm: one square 0.456, two 0.453; 30 mm: 0.404 / 0.375.) A warm call ends every workgroup with a dearer flush (bucket
+        // search, a returning add per bucket it touches, scattered writes), so it gains most from fewer, larger tables.
+        const uint64_t by_leaf = vs.leaf < 30 ? 1 : vs.regions ? (vs.leaf >= 150 ? 8 : vs.leaf >= 40 ? 4 : 2) : (vs.leaf >= 45 ? 4 : 2);
         rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);
         rounds = rounds >= 8 ? 8 : rounds >= 4 ? 4 : rounds >= 2 ? 2 : 1;
         if (env_rounds > 0) rounds = env_rounds >= 8 ? 8 : env_rounds >= 4 ? 4 : env_rounds >= 2 ? 2 : 1;
