@@ -604,6 +604,20 @@ def run_node(args):
     if config5:
         out["partials_reduced_per_step"] = int(reduced)
         out["config"]["leaf_mm"] = LEAF
+        if P == 1 and os.environ.get("PCS_NODE_ONE_CALL", "1") != "0":
+            # one peer: submit enqueued the rasters -> voxels call (no partials leave the library). Beside it, the same loop with the
+            # partials pipeline a node of several peers runs (pre-aggregation of k+1 beside the root's sort + mean of k)
+            node.set_timing(False)
+            os.environ["PCS_NODE_ONE_CALL"] = "0"
+            try:
+                run(max(args.warmup, 4)); sync_all()
+                t1 = time.perf_counter(); run(args.steps); sync_all()
+                out["one_peer"] = {"route": "pcs_process_frames_voxel_device enqueued at submit (warm bucket tail: 2 launches per frame-set)",
+                                   "partials_pipeline_ms_per_step": round((time.perf_counter() - t1) * 1e3 / args.steps, 5),
+                                   "note": "partials_pipeline = PCS_NODE_ONE_CALL=0: partials to caller-held arrays, sort + mean on a second "
+                                           "context beside the next frame-set's pre-aggregation (what a node of several peers runs on its root)"}
+            finally:
+                del os.environ["PCS_NODE_ONE_CALL"]
     else:
         out["per_stream_fps"] = round(args.steps / elapsed, 1)
         out["points_per_stream"] = counts

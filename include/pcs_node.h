@@ -167,7 +167,10 @@ int  pcs_node_process_voxel_device(pcs_node* node, const uint16_t* const* d_dept
  * two slots): submit enqueues every GPU's pre-aggregation and the read-back of its partial count and returns; the exchange
  * (sized by those counts) and, behind it on the root, the sort + segmented mean are enqueued by the next submit or by
  * pcs_node_wait_voxel. Written as  submit(k+1); wait(k);  the pre-aggregation of k+1 overlaps the exchange and the root's
- * sort of k. The two frame-sets need different d_voxels_root buffers. pcs_node_process_voxel_device(PARTIALS) = submit + wait. */
+ * sort of k. The two frame-sets need different d_voxels_root buffers. pcs_node_process_voxel_device(PARTIALS) = submit + wait.
+ * A node of ONE peer has nothing to exchange: submit enqueues pcs_process_frames_voxel_device (rasters -> voxel cloud, two launches
+ * on a warm context) on the peer's stream and wait only waits; stats report partials = 0 (they never leave the library's
+ * workspace). PCS_NODE_ONE_CALL=0 keeps the partials pipeline for such a node (A/B; tests).                                     */
 int  pcs_node_submit_voxel_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int16_t* d_voxels_root, size_t voxels_shorts, int* ticket);
 int  pcs_node_wait_voxel(pcs_node* node, int ticket, int* n_voxels);

@@ -50,6 +50,7 @@ enum TicketKind { kStitch = 0, kVoxel = 1 };
 
 struct Ticket {
     bool busy = false, exchanged = false;
+    bool one_call = false;                // voxel ticket of a one-peer node: the whole pipeline was enqueued at submit (nothing to exchange)
     bool timing = false;                  // pcs_node_set_timing as of the SUBMIT: the events of this slot were recorded (or not) then
     int id = -1, kind = kStitch, rc = PCS_OK;
     std::string err;
@@ -894,6 +895,28 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     tk = Ticket{};
     tk.kind = kVoxel; tk.id = n->next_ticket; tk.leaf = leaf_mm; tk.d_voxels = d_voxels; tk.voxels_shorts = voxels_shorts;
     tk.timing = n->timing;
+    // ONE peer holds every camera: there is nothing to exchange, and the partials need not leave the library's workspace — the
+    // call that goes from the rasters to the voxel cloud (warm bucket tail: two launches) on the peer's own stream. Two frame-sets
+    // in flight then simply queue behind each other: 16 x 1080p at 50 mm 0.174 ms per frame-set, against 0.205 for the
+    // partials / reduce-on-a-second-context pipeline below (its tail beside the next pre-aggregation; PCS_NODE_ONE_CALL=0 keeps it).
+    const char* env_one = getenv("PCS_NODE_ONE_CALL");          // (read at every submit: the tests run both ways in one process)
+    if (P == 1 && !(env_one && env_one[0] == '0')) {
+        Peer& p = n->peers[0];
+        HIPCHK(n, hipSetDevice(p.dev));
+        hipStream_t ks = kstream(p);
+        if (tk.timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
+        PCSCHK(n, p.ctx, pcs_process_frames_voxel_device(p.ctx, d_depth, d_color, leaf_mm, d_voxels, voxels_shorts,
+                                                         static_cast<int32_t*>(n->d_vox_n[slot])));
+        HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, ks));
+        if (tk.timing) { HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks)); HIPCHK(n, hipEventRecord(n->ev_r0[slot], ks)); }
+        HIPCHK(n, hipEventRecord(p.packed[slot], ks));
+        HIPCHK(n, hipEventRecord(n->ev_done[slot], ks));
+        tk.one_call = true; tk.exchanged = true; tk.busy = true;
+        tk.submit_host_ms = (float)(now_ms() - t_host0);
+        *ticket = n->next_ticket++;
+        flush_other(n, slot);
+        return PCS_OK;
+    }
     for (int r = 0; r < P; r++) {
         Peer& p = n->peers[r];
         HIPCHK(n, hipSetDevice(p.dev));

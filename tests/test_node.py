@@ -128,12 +128,17 @@ def test_a_failed_submit_leaves_the_node_usable(oracle, flags):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0]])
-def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, devices):
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], "one peer, partials pipeline"])
+def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, devices, monkeypatch):
     """pcs_node_submit_voxel_device / pcs_node_wait_voxel: partials pre-aggregated per peer, ONE grouped exchange of keys +
     partials, sort + segmented mean on the root — byte-identical to the voxel grid of the stitched cloud, frame after frame,
-    with the pre-aggregation of k+1 queued before the exchange of k."""
+    with the pre-aggregation of k+1 queued before the exchange of k. A node of ONE peer enqueues the rasters -> voxels call at
+    submit instead (no partials leave the library: stats say 0); PCS_NODE_ONE_CALL=0 keeps the partials pipeline for it."""
     from pointcloud_stitching_amd.node import PcsNode, VOXEL_PARTIALS, VOXEL_PAYLOADS
+    one_call = devices == [0]
+    if isinstance(devices, str):
+        devices = [0]
+        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0")
     n, w, h, frames, leaf = 4, 320, 240, 5, 40
     cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
     sets = [([S.synth_depth(w, h, s, seed=S.SEED + 17 * f) for s in range(n)],
@@ -152,18 +157,21 @@ def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, dev
             assert nv == want[k - 1].shape[0]
             assert (_fetch(mem, vox[(k - 1) & 1], nv) == want[k - 1]).all(), k - 1
             st = node.last_stats()
-            assert st["reduced"] >= nv and st["root_ms"] > 0
+            if one_call:
+                assert st["reduced"] == 0 and st["kernels_ms"] > 0
+            else:
+                assert st["reduced"] >= nv and st["root_ms"] > 0
             assert (st["exchanged_bytes"] > 0) == (len(devices) > 1) and st["exchanged_bytes"] % 40 == 0
         # the synchronous forms (both routes) on the same node afterwards
         for route in (VOXEL_PARTIALS, VOXEL_PAYLOADS):
             nv, stats = node.process_voxel_device(*dev_sets[1], leaf, vox[0], cap, route)
             assert nv == want[1].shape[0] and (_fetch(mem, vox[0], nv) == want[1]).all(), route
-            assert stats["voxels"] == nv and stats["root_voxel_ms"] > 0
+            assert stats["voxels"] == nv and (stats["root_voxel_ms"] > 0 or (one_call and route == VOXEL_PARTIALS))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", [[0], [0] * 8])
-def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices):
+@pytest.mark.parametrize("devices", [[0], [0] * 8, "one peer, partials pipeline"])
+def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices, monkeypatch):
     """BASELINE configs[4] at full size — 16 x 1920x1080, invalid-depth compaction, 50 mm voxel grid — through the pipelined node
     call with two frame-sets in flight; [0]*8 is the configuration's own shape (2 cameras per peer, 8 peers) with the
     exchange on RCCL. Both frame-sets are the digest's frame."""
@@ -173,6 +181,9 @@ def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices):
     depth = [S.synth_depth(W, H, s) for s in range(N)]
     color = [S.synth_color(W, H, s) for s in range(N)]
     gold = GOLD["voxel"][str(leaf)]
+    if isinstance(devices, str):
+        devices = [0]
+        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0")
     with PcsNode(cfgs, devices=devices, flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
         cap = node.max_payload_shorts
         dd, dc = _upload(mem, depth, color)
