@@ -1268,7 +1268,7 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 #define PCS_VOX_SLOTS 2048
 #endif
 // Workgroup shape of the raster / payload readers: 512 lanes (8 wavefronts) and a 2048-slot table (72 KiB): two workgroups per
-// CU, 4 wavefronts per SIMD at ~105 VGPRs. Round 5 measured the two ways to a FIFTH wavefront per SIMD (<= 96 VGPRs), 16 x 1080p
+// CU, 4 wavefronts per SIMD at 120 - 126 VGPRs (~105 when these measurements were taken, with packed records). Round 5 measured the two ways to a FIFTH wavefront per SIMD (<= 96 VGPRs), 16 x 1080p
 // at 50 mm, one call, A/B on one box:
 //   640 lanes x 2 workgroups           0.266 vs 0.197 ms — a workgroup's 10 wavefronts are dealt to the SIMDs 3-3-2-2 and two such
 //                                      workgroups need six slots on two SIMDs: only ONE fits a CU (a workgroup must be a multiple of
