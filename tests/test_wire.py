@@ -1,9 +1,11 @@
 """The reference's TCP framing and star topology on one box:
    edge(s) --[int32 bytes][points]--> central --'Z' pull--> consumer (this test plays the Unity client)."""
 import os
+import functools
 import socket
 import struct
 import subprocess
+import sys
 import time
 
 import numpy as np
@@ -27,15 +29,36 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def connect(port, timeout=60.0):
+class ServerStartError(RuntimeError):
+    """The server under test never listened (it exited, or did not get through start-up in time): not a wire-protocol failure."""
+
+
+def connect(port, timeout=150.0, procs=()):
+    """Connect to a server that is still starting (HIP start-up + pcs_create come before its listen()). Gives up at once when one of
+    `procs` has exited — with its exit code and stderr in the error — and after `timeout` seconds otherwise."""
     t0 = time.time()
     while True:
         try:
             return socket.create_connection(("127.0.0.1", port), timeout=30)
-        except OSError:
-            if time.time() - t0 > timeout:
-                raise
+        except OSError as e:
+            dead = [q for q in procs if q.poll() is not None]
+            if dead or time.time() - t0 > timeout:
+                why = "; ".join(f"exited rc={q.returncode}: {(q.stderr.read() if q.stderr else '')[-600:]}" for q in dead) or "still starting"
+                raise ServerStartError(f"no server on port {port} after {time.time() - t0:.0f} s ({why})") from e
             time.sleep(0.1)
+
+
+def retry_server_start(fn):
+    """One more attempt (new ports, new processes) when a server did not come up: on a GPU box under load a process can take long
+    to get through HIP start-up; a failure of the protocol or of the bytes is never retried."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except ServerStartError as e:
+            print(f"{fn.__name__}: {e}; one more attempt", file=sys.stderr)
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def read_n(sock, n):
@@ -82,12 +105,13 @@ def test_central_accepts_the_reference_invocation():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pull", [False, True])
+@retry_server_start
 def test_edge_server_frames(oracle, pull):
     port = free_port()
     args = [EDGE, "-f", "synth:128x96", "-m", "-r", "3", "-p", str(port), "-P" if pull else "-s"]
     p = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        sock = connect(port)
+        sock = connect(port, procs=[p])
         for frame in range(3):
             if pull:
                 sock.sendall(b"Z")
@@ -105,12 +129,13 @@ def test_edge_server_frames(oracle, pull):
 
 
 @pytest.mark.gpu
+@retry_server_start
 def test_edge_rejects_a_faulty_pull_request():
     port = free_port()
     p = subprocess.Popen([EDGE, "-f", "synth:64x48", "-m", "-r", "2", "-p", str(port), "-P"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        sock = connect(port)
+        sock = connect(port, procs=[p])
         sock.sendall(b"Q")
         out, err = p.communicate(timeout=60)
         assert p.returncode == 1 and "Faulty pull request" in err       # src/pcs-camera-optimized.cpp:207-209
@@ -120,6 +145,7 @@ def test_edge_rejects_a_faulty_pull_request():
 
 
 @pytest.mark.gpu
+@retry_server_start
 def test_full_star_topology_two_edges_one_central(oracle):
     p1, p2, p3 = free_port(), free_port(), free_port()
     edges = [subprocess.Popen([EDGE, "-f", "synth:128x96", "-m", "-r", "4", "-p", str(p), "-P"],
@@ -129,7 +155,7 @@ def test_full_star_topology_two_edges_one_central(oracle):
         time.sleep(0.5)
         central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-d", "2", "-p", str(p3), "-r", "2", "-t"],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        consumer = connect(p3)
+        consumer = connect(p3, procs=[central] + edges)
         for frame in range(2):
             consumer.sendall(b"Z")
             got = read_frame(consumer)
@@ -152,6 +178,7 @@ def test_full_star_topology_two_edges_one_central(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("stride", [1, 3])
+@retry_server_start
 def test_star_with_the_centre_side_transform(oracle, tmp_path, stride):
     """`pcs-multicamera-optimized -c ... -T transforms.txt`: the semantics of the program the CLI is installed as — every camera's
     payload decoded, moved by transform[i], re-encoded, then concatenated (src/pcs-multicamera-optimized.cpp:226-265, 289) —
@@ -168,7 +195,7 @@ def test_star_with_the_centre_side_transform(oracle, tmp_path, stride):
         time.sleep(0.5)
         central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-d", str(stride), "-p", str(p3), "-r", "2", "-T", str(tf)],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        consumer = connect(p3)
+        consumer = connect(p3, procs=[central] + edges)
         for frame in range(2):
             consumer.sendall(b"Z")
             got = read_frame(consumer)
@@ -192,12 +219,13 @@ def test_star_with_the_centre_side_transform(oracle, tmp_path, stride):
 
 
 @pytest.mark.gpu
+@retry_server_start
 def test_central_all_gpu_mode(oracle):
     port = free_port()
     p = subprocess.Popen([CENTRAL, "-i", "synth:128x96", "-N", "3", "-d", "3", "-p", str(port), "-r", "2"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        sock = connect(port)
+        sock = connect(port, procs=[p])
         for frame in range(2):
             sock.sendall(b"Z")
             got = read_frame(sock)
@@ -214,6 +242,7 @@ def test_central_all_gpu_mode(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("leaf,drop,stride", [(50, True, 1), (20, False, 1), (200, True, 3)])
+@retry_server_start
 def test_central_serves_the_voxel_grid(oracle, leaf, drop, stride):
     """-V <mm>: the consumer receives the voxel-grid downsample of the stitched cloud (BASELINE config 5), produced from
     the rasters in one device call (>= 36 mm: no stitched cloud in HBM; below, or with a stride: through it)."""
@@ -221,7 +250,7 @@ def test_central_serves_the_voxel_grid(oracle, leaf, drop, stride):
     args = [CENTRAL, "-i", "synth:160x120", "-N", "3", "-V", str(leaf), "-d", str(stride), "-p", str(port), "-r", "2"] + (["-Z"] if drop else [])
     p = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        sock = connect(port)
+        sock = connect(port, procs=[p])
         for frame in range(2):
             sock.sendall(b"Z")
             got = read_frame(sock)
@@ -238,6 +267,7 @@ def test_central_serves_the_voxel_grid(oracle, leaf, drop, stride):
 
 
 @pytest.mark.gpu
+@retry_server_start
 def test_central_voxel_grid_of_edge_payloads(oracle):
     """-c + -V: two edge servers' payloads are concatenated on the GPU and their voxel grid is served."""
     p1, p2, p3 = free_port(), free_port(), free_port()
@@ -248,7 +278,7 @@ def test_central_voxel_grid_of_edge_payloads(oracle):
         time.sleep(0.5)
         central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-V", "100", "-p", str(p3), "-r", "1"],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        consumer = connect(p3)
+        consumer = connect(p3, procs=[central] + edges)
         consumer.sendall(b"Z")
         got = read_frame(consumer)
         consumer.close()
@@ -265,6 +295,7 @@ def test_central_voxel_grid_of_edge_payloads(oracle):
 
 
 @pytest.mark.gpu
+@retry_server_start
 def test_central_node_mode_one_gpu(oracle):
     """-G 1: the single-process multi-GPU layer (libpcs_node) with one device — per-device context, counts,
     stitched buffer on the root. (The N>1 exchange is straight-line RCCL and needs a multi-GPU box.)"""
@@ -272,7 +303,7 @@ def test_central_node_mode_one_gpu(oracle):
     p = subprocess.Popen([CENTRAL, "-i", "synth:128x96", "-N", "4", "-G", "1", "-p", str(port), "-r", "2"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        sock = connect(port)
+        sock = connect(port, procs=[p])
         for frame in range(2):
             sock.sendall(b"Z")
             got = read_frame(sock)
