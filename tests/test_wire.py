@@ -48,6 +48,31 @@ def connect(port, timeout=150.0, procs=()):
             time.sleep(0.1)
 
 
+def wait_listening(ports, procs=(), timeout=150.0):
+    """Until every port is in LISTEN state (/proc/net/tcp*), WITHOUT connecting: an edge server takes exactly one client, and that
+    client is the central. (The central connect()s once and exits if an edge is not up yet, as the reference's does: a fixed sleep
+    before starting it is a race against the edges' HIP start-up.)"""
+    want = {f"{p:04X}" for p in ports}
+    t0 = time.time()
+    while True:
+        up = set()
+        for table in ("/proc/net/tcp", "/proc/net/tcp6"):
+            try:
+                for line in open(table).read().splitlines()[1:]:
+                    f = line.split()
+                    if f[3] == "0A":
+                        up.add(f[1].rsplit(":", 1)[1])
+            except OSError:
+                pass
+        if want <= up:
+            return
+        dead = [q for q in procs if q.poll() is not None]
+        if dead or time.time() - t0 > timeout:
+            why = "; ".join(f"exited rc={q.returncode}: {(q.stderr.read() if q.stderr else '')[-600:]}" for q in dead) or "still starting"
+            raise ServerStartError(f"ports {sorted(ports)} not all listening after {time.time() - t0:.0f} s ({why})")
+        time.sleep(0.05)
+
+
 def retry_server_start(fn):
     """One more attempt (new ports, new processes) when a server did not come up: on a GPU box under load a process can take long
     to get through HIP start-up; a failure of the protocol or of the bytes is never retried."""
@@ -152,7 +177,7 @@ def test_full_star_topology_two_edges_one_central(oracle):
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for p in (p1, p2)]
     central = None
     try:
-        time.sleep(0.5)
+        wait_listening([p1, p2], procs=edges)
         central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-d", "2", "-p", str(p3), "-r", "2", "-t"],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         consumer = connect(p3, procs=[central] + edges)
@@ -192,7 +217,7 @@ def test_star_with_the_centre_side_transform(oracle, tmp_path, stride):
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for p in (p1, p2)]
     central = None
     try:
-        time.sleep(0.5)
+        wait_listening([p1, p2], procs=edges)
         central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-d", str(stride), "-p", str(p3), "-r", "2", "-T", str(tf)],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         consumer = connect(p3, procs=[central] + edges)
@@ -275,7 +300,7 @@ def test_central_voxel_grid_of_edge_payloads(oracle):
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for p in (p1, p2)]
     central = None
     try:
-        time.sleep(0.5)
+        wait_listening([p1, p2], procs=edges)
         central = subprocess.Popen([CENTRAL, "-c", f"127.0.0.1:{p1},127.0.0.1:{p2}", "-V", "100", "-p", str(p3), "-r", "1"],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         consumer = connect(p3, procs=[central] + edges)
