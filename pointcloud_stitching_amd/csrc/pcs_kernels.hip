@@ -1260,6 +1260,7 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 // one partial per occupied slot is appended to the same arrays the payload reader fills, and pcs_voxel.hip's sort and
 // segmented mean run unchanged.
 #include "pcs_voxel_agg.h"
+#include "pcs_vox_tiling.h"
 
 #ifndef PCS_VOX_THREADS
 #define PCS_VOX_THREADS 512
@@ -1699,25 +1700,6 @@ __device__ __forceinline__ void vox_table_flush(const VoxTable& T, const VoxelSt
     }
 }
 
-// How a launch of the raster reader cuts the rasters into workgroups, in SQUARES of 64 x 64 pixels (one round of the 512
-// lanes: 8 lanes x 8 pixels per row, 64 rows; a wavefront's loads cover 8 full 128-byte lines of Z16). A voxel of a few dozen
-// pixels across lies inside one square patch but in three or four 8-row strips, so square patches leave 2.2x (50 mm) to 4x
-// (200 mm) fewer partials behind than runs of consecutive pixels; more squares per table, fewer still. Two tiers:
-//   head: square-rows [0, ya) of every stream in patches of rx x ry squares (one table each),
-//   tail: square-rows [ya, ..) in patches of rxb x 1 squares — smaller work items, dealt LAST.
-// Workgroups start in the order of their linear id: all streams' head patches come first, all tail patches after them. The
-// kernel is VALU-bound and a head workgroup lives for a fifth of the launch, so the chip's last round of workgroups decides
-// when the launch ends: short items dealt last level it, short items in the middle of the order (where each stream's remainder
-// row used to sit, and at the price of a full patch: its two rounds below the raster ran on nothing) do not. 16 x 1080p at
-// 50 mm, one call: 0.184 -> 0.178 ms; passing over the empty rounds alone, in the old order: 0.185.
-struct VoxTiling {
-    int rx, ry;          // head patch, in squares (rx == 0: consecutive pixels, `rounds` x 4096 per workgroup; any raster)
-    int rxb;             // tail patch: rxb x 1 squares
-    int ya;              // first square-row of the tail (a multiple of ry)
-    int gxa, gxb;        // patches per square-row in the head / tail (from the launch's widest raster)
-    int na, nb;          // head / tail patches per stream; gridDim.x == na + nb
-};
-
 // 512 lanes x several rounds rather than 1024 x 1: the raster reader needs > 100 VGPRs (the stitch kernels' 8 points in
 // flight plus the table phase), which leaves room for one 1024-lane workgroup per CU — its load phase and its LDS phase
 // then have nothing to overlap with. Two 512-lane workgroups fit, and there is no barrier between the rounds.
@@ -1730,19 +1712,8 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     int s = blockIdx.y;
     uint32_t sq_x0 = 0, sq_y0 = 0, nrx = 1, nry = (uint32_t)rounds;          // rx == 0: `rounds` runs of 4096 consecutive pixels
     if (tl.rx) {
-        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, head = (uint32_t)tl.na * gridDim.y;
-        if (lin < head) {
-            s = (int)(lin / (uint32_t)tl.na);
-            const uint32_t q = lin % (uint32_t)tl.na;
-            sq_x0 = (q % (uint32_t)tl.gxa) * (uint32_t)tl.rx; sq_y0 = (q / (uint32_t)tl.gxa) * (uint32_t)tl.ry;
-            nrx = (uint32_t)tl.rx; nry = (uint32_t)tl.ry;
-        } else {
-            const uint32_t r = lin - head;
-            s = (int)(r / (uint32_t)tl.nb);
-            const uint32_t q = r % (uint32_t)tl.nb;
-            sq_x0 = (q % (uint32_t)tl.gxb) * (uint32_t)tl.rxb; sq_y0 = (uint32_t)tl.ya + q / (uint32_t)tl.gxb;
-            nrx = (uint32_t)tl.rxb; nry = 1u;
-        }
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+        PCS_VOX_TILING_DECODE(tl, lin, gridDim.y, s, sq_x0, sq_y0, nrx, nry);
     }
     const StreamParams& P = params[stream0 + s];
     request_constants(P, fp.depth[s], fp.color[s]);
@@ -2319,16 +2290,7 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         // one warm call, ms with 0 / 25 / 40 / 60 / 100 % of the square-rows in the tail (one box): 50 mm 0.174 / 0.176 / 0.178 /
         // 0.183 / 0.187, 100 mm 0.146 / 0.149 / 0.151 / 0.155 / 0.161; PCS_VOXEL_TAILPCT keeps the knob for the lab.
         static const int env_tail = [] { const char* v = getenv("PCS_VOXEL_TAILPCT"); return v ? atoi(v) : 0; }();
-        const uint32_t ry = (uint32_t)rounds / (uint32_t)rx;
-        const uint32_t sx = (max_w + 63u) / 64u, sy = (max_h + kVoxRows - 1) / kVoxRows;
-        const uint32_t rxb = ry >= 2 ? (uint32_t)rx : std::max<uint32_t>(1u, (uint32_t)rx / 2u);
-        uint32_t tail_rows = sy % ry;
-        const uint32_t want = std::min<uint32_t>(sy, (sy * (uint32_t)std::max(0, std::min(env_tail, 100)) + 50u) / 100u);
-        while (tail_rows < want && tail_rows + ry <= sy) tail_rows += ry;
-        if (ry == 1 && rxb == (uint32_t)rx) tail_rows = 0;                 // (one square per table: nothing smaller to deal)
-        tl.rx = rx; tl.ry = (int)ry; tl.rxb = (int)rxb; tl.ya = (int)(sy - tail_rows);
-        tl.gxa = (int)((sx + (uint32_t)rx - 1) / (uint32_t)rx); tl.gxb = (int)((sx + rxb - 1) / rxb);
-        tl.na = tl.gxa * (tl.ya / (int)ry); tl.nb = tl.gxb * (int)tail_rows;
+        tl = vox_tiling_make(max_w, max_h, kVoxRows, (unsigned)rx, (unsigned)rounds / (unsigned)rx, env_tail);
         grid = dim3((unsigned)(tl.na + tl.nb), (unsigned)n_launch, 1);
     } else {
         const uint32_t tile_points = kVoxRoundPoints * (uint32_t)rounds;

@@ -1,0 +1,93 @@
+"""Host logic of the voxel pipeline's raster reader (pointcloud_stitching_amd/csrc/pcs_vox_tiling.h): whatever the geometry, the
+workgroups of a launch visit every 64 x 64 square of every stream's raster exactly once, head patches before tail patches. The header
+is plain C++ (the kernel and its launcher #include the same text), compiled here with g++ and run on the CPU."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "pointcloud_stitching_amd", "csrc", "pcs_vox_tiling.h")
+
+CHECKER = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "pcs_vox_tiling.h"
+// what pcs_fused_voxel_partials_kernel does with its patch, square by square (rows = 64)
+static unsigned long long rng = 88172645463325252ull;
+static unsigned rnd(unsigned n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (unsigned)(rng % n); }
+int main()
+{
+    const unsigned shapes[4][2] = {{1, 1}, {2, 1}, {2, 2}, {4, 2}};
+    const int pcts[5] = {0, 25, 60, 100, -5};
+    long long launches = 0, squares = 0;
+    for (int trial = 0; trial < 20000; trial++) {
+        const unsigned S = 1 + rnd(4);
+        unsigned W[4], H[4], max_w = 0, max_h = 0;
+        for (unsigned s = 0; s < S; s++) {
+            W[s] = 8 * (1 + rnd(trial % 3 ? 40 : 260)); H[s] = 1 + rnd(trial % 3 ? 300 : 1200);
+            if (trial % 7 == 0) { W[s] = 1920; H[s] = 1080; }
+            if (W[s] > max_w) max_w = W[s];
+            if (H[s] > max_h) max_h = H[s];
+        }
+        const unsigned* sh = shapes[rnd(4)];
+        const VoxTiling tl = vox_tiling_make(max_w, max_h, 64, sh[0], sh[1], pcts[rnd(5)]);
+        if (tl.ya % tl.ry != 0 || tl.na < 0 || tl.nb < 0 || tl.na + tl.nb <= 0) { printf("bad tiling\n"); return 1; }
+        const unsigned sxm = (max_w + 63) / 64, sym = (max_h + 63) / 64;
+        std::vector<int> seen((size_t)S * sxm * sym, 0);
+        const unsigned gx = (unsigned)(tl.na + tl.nb);
+        bool tail_seen = false;
+        for (unsigned by = 0; by < S; by++) for (unsigned bx = 0; bx < gx; bx++) {
+            const uint32_t lin = by * gx + bx;
+            int s = -1; uint32_t sq_x0 = 0, sq_y0 = 0, nrx = 0, nry = 0;
+            PCS_VOX_TILING_DECODE(tl, lin, S, s, sq_x0, sq_y0, nrx, nry);
+            if (s < 0 || s >= (int)S) { printf("stream %d out of range\n", s); return 1; }
+            const bool tail = lin >= (uint32_t)tl.na * S;
+            if (tail) tail_seen = true; else if (tail_seen) { printf("a head patch after a tail patch\n"); return 1; }
+            if (sq_y0 * 64u >= H[s] || sq_x0 * 64u >= W[s]) continue;                 // the kernel's early return
+            for (uint32_t yy = 0; yy < nry; yy++) {
+                if ((sq_y0 + yy) * 64u >= H[s]) break;
+                for (uint32_t xx = 0; xx < nrx; xx++) {
+                    if ((sq_x0 + xx) * 64u >= W[s]) break;
+                    if (sq_y0 + yy >= sym || sq_x0 + xx >= sxm) { printf("square outside the launch's grid\n"); return 1; }
+                    seen[((size_t)s * sym + sq_y0 + yy) * sxm + sq_x0 + xx]++;
+                }
+            }
+        }
+        for (unsigned s = 0; s < S; s++) for (unsigned r = 0; r < sym; r++) for (unsigned c = 0; c < sxm; c++) {
+            const int want = (r * 64u < H[s] && c * 64u < W[s]) ? 1 : 0;
+            if (seen[((size_t)s * sym + r) * sxm + c] != want) {
+                printf("trial %d: stream %u (%ux%u of %ux%u) square (%u,%u) visited %d times, patch %dx%d tail %dx1 from row %d\n", trial, s, W[s], H[s],
+                       max_w, max_h, r, c, seen[((size_t)s * sym + r) * sxm + c], tl.rx, tl.ry, tl.rxb, tl.ya);
+                return 1;
+            }
+            squares += want;
+        }
+        launches++;
+    }
+    // the geometry the record was taken on: 16 x 1920x1080, 4 squares per table -> 120 head + 15 tail patches per stream
+    const VoxTiling c5 = vox_tiling_make(1920, 1080, 64, 2, 2, 0);
+    if (c5.na != 120 || c5.nb != 15 || c5.ya != 16 || c5.rxb != 2) { printf("config 5: na %d nb %d ya %d rxb %d\n", c5.na, c5.nb, c5.ya, c5.rxb); return 1; }
+    const VoxTiling c8 = vox_tiling_make(1920, 1080, 64, 4, 2, 0);
+    if (c8.na != 64 || c8.nb != 8 || c8.gxa != 8) { printf("8 squares: na %d nb %d gxa %d\n", c8.na, c8.nb, c8.gxa); return 1; }
+    printf("ok %lld launches %lld squares\n", launches, squares);
+    return 0;
+}
+'''
+
+
+def test_every_square_is_visited_exactly_once(tmp_path):
+    src = tmp_path / "vox_tiling_check.cpp"
+    src.write_text(CHECKER)
+    exe = tmp_path / "vox_tiling_check"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok ")
+
+
+def test_the_kernel_and_the_launcher_use_this_header():
+    src = open(os.path.join(os.path.dirname(HEADER), "pcs_kernels.hip")).read()
+    assert '#include "pcs_vox_tiling.h"' in src and "PCS_VOX_TILING_DECODE(tl, lin, gridDim.y" in src and "vox_tiling_make(max_w, max_h, kVoxRows" in src
