@@ -151,6 +151,19 @@ class Leg:
         return False
 
 
+def emit(out):
+    """The contract's ONE JSON line — and the LAST line on stdout: what C libraries left in the C stdio buffer (RCCL prints a
+    version banner with printf when a communicator is created; into a pipe it would otherwise be flushed at exit, after this line)
+    goes out first."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:          # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def run_config5(args):
     """BASELINE.json configs[4]: 16 synthetic 1920x1080 streams, 16/N per GPU, wavefront invalid-depth compaction and a
     voxel-grid downsample of the stitched cloud on rank 0. A step = one frame-set through
@@ -338,7 +351,7 @@ def run_config5(args):
                                        "sample": f"{ns} of {total_streams} streams: deprojection + pack + compaction + stitch + voxel grid by the "
                                                  f"scalar CPU oracle, best of {passes} passes ({best:.2f} s each); the reference itself has no "
                                                  f"voxel grid (src/pcs-multicamera-optimized.cpp:17 only includes the header)"}
-        print(json.dumps(out), flush=True)
+        emit(out)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -657,8 +670,11 @@ def run_node(args):
     if node_error:
         out["node_error"] = node_error
         out["config"]["gather_to_rank0"] = False
-    print(json.dumps(out), flush=True)
-    node.close()
+    try:
+        node.close()          # (RCCL teardown before the line, so that nothing follows it)
+    except Exception:          # noqa: BLE001
+        pass
+    emit(out)
     return 0
 
 
@@ -1682,7 +1698,7 @@ def main():
                 out["cpu_baseline"] = cpu_first
                 if args.mode == "dense":
                     out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     if ctx0 is not ctx:
         ctx0.close()
