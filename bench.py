@@ -151,16 +151,20 @@ class Leg:
         return False
 
 
-def emit(out):
-    """The contract's ONE JSON line — and the LAST line on stdout: what C libraries left in the C stdio buffer (RCCL prints a
-    version banner with printf when a communicator is created; into a pipe it would otherwise be flushed at exit, after this line)
-    goes out first."""
+def flush_c_stdio():
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:          # noqa: BLE001
         pass
     sys.stdout.flush()
+
+
+def emit(out):
+    """The contract's ONE JSON line — and the LAST line on stdout: what C libraries left in the C stdio buffer (RCCL prints a
+    version banner with printf when a communicator is created; into a pipe it would otherwise be flushed at exit, after this line)
+    goes out first."""
+    flush_c_stdio()
     print(json.dumps(out), flush=True)
 
 
@@ -303,6 +307,9 @@ def run_config5(args):
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         ph = dict(zip(("kernel", "exchange", "root_voxel"), [float(x) for x in mx.tolist()]))
 
+    if world > 1:
+        flush_c_stdio()           # (as in main: nothing of any rank may follow rank 0's line on the shared stdout)
+        dist.barrier()
     if rank == 0:
         pts_step = total_streams * npts
         ms_per_step = elapsed * 1e3 / args.steps
@@ -1097,6 +1104,10 @@ def main():
             traffic = None
     policy = POLICY[min(ctx.stream_math(s) for s in range(S))]
 
+    if world > 1:
+        # every rank's C stdio (RCCL's banner) is out before rank 0 prints the line: the ranks share one stdout under torchrun
+        flush_c_stdio()
+        dist.barrier()
     if rank == 0:
         total_points = set_points * sets_per_launch * world * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
