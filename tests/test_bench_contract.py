@@ -259,3 +259,17 @@ def test_readme_quotes_only_the_recorded_bench_line():
     assert not re.search(r"GPU\s*=\s*\d+", outside)
     d = rr.load(os.path.join(ROOT, src))
     assert d["n_gpus"] == 1 and "configs[2]" in d["config"]["workload"] and "leg_errors" not in d
+
+
+def test_the_line_is_the_last_line_on_stdout_even_after_c_level_prints():
+    """RCCL prints its version banner with printf; through a pipe the C buffer is flushed at exit — after anything Python printed —
+    unless bench.py flushes it first. A child process: printf through libc, then bench.emit; the pipe must end with the JSON line."""
+    code = ("import ctypes, importlib.util, sys\n"
+            "ctypes.CDLL(None).printf(b'RCCL version : banner from C stdio\\n')\n"
+            f"spec = importlib.util.spec_from_file_location('bench_module', {BENCH!r})\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "b.emit({'metric': 'm', 'value': 1.0})\n")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines[0].startswith("RCCL version") and json.loads(lines[-1]) == {"metric": "m", "value": 1.0}
