@@ -2270,11 +2270,8 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
         //   LSD tail           30 mm 0.378 / 0.402, 36 mm 0.269 / 0.277, 50 mm 0.227 / 0.222, 100 mm 0.193 / 0.183, 200 mm 0.176 / 0.169
         // (25 mm: one square 0.456, two 0.453; 30 mm: 0.404 / 0.375.) A warm call ends every workgroup with a dearer flush (bucket
         // search, a returning add per bucket it touches, scattered writes), so it gains most from fewer, larger tables.
-        const uint64_t by_leaf = vs.leaf < 30 ? 1 : vs.regions ? (vs.leaf >= 150 ? 8 : vs.leaf >= 40 ? 4 : 2) : (vs.leaf >= 45 ? 4 : 2);
-        rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);
-        rounds = rounds >= 8 ? 8 : rounds >= 4 ? 4 : rounds >= 2 ? 2 : 1;
-        if (env_rounds > 0) rounds = env_rounds >= 8 ? 8 : env_rounds >= 4 ? 4 : env_rounds >= 2 ? 2 : 1;
-        rx = rounds == 8 ? 4 : rounds >= 2 ? 2 : 1;
+        const VoxPatchShape shape = vox_patch_shape(vs.leaf, vs.regions != 0u, launch_tiles, env_rounds);      // pcs_vox_tiling.h
+        rounds = shape.squares; rx = shape.rx;
     } else {
         const uint64_t by_leaf = std::min<uint64_t>(8, std::max<uint64_t>(3, ((uint64_t)vs.leaf * vs.leaf) / 625u));
         rounds = (int)std::min<uint64_t>(by_leaf, fill_cap);

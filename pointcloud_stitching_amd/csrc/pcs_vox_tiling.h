@@ -45,6 +45,24 @@ inline VoxTiling vox_tiling_make(unsigned max_w, unsigned max_h, unsigned rows, 
     return tl;
 }
 
+// Squares (4096 pixels) that share one 2048-slot table on the patch route, and the head patch's width in squares: by the leaf
+// (the voxels under a table fall roughly with the square of the leaf; a wrong guess costs speed, never bits — runs that find no slot
+// go out as partials of their own), by the tail that follows (`regions`: a warm bucket call's workgroups end with the dearer flush
+// and gain most from fewer, larger tables) and capped so that the launch still fills the chip twice (launch_squares = the launch's
+// pixels / 4096; 3 % slack: 16 x 1080p are 8112 squares and take 8 per table). The measurements behind the thresholds:
+// pcs_kernels.hip, launch_fused_voxel_partials. force > 0 (PCS_VOXEL_ROUNDS) overrides the rule.
+struct VoxPatchShape { int squares, rx; };
+inline VoxPatchShape vox_patch_shape(unsigned leaf_mm, bool regions, unsigned long long launch_squares, int force)
+{
+    unsigned long long cap = (launch_squares + launch_squares / 32u) / 1024u;
+    if (cap < 1u) cap = 1u;
+    const unsigned long long by_leaf = leaf_mm < 30u ? 1u : regions ? (leaf_mm >= 150u ? 8u : leaf_mm >= 40u ? 4u : 2u) : (leaf_mm >= 45u ? 4u : 2u);
+    unsigned long long r = by_leaf < cap ? by_leaf : cap;
+    if (force > 0) r = (unsigned long long)force;
+    const int squares = r >= 8u ? 8 : r >= 4u ? 4 : r >= 2u ? 2 : 1;
+    return VoxPatchShape{squares, squares == 8 ? 4 : squares >= 2 ? 2 : 1};
+}
+
 // Workgroup `lin` (= blockIdx.y * gridDim.x + blockIdx.x) of a launch over n_streams streams (= gridDim.y): its stream, the
 // first square of its patch and the patch's extent in squares. All streams' head patches come first, then all tail patches.
 // A macro, so that the kernel's code is this text itself (a function taking references compiled to a different register

@@ -72,6 +72,19 @@ int main()
     if (c5.na != 120 || c5.nb != 15 || c5.ya != 16 || c5.rxb != 2) { printf("config 5: na %d nb %d ya %d rxb %d\n", c5.na, c5.nb, c5.ya, c5.rxb); return 1; }
     const VoxTiling c8 = vox_tiling_make(1920, 1080, 64, 4, 2, 0);
     if (c8.na != 64 || c8.nb != 8 || c8.gxa != 8) { printf("8 squares: na %d nb %d gxa %d\n", c8.na, c8.nb, c8.gxa); return 1; }
+    // the squares-per-table rule (the thresholds the record was taken with)
+    struct { unsigned leaf; bool regions; unsigned long long sq; int force, squares, rx; } rule[] = {
+        {50, true, 8112, 0, 4, 2}, {50, false, 8112, 0, 4, 2}, {40, true, 8112, 0, 4, 2}, {40, false, 8112, 0, 2, 2}, {36, true, 8112, 0, 2, 2},
+        {150, true, 8112, 0, 8, 4}, {200, false, 8112, 0, 4, 2}, {29, true, 8112, 0, 1, 1}, {30, true, 8112, 0, 2, 2},
+        {200, true, 1800, 0, 1, 1}, {200, true, 4096, 0, 4, 2}, {200, true, 2100, 0, 2, 2}, {200, true, 7900, 0, 4, 2}, {200, true, 7944, 0, 8, 4},
+        {50, true, 8112, 8, 8, 4}, {50, true, 8112, 3, 2, 2}, {10, true, 100, 5, 4, 2}, {32767, true, 1ull << 40, 0, 8, 4}, {1, false, 0, 0, 1, 1}};
+    for (auto& q : rule) {
+        const VoxPatchShape sh = vox_patch_shape(q.leaf, q.regions, q.sq, q.force);
+        if (sh.squares != q.squares || sh.rx != q.rx || sh.squares % sh.rx) {
+            printf("rule: leaf %u regions %d squares %llu force %d -> %d x (rx %d), expected %d (rx %d)\n", q.leaf, (int)q.regions, q.sq, q.force, sh.squares, sh.rx, q.squares, q.rx);
+            return 1;
+        }
+    }
     printf("ok %lld launches %lld squares\n", launches, squares);
     return 0;
 }
@@ -90,4 +103,4 @@ def test_every_square_is_visited_exactly_once(tmp_path):
 
 def test_the_kernel_and_the_launcher_use_this_header():
     src = open(os.path.join(os.path.dirname(HEADER), "pcs_kernels.hip")).read()
-    assert '#include "pcs_vox_tiling.h"' in src and "PCS_VOX_TILING_DECODE(tl, lin, gridDim.y" in src and "vox_tiling_make(max_w, max_h, kVoxRows" in src
+    assert '#include "pcs_vox_tiling.h"' in src and "PCS_VOX_TILING_DECODE(tl, lin, gridDim.y" in src and "vox_tiling_make(max_w, max_h, kVoxRows" in src and "vox_patch_shape(vs.leaf" in src
