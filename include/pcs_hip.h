@@ -293,9 +293,13 @@ int pcs_transform_payloads_device(pcs_ctx* ctx, int n_cams, const pcs_payload_de
  * NOT in the reference (it includes pcl/filters/voxel_grid.h but never instantiates it). Defined in the
  * payload's integer millimetre domain: voxel = floor(coord / leaf_mm) per axis; one output point per occupied
  * voxel = integer mean of x,y,z (truncating) and of R,G,B; output sorted by (z,y,x) voxel, x fastest.
- * The output needs room for n_points points in the worst case. *d_out_points / *out_points = voxels written (the device forms
- * write -1 there if the bucket tail gave up waiting for one of its own workgroups after ~0.5 s — a stalled device; the host form
- * turns that into PCS_ERR_HIP. It has not been observed; the wait is bounded so that a launch can end wrong but never hang).
+ * The output needs room for n_points points in the worst case. *d_out_points / *out_points = voxels written. The device forms
+ * write -1 there if the bucket tail gave up waiting for one of its own workgroups after ~0.5 s (a stalled or preempted device; the
+ * wait is bounded so that a launch can end wrong but never hang; it has not been observed outside pcs_inject_voxel_stall): the
+ * bytes of such a call are NOT valid. Whoever reads a negative count calls pcs_set_voxel_tail(ctx, PCS_VOXEL_TAIL_LSD_LATCHED) and
+ * runs the call again — the LSD tail waits for nobody. Every form of this library that reads the count itself does exactly that
+ * (pcs_voxel_grid, libpcs_node's waits, the CLIs) and reports PCS_ERR_HIP only if the second run is negative too: a negative
+ * length never reaches a caller's size arithmetic or the wire (src/pcs-multicamera-client.cpp:394-403).
  * The device form is fully asynchronous on the context stream (pre-aggregation, radix sort and segmented mean are
  * hand-written kernels that read their sizes from device memory; no host round trip in the middle).            */
 int pcs_voxel_grid_device(pcs_ctx* ctx, const int16_t* d_payload, int n_points, int leaf_mm,
@@ -323,7 +327,15 @@ int pcs_voxel_grid_device_counted(pcs_ctx* ctx, const int16_t* d_payload, const 
 #define PCS_VOXEL_TAIL_AUTO   0
 #define PCS_VOXEL_TAIL_BUCKET 1
 #define PCS_VOXEL_TAIL_LSD    2
+/* after a flagged call (*out_points == -1): LSD from here on for this context, NOT overridable by the environment, both control
+ * blocks of the workspace cleared before the next call; counted by pcs_voxel_tail_reruns. AUTO / BUCKET / LSD lift the latch. */
+#define PCS_VOXEL_TAIL_LSD_LATCHED 3
 int pcs_set_voxel_tail(pcs_ctx* ctx, int tail);
+int pcs_voxel_tail_reruns(const pcs_ctx* ctx);     /* how often LSD_LATCHED was set on this context (by the library or the caller) */
+/* Fault injection (tests; the CLIs: environment PCS_BKT_INJECT_STALL=<launches>, read once): the next `launches` bucket-tail
+ * launches of this PROCESS run with their first workgroup asleep for 0.4 ms and a 20 us wait bound, i.e. they give up and end
+ * flagged exactly as a launch on a stalled device would. 0 clears.                                                          */
+int pcs_inject_voxel_stall(int launches);
 
 /* Rasters -> voxel grid in one asynchronous call, WITHOUT materialising the stitched cloud: the result (bytes and
  * *d_out_points) is exactly pcs_voxel_grid_device applied to the payload pcs_process_frames_device would write for the

@@ -174,6 +174,11 @@ int  pcs_node_process_voxel_device(pcs_node* node, const uint16_t* const* d_dept
 int  pcs_node_submit_voxel_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int16_t* d_voxels_root, size_t voxels_shorts, int* ticket);
 int  pcs_node_wait_voxel(pcs_node* node, int ticket, int* n_voxels);
+/* A voxel frame-set whose bucket tail ended flagged (device count -1: include/pcs_hip.h, pcs_voxel_grid_device) is run again by
+ * the wait that finds it, on the LSD tail, which is then latched for that context; *n_voxels is never negative, and PCS_ERR_HIP is
+ * returned if the second run is flagged too. For that the rasters handed to pcs_node_submit_voxel_device stay the caller's to
+ * keep valid until the ticket's wait has returned. This counts the frame-sets that were run again (0 on a healthy device).    */
+int  pcs_node_voxel_reruns(const pcs_node* node);
 /* Host form: rasters uploaded to their owning GPUs, the voxel cloud downloaded into `out` with the wire header like
  * pcs_node_process ([int32 bytes][records] when write_header; records always start at out + 2 shorts).              */
 int  pcs_node_process_voxel(pcs_node* node, const uint16_t* const* depth, const uint8_t* const* color, int leaf_mm, int route,

@@ -290,8 +290,18 @@ class PcsContext:
         return [int(per[i]) for i in range(n)], total.value
 
     def set_voxel_tail(self, tail: int) -> None:
-        """0 = by the leaf (default), 1 = bucket tail, 2 = LSD sort + segmented mean; see pcs_set_voxel_tail."""
+        """0 = by the leaf (default), 1 = bucket tail, 2 = LSD sort + segmented mean, 3 = LSD latched after a flagged call
+        (what a caller of the device forms sets when it reads a voxel count of -1, before it runs the call again); see
+        pcs_set_voxel_tail."""
         self._check(self._lib.pcs_set_voxel_tail(self._h, int(tail)))
+
+    def voxel_tail_reruns(self) -> int:
+        """How often the LSD tail was latched on this context after a flagged bucket-tail call (pcs_voxel_tail_reruns)."""
+        return int(self._lib.pcs_voxel_tail_reruns(self._h))
+
+    def inject_voxel_stall(self, launches: int) -> None:
+        """Fault injection: the next `launches` bucket-tail launches of this process end flagged (pcs_inject_voxel_stall)."""
+        self._check(self._lib.pcs_inject_voxel_stall(int(launches)))
 
     # -- voxel grid (defined by this build; see include/pcs_hip.h) --------------------------------
     def voxel_grid(self, payload: np.ndarray, leaf_mm: int) -> np.ndarray:

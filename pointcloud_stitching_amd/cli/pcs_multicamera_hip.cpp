@@ -40,6 +40,7 @@
 #include <iostream>
 #include <string>
 #include <thread>
+#include <functional>
 #include <vector>
 
 #include <getopt.h>
@@ -272,10 +273,18 @@ int main(int argc, char** argv)
         }
         if (!stitched.resize(PCS_HEADER_SHORTS + vox_cap_points * PCS_POINT_SHORTS)) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
     }
-    // the voxel cloud of whatever d_vox / d_nvox hold -> stitched (header + records)
-    auto fetch_voxels = [&]() -> bool {
+    // the voxel cloud of whatever d_vox / d_nvox hold -> stitched (header + records). `again` repeats the device call that filled
+    // them: a count of -1 (the bucket tail gave up on a stalled device, include/pcs_hip.h) is answered by one more run on the LSD
+    // tail; a negative length never reaches the size arithmetic below or the wire (the reference sends `size` as it is, :394-403)
+    auto fetch_voxels = [&](const std::function<int()>& again) -> bool {
         int32_t nv = 0;
         if (pcs_memcpy_d2h(ctx, &nv, d_nvox, sizeof nv) != PCS_OK || pcs_synchronize(ctx) != PCS_OK) return false;
+        if (nv < 0) {
+            std::cerr << "voxel grid: the bucket tail gave up waiting for a workgroup; running the frame-set again on the LSD tail" << std::endl;
+            if (pcs_set_voxel_tail(ctx, PCS_VOXEL_TAIL_LSD_LATCHED) != PCS_OK || again() != PCS_OK) return false;
+            if (pcs_memcpy_d2h(ctx, &nv, d_nvox, sizeof nv) != PCS_OK || pcs_synchronize(ctx) != PCS_OK) return false;
+            if (nv < 0) { std::cerr << "voxel grid: negative count on the LSD tail too" << std::endl; return false; }
+        }
         size_bytes = nv * PCS_POINT_BYTES;
         if (size_bytes && pcs_memcpy_d2h(ctx, stitched.data() + PCS_HEADER_SHORTS, d_vox, (size_t)size_bytes) != PCS_OK) return false;
         if (pcs_synchronize(ctx) != PCS_OK) return false;
@@ -348,6 +357,8 @@ int main(int argc, char** argv)
         const double mpix = (double)n_streams * W * H / 1e6;
         std::cout << "Pipelined " << (voxel_leaf ? "voxel grid" : "stitch") << " over " << n_gpus << " peer(s): " << ms << " ms per frame-set, "
                   << mpix / ms * 1e3 << " Mpoints/s in, " << last_n << (voxel_leaf ? " voxels" : " points") << std::endl;
+        if (voxel_leaf && pcs_node_voxel_reruns(node) > 0)
+            std::cout << "Voxel frame-sets run again on the LSD tail after a flagged bucket tail: " << pcs_node_voxel_reruns(node) << std::endl;
         if (timer && iters > 1)
             std::cout << "GPU " << ids[0] << " per frame-set: kernels " << k_ms / (iters - 1) << " ms, exchange " << x_ms / (iters - 1)
                       << " ms, root " << r_ms / (iters - 1) << " ms (" << st.exchanged_bytes << " B into the root)" << std::endl;
@@ -435,10 +446,13 @@ int main(int argc, char** argv)
                     if (pcs_memcpy_h2d(ctx, d_depth[s], depth[s].data(), depth[s].size() * 2) != PCS_OK ||
                         pcs_memcpy_h2d(ctx, d_color[s], color[s].data(), color[s].size()) != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
                 }
-                rc = pcs_process_frames_voxel_device(ctx, reinterpret_cast<const uint16_t* const*>(d_depth.data()),
-                                                     reinterpret_cast<const uint8_t* const*>(d_color.data()), voxel_leaf,
-                                                     static_cast<int16_t*>(d_vox), vox_cap_points * PCS_POINT_SHORTS, static_cast<int32_t*>(d_nvox));
-                if (rc != PCS_OK || !fetch_voxels()) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+                auto run_voxel = [&]() {
+                    return pcs_process_frames_voxel_device(ctx, reinterpret_cast<const uint16_t* const*>(d_depth.data()),
+                                                           reinterpret_cast<const uint8_t* const*>(d_color.data()), voxel_leaf,
+                                                           static_cast<int16_t*>(d_vox), vox_cap_points * PCS_POINT_SHORTS, static_cast<int32_t*>(d_nvox));
+                };
+                rc = run_voxel();
+                if (rc != PCS_OK || !fetch_voxels(run_voxel)) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
             } else if (node) {
                 rc = pcs_node_process(node, dp.data(), cp.data(), stitched.data(), stitched.size(), 1, nullptr, &size_bytes);
                 if (rc != PCS_OK) { std::cerr << pcs_node_last_error(node) << std::endl; return 1; }
@@ -476,9 +490,12 @@ int main(int argc, char** argv)
                                    (size_t)n_streams * cam_cap_bytes / 2, &total_pts);
             if (rc != PCS_OK) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
             if (voxel_leaf) {
-                rc = pcs_voxel_grid_device(ctx, static_cast<const int16_t*>(d_stitched), total_pts, voxel_leaf, static_cast<int16_t*>(d_vox),
-                                           vox_cap_points * PCS_POINT_SHORTS, static_cast<int32_t*>(d_nvox));
-                if (rc != PCS_OK || !fetch_voxels()) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
+                auto run_voxel = [&]() {
+                    return pcs_voxel_grid_device(ctx, static_cast<const int16_t*>(d_stitched), total_pts, voxel_leaf, static_cast<int16_t*>(d_vox),
+                                                 vox_cap_points * PCS_POINT_SHORTS, static_cast<int32_t*>(d_nvox));
+                };
+                rc = run_voxel();
+                if (rc != PCS_OK || !fetch_voxels(run_voxel)) { std::cerr << pcs_last_error(ctx) << std::endl; return 1; }
             } else {
                 size_bytes = total_pts * PCS_POINT_BYTES;
                 if (size_bytes && pcs_memcpy_d2h(ctx, stitched.data() + PCS_HEADER_SHORTS, d_stitched, (size_t)size_bytes) != PCS_OK) return 1;

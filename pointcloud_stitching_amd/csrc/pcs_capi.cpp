@@ -84,6 +84,7 @@ struct pcs_ctx {
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
     void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
     VoxelWsState                    vox_state;          // which control block of s_voxel_ws the next voxel call uses
+    int                             voxel_reruns = 0;   // calls that ended flagged (-1) and latched the LSD tail (pcs_voxel_tail_reruns)
     int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
     int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
     uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
@@ -1556,9 +1557,24 @@ static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_po
 int pcs_set_voxel_tail(pcs_ctx* c, int tail)
 {
     if (!c) return PCS_ERR_INVALID_ARG;
-    if (tail != PCS_VOXEL_TAIL_AUTO && tail != PCS_VOXEL_TAIL_BUCKET && tail != PCS_VOXEL_TAIL_LSD)
+    if (tail != PCS_VOXEL_TAIL_AUTO && tail != PCS_VOXEL_TAIL_BUCKET && tail != PCS_VOXEL_TAIL_LSD && tail != PCS_VOXEL_TAIL_LSD_LATCHED)
         return fail(c, PCS_ERR_INVALID_ARG, "unknown voxel tail %d", tail);
+    if (tail == PCS_VOXEL_TAIL_LSD_LATCHED) {
+        // (the flagged call's control block is cleared by the next call as any other's; clearing both costs one memset, once)
+        c->vox_state.stalled = true; c->vox_state.clean = false; c->vox_state.spl_leaf = 0;
+        c->voxel_reruns++;
+        return PCS_OK;
+    }
     c->vox_state.tail_pref = tail;
+    c->vox_state.stalled = false;
+    return PCS_OK;
+}
+
+int pcs_voxel_tail_reruns(const pcs_ctx* c) { return c ? c->voxel_reruns : 0; }
+
+int pcs_inject_voxel_stall(int launches)
+{
+    pcs::inject_voxel_stall(launches);
     return PCS_OK;
 }
 
@@ -1749,8 +1765,17 @@ int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm
     int32_t nv = 0;
     HIPCHK(c, hipMemcpyAsync(&nv, c->d_counts, sizeof nv, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nv < 0)       // the device forms report this count as it is (-1); see include/pcs_hip.h
-        return fail(c, PCS_ERR_HIP, "the voxel pipeline gave up waiting for one of its own workgroups (device stalled?)");
+    if (nv < 0) {
+        // the bucket tail gave up waiting for one of its own workgroups (the device forms report the -1 as it is; see
+        // include/pcs_hip.h): the input is still in s_voxel_in — once more on the LSD tail, which waits for nobody, and LSD for
+        // this context from here on
+        if ((rc = pcs_set_voxel_tail(c, PCS_VOXEL_TAIL_LSD_LATCHED))) return rc;
+        rc = pcs_voxel_grid_device(c, c->s_voxel_in, n_points, leaf_mm, c->s_voxel_out, (size_t)n_points * PCS_POINT_SHORTS, c->d_counts);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(&nv, c->d_counts, sizeof nv, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (nv < 0) return fail(c, PCS_ERR_HIP, "the voxel pipeline reported a negative count on the LSD tail");
+    }
     if (out_shorts < (size_t)nv * PCS_POINT_SHORTS)
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts, %zu needed", out_shorts, (size_t)nv * PCS_POINT_SHORTS);
     if (nv) HIPCHK(c, hipMemcpy(out, c->s_voxel_out, (size_t)nv * PCS_POINT_BYTES, hipMemcpyDeviceToHost));

@@ -172,6 +172,7 @@ struct VoxelWsState {
     int         spl_leaf = 0;       // bucket tail: the leaf the workspace's splitters were made for (0: none)
     uint32_t    bkt_calls = 0;      // bucket-tail calls enqueued on this workspace (tags their published counts)
     int         tail_pref = 0;      // pcs_set_voxel_tail: 0 by the leaf, 1 bucket, 2 LSD (the environment overrides)
+    bool        stalled = false;    // a bucket-tail call of this owner ended flagged (-1): LSD from here on, whatever the environment says
 };
 hipError_t launch_voxel_grid(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points, int leaf_mm, void* d_ws,
                              size_t ws_bytes, VoxelWsState* ws, int16_t* d_out, int32_t* d_out_points, hipStream_t st);
@@ -211,6 +212,8 @@ hipError_t voxel_partials_stage(int leaf_mm, unsigned long long* d_keys, void* d
 hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const void* d_partials, uint32_t n_partials,
                                       const int32_t* d_n_partials, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState* ws,
                                       int16_t* d_out, int32_t* d_out_points, hipStream_t st);
+// fault injection: the next `launches` bucket-tail launches end flagged (*out_points = -1), as after a stalled workgroup
+void inject_voxel_stall(int launches);
 // the same table fed from a 16-byte aligned payload (pcs_kernels.hip; the unaligned forms stay in pcs_voxel.hip)
 hipError_t launch_payload_voxel_partials(const int16_t* d_payload, uint32_t n_points, const int32_t* d_n_points,
                                          const VoxelStage& vs, hipStream_t st);

@@ -62,6 +62,8 @@ struct Ticket {
     int leaf = 0;
     int16_t* d_voxels = nullptr;
     size_t voxels_shorts = 0;
+    std::vector<const uint16_t*> d_depth; // one-call voxel ticket: the rasters, should the call have to be run again (flagged bucket tail)
+    std::vector<const uint8_t*> d_color;
     int64_t exchanged_bytes = 0;          // moved by the grouped RCCL exchange
     int64_t direct_bytes = 0;             // stored into the root's buffer by the peers' own kernels (PCS_NODE_DIRECT_STORE)
     float submit_host_ms = 0.0f, exchange_host_ms = 0.0f;     // host time spent enqueueing (submit without / the exchange itself)
@@ -106,6 +108,7 @@ struct pcs_node {
     hipEvent_t ev_k0[2] = {nullptr, nullptr}, ev_k1[2] = {nullptr, nullptr}, ev_r0[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     hipEvent_t ev_x0[2] = {nullptr, nullptr};     // root: comm stream, the group is about to be enqueued
     pcs_node_stats last{};
+    int voxel_reruns = 0;                 // voxel frame-sets whose bucket tail ended flagged (-1) and were run again on the LSD tail
     int rccl_version = 0;                 // ncclGetVersion of the library that answered (0: no communicator was asked for)
     std::string rccl_library;             // its path (dladdr)
     std::string err;
@@ -912,6 +915,7 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
         HIPCHK(n, hipEventRecord(p.packed[slot], ks));
         HIPCHK(n, hipEventRecord(n->ev_done[slot], ks));
         tk.one_call = true; tk.exchanged = true; tk.busy = true;
+        tk.d_depth.assign(d_depth, d_depth + (size_t)P * S); tk.d_color.assign(d_color, d_color + (size_t)P * S);
         tk.submit_host_ms = (float)(now_ms() - t_host0);
         *ticket = n->next_ticket++;
         flush_other(n, slot);
@@ -943,12 +947,37 @@ int pcs_node_wait_voxel(pcs_node* n, int ticket, int* n_voxels)
     Ticket* tk = nullptr;
     const int rc = wait_common(n, ticket, kVoxel, tk);
     if (rc != PCS_OK) return rc;
-    HIPCHK(n, hipSetDevice(n->peers[0].dev));
-    HIPCHK(n, hipEventSynchronize(n->ev_done[ticket & 1]));
-    if (n_voxels) *n_voxels = n->h_vcount[ticket & 1][n->n_peers];
+    const int slot = ticket & 1, P = n->n_peers;
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
+    HIPCHK(n, hipEventSynchronize(n->ev_done[slot]));
     fill_stats(n, *tk);
+    if (n->h_vcount[slot][P] < 0) {
+        // The bucket tail gave up waiting for one of its own workgroups (include/pcs_hip.h): the bytes in d_voxels are not valid.
+        // Once more on the LSD tail, which waits for nobody, latched for that context; what the tail read is still where it was
+        // (the rasters of a one-call ticket are the caller's until this wait returns; the merged partials sit in this slot's
+        // arrays until the slot's next submit). It queues behind whatever the next submit already enqueued on that stream.
+        pcs_ctx* vc = tk->one_call ? root.ctx : n->reduce_ctx;
+        PCSCHK(n, vc, pcs_set_voxel_tail(vc, PCS_VOXEL_TAIL_LSD_LATCHED));
+        n->voxel_reruns++;
+        hipStream_t vs = static_cast<hipStream_t>(pcs_get_stream(vc));
+        if (tk->one_call)
+            PCSCHK(n, vc, pcs_process_frames_voxel_device(vc, tk->d_depth.data(), tk->d_color.data(), tk->leaf, tk->d_voxels, tk->voxels_shorts,
+                                                          static_cast<int32_t*>(n->d_vox_n[slot])));
+        else
+            PCSCHK(n, vc, pcs_voxel_grid_from_partials_device(vc, static_cast<const uint64_t*>(root.d_vkeys[slot]),
+                                                              static_cast<const pcs_voxel_partial*>(root.d_vparts[slot]), (int)tk->total, nullptr,
+                                                              tk->leaf, tk->d_voxels, tk->voxels_shorts, static_cast<int32_t*>(n->d_vox_n[slot])));
+        HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, vs));
+        HIPCHK(n, hipStreamSynchronize(vs));
+        if (n->h_vcount[slot][P] < 0)
+            return nfail(n, PCS_ERR_HIP, "the voxel pipeline reported a negative count on the LSD tail too (device stalled?)");
+    }
+    if (n_voxels) *n_voxels = n->h_vcount[slot][P];
     return PCS_OK;
 }
+
+int pcs_node_voxel_reruns(const pcs_node* n) { return n ? n->voxel_reruns : 0; }
 
 int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int route, int16_t* d_voxels, size_t voxels_shorts, int* n_voxels, pcs_node_voxel_stats* stats)
@@ -1002,6 +1031,14 @@ int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, c
         HIPCHK(n, hipEventRecord(n->ev_done[0], ks));
         int32_t v = 0;
         PCSCHK(n, root.ctx, pcs_memcpy_d2h(root.ctx, &v, n->d_vox_n[0], sizeof v));        // synchronises the root's kernel stream
+        if (v < 0) {        // flagged bucket tail: the stitched cloud is still there — again on the LSD tail (pcs_node_wait_voxel)
+            PCSCHK(n, root.ctx, pcs_set_voxel_tail(root.ctx, PCS_VOXEL_TAIL_LSD_LATCHED));
+            n->voxel_reruns++;
+            PCSCHK(n, root.ctx, pcs_voxel_grid_device(root.ctx, static_cast<const int16_t*>(n->d_stitched), total, leaf_mm, d_voxels,
+                                                      voxels_shorts, static_cast<int32_t*>(n->d_vox_n[0])));
+            PCSCHK(n, root.ctx, pcs_memcpy_d2h(root.ctx, &v, n->d_vox_n[0], sizeof v));
+            if (v < 0) return nfail(n, PCS_ERR_HIP, "the voxel pipeline reported a negative count on the LSD tail too (device stalled?)");
+        }
         nv = v;
         (void)hipEventElapsedTime(&st.root_ms, n->ev_r0[0], n->ev_done[0]);
         st.reduced = total;

@@ -27,6 +27,7 @@
 // (Round 1 used rocPRIM's radix_sort_pairs + reduce_by_key for steps 2-3: 0.56 ms of library kernels per call at 50 mm,
 // plus a stream synchronisation in the middle of the call to learn m.)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1104,7 +1105,11 @@ __device__ __forceinline__ void bkt_hash(unsigned long long key, unsigned int& f
 // generation: nobody clears the words) as soon as they know them. Waiting on LOWER-numbered workgroups only is safe on hardware
 // that starts workgroups in order (what rocPRIM's look-back scan relies on too); the wait is bounded all the same: after ~0.5 s
 // the workgroup gives up, flags the call (ctl[3] -> *out_points = -1) and carries on, so a launch can end wrong but never hang.
-__device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsigned int b, unsigned int gen, unsigned int* ctl, unsigned int* wsum)
+// The host forms that read the count re-run a flagged call on the LSD tail (pcs_capi.cpp, pcs_node.cpp). `bound`: the wait in
+// 100 MHz ticks (kBktWaitTicks; a launch with an injected stall, pcs_inject_voxel_stall, waits 20 us only).
+constexpr long long kBktWaitTicks = 50000000ll, kBktStallWaitTicks = 2000ll, kBktStallTicks = 40000ll;
+__device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsigned int b, unsigned int gen, unsigned int* ctl, unsigned int* wsum,
+                                                 const long long bound)
 {
     unsigned int sum = 0;
     bool gave_up = false;
@@ -1115,7 +1120,7 @@ __device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsign
             do {
                 __builtin_amdgcn_s_sleep(4);
                 v = __hip_atomic_load(pub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((v >> 26) != gen && wall_clock64() - t0 < 50000000ll);
+            } while ((v >> 26) != gen && wall_clock64() - t0 < bound);
             if ((v >> 26) != gen) { gave_up = true; v = 0u; }
         }
         sum += v & ((1u << 26) - 1u);
@@ -1338,7 +1343,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                                const unsigned int* __restrict__ cursor, unsigned int* __restrict__ cursor_next,
                                const unsigned long long* __restrict__ kscr_list, const VoxelPartial* __restrict__ pscr_list,
                                const unsigned short* __restrict__ ov_ids, unsigned long long* __restrict__ gath_k,
-                               VoxelPartial* __restrict__ gath_p)
+                               VoxelPartial* __restrict__ gath_p, const unsigned int stall)
 {
     __shared__ unsigned long long tkey[kBktSlots];
     __shared__ unsigned long long tx[kBktSlots], ty[kBktSlots], tz[kBktSlots], tr[kBktSlots], tg[kBktSlots], tbn[kBktSlots];
@@ -1351,6 +1356,13 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     unsigned int m = ctl[0];
     const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // fault injection (pcs_inject_voxel_stall; the tests walk the give-up path with it): bucket 0's workgroup sleeps 0.4 ms before
+    // it does anything, everybody else waits 20 us for a count — every later bucket gives up, the call ends flagged
+    const long long wait_bound = stall ? kBktStallWaitTicks : kBktWaitTicks;
+    if (stall && blockIdx.x == 0u) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < kBktStallTicks) __builtin_amdgcn_s_sleep(64);
+    }
     // WARM call (regions): the pre-aggregation put bucket b's partials into region b — reg[1] slots at b * reg[1], cursor[b] of them
     // offered — and ctl[0] counts the partials that found their region full. Every workgroup sums the counts for itself (1024
     // words): the partials before its bucket are what the splitter refresh needs, their total what the next call is sized by.
@@ -1561,7 +1573,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
                     continue;
                 }
                 BKT_STAMP(4);      // ranked: key order known
-                if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt); have_base = true; }
+                if (direct) { base = bkt_base(pub, b, gen, ctl, wcnt, wait_bound); have_base = true; }
                 BKT_STAMP(5);      // base known
                 int16_t* const rec = direct ? out : tmp_rec;
                 const unsigned int first = direct ? base : rank0 + emitted;
@@ -1607,7 +1619,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
         if (!published && threadIdx.x == 0)                    // empty buckets, and buckets that took several passes
             __hip_atomic_store(pub + b, (gen << 26) | emitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!have_base && emitted != 0u) {                     // several passes: the parked records to their final place
-            base = bkt_base(pub, b, gen, ctl, wcnt);
+            base = bkt_base(pub, b, gen, ctl, wcnt, wait_bound);
             have_base = true;
             __threadfence_block();
             const int16_t* __restrict__ src = tmp_rec + (size_t)rank0 * PCS_POINT_SHORTS;
@@ -1617,7 +1629,7 @@ void pcs_vox_bkt_reduce_kernel(const unsigned long long* __restrict__ keys_s, co
         if (threadIdx.x == 0) cursor_next[b] = 0u;             // the next bucket call's cursors (nobody reads them in this launch)
         if (b == kBkt - 1u) {
             // the last bucket knows the total; it also clears the next call's control block (plan_for)
-            if (!have_base) base = bkt_base(pub, b, gen, ctl, wcnt);
+            if (!have_base) base = bkt_base(pub, b, gen, ctl, wcnt, wait_bound);
             if (threadIdx.x == 0) {
                 const unsigned int total = base + emitted;
                 const bool failed = __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -1733,8 +1745,9 @@ struct Plan {
 // ~1000 partials. With many more partials its buckets outgrow the LDS table and are worked off in several passes — the LSD
 // sort is the better tool there. The host does not know the number of partials (nothing is read back), so the choice goes by
 // the leaf: PCS_VOXEL_TAIL=bucket / lsd overrides (read at every call: the tests run both).
-bool choose_bucket_tail(int leaf_mm, int pref)
+bool choose_bucket_tail(int leaf_mm, int pref, bool stalled)
 {
+    if (stalled) return false;      // latched after a flagged call (PCS_VOXEL_TAIL_LSD_LATCHED): not for the environment to undo
     if (const char* v = getenv("PCS_VOXEL_TAIL")) {
         if (v[0] == 'b') return true;
         if (v[0] == 'l') return false;
@@ -1813,7 +1826,7 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     pl.track_bits = 3u * pl.bits > 3u * kRadixBits;
     if (track_env >= 0) pl.track_bits = track_env != 0;
     // (a bucket publishes its voxel count in 26 bits beside a 6-bit tag: clouds of 2^26 points and more take the LSD tail)
-    pl.bucket = choose_bucket_tail(leaf_mm, ws.tail_pref) && n_points < (1u << 26);
+    pl.bucket = choose_bucket_tail(leaf_mm, ws.tail_pref, ws.stalled) && n_points < (1u << 26);
     if (pl.bucket) {
         pl.idx_bits = 0;              // raw keys, as in the exchange format: the bucket tail moves the partials themselves
         pl.track_bits = false;
@@ -1826,6 +1839,23 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
         pl.regions = !(regions_env && regions_env[0] == '0') && !pl.need_sample && ws.bkt_calls > 0;
     }
     return hipSuccess;
+}
+
+// Fault injection: the next `launches` bucket-tail launches of this process run with a stalled first workgroup and end flagged
+// (*out_points = -1). PCS_BKT_INJECT_STALL=<launches> sets the counter at its first use (the CLIs have no other way in).
+std::atomic<int> g_stall_left{-1};
+bool take_injected_stall()
+{
+    int v = g_stall_left.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("PCS_BKT_INJECT_STALL");
+        int want = e ? atoi(e) : 0;
+        if (want < 0) want = 0;
+        if (g_stall_left.compare_exchange_strong(v, want)) v = want; else v = g_stall_left.load();
+    }
+    while (v > 0)
+        if (g_stall_left.compare_exchange_weak(v, v - 1)) return true;
+    return false;
 }
 
 // The bucket tail on the partials a pre-aggregation left in the workspace (or a caller handed over: pl.raw).
@@ -1848,7 +1878,7 @@ hipError_t bucket_tail(const Plan& pl, uint32_t n_points, int16_t* d_out, int32_
                        (long long*)(PCS_BKT_TRACE && getenv("PCS_BKT_TRACE_PTR") ? strtoull(getenv("PCS_BKT_TRACE_PTR"), nullptr, 0) : 0ull),
                        pl.regions ? 1u : 0u, w.keys_r, w.part_r, (unsigned int)std::min<size_t>(w.region_slots, 0xFFFFFFFFu),
                        w.reg + 64 * pl.bpar, w.reg + 64 * (pl.bpar ^ 1u), w.cursor + kBkt * pl.bpar, w.cursor + kBkt * (pl.bpar ^ 1u),
-                       w.keys_a, w.part, w.bucket_of, w.keys_s, w.part_s);
+                       w.keys_a, w.part, w.bucket_of, w.keys_s, w.part_s, take_injected_stall() ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -1913,6 +1943,8 @@ hipError_t finish_call(VoxelWsState& ws, hipError_t e, int bucket_leaf = 0)
 }
 
 }  // namespace
+
+void inject_voxel_stall(int launches) { g_stall_left.store(launches < 0 ? 0 : launches); }
 
 // d_n_points != nullptr: the number of points is read from device memory (<= n_points, which then is the capacity that
 // sizes the workspace and the grids)

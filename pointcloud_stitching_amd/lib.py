@@ -50,6 +50,8 @@ SYMBOLS = [
     ("pcs_stitch_device", C.c_int, [_VP, _P(_VP), _P(C.c_int), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_transform_payloads_device", C.c_int, [_VP, C.c_int, _P(PayloadDesc), C.c_int, _VP, C.c_size_t, _P(C.c_int), _P(C.c_int)]),
     ("pcs_set_voxel_tail", C.c_int, [_VP, C.c_int]),
+    ("pcs_voxel_tail_reruns", C.c_int, [_VP]),
+    ("pcs_inject_voxel_stall", C.c_int, [C.c_int]),
     ("pcs_voxel_grid_device", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     ("pcs_voxel_grid_device_counted", C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     ("pcs_process_frames_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, C.c_size_t, _VP]),

@@ -68,6 +68,7 @@ SYMBOLS = [
     ("pcs_node_last_stats", C.c_int, [_VP, _P(NodeStats)]),
     ("pcs_node_submit_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_node_wait_voxel", C.c_int, [_VP, C.c_int, _P(C.c_int)]),
+    ("pcs_node_voxel_reruns", C.c_int, [_VP]),
     ("pcs_node_process_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int), _P(VoxelStats)]),
     ("pcs_node_process_voxel", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(VoxelStats)]),
 ]
@@ -228,6 +229,10 @@ class PcsNode:
         nv = C.c_int(0)
         self._check(self._lib.pcs_node_wait_voxel(self._h, int(ticket), C.byref(nv)))
         return nv.value
+
+    def voxel_reruns(self) -> int:
+        """Voxel frame-sets this node ran again on the LSD tail after a flagged bucket tail (pcs_node_voxel_reruns)."""
+        return int(self._lib.pcs_node_voxel_reruns(self._h))
 
     def process_voxel(self, depth, color, leaf_mm: int, route: int = VOXEL_PARTIALS):
         """pcs_node_process_voxel: host rasters in -> (voxel records int16 [n,5], stats dict)."""
