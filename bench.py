@@ -628,7 +628,7 @@ def run_node(args):
             # one peer: submit enqueued the rasters -> voxels call (no partials leave the library). Beside it, the same loop with the
             # partials pipeline a node of several peers runs (pre-aggregation of k+1 beside the root's sort + mean of k)
             node.set_timing(False)
-            os.environ["PCS_NODE_ONE_CALL"] = "0"
+            node.set_one_call(False)
             try:
                 run(max(args.warmup, 4)); sync_all()
                 t1 = time.perf_counter(); run(args.steps); sync_all()
@@ -637,7 +637,7 @@ def run_node(args):
                                    "note": "partials_pipeline = PCS_NODE_ONE_CALL=0: partials to caller-held arrays, sort + mean on a second "
                                            "context beside the next frame-set's pre-aggregation (what a node of several peers runs on its root)"}
             finally:
-                del os.environ["PCS_NODE_ONE_CALL"]
+                node.set_one_call(True)
     else:
         out["per_stream_fps"] = round(args.steps / elapsed, 1)
         out["points_per_stream"] = counts

@@ -278,9 +278,12 @@ int pcs_stitch_device(pcs_ctx* ctx, const int16_t* const* d_cam_payload, const i
  * payload (what `*stitched_cloud += *cloud_ptr[i]`, :361-364, and convertPointCloudXYZRGBToBuffer produce); all cameras of a
  * call share launches of up to 16 clouds. `cams` is a HOST array whose payload pointers are DEVICE pointers. A camera may be
  * transformed in place (its output slice starting exactly at its input, downsample 1); any other overlap of an input with an
- * output slice is refused. points_per_cam (optional, host) and *total_points are host-known: ceil(n_points / downsample)
- * (the reference sizes its cloud with size / downsample, rounded DOWN, and then writes past it when size % downsample != 0,
- * :231-246; the ceiling is what its loop produces). 20 B of HBM traffic per kept record.                                    */
+ * output slice is refused. points_per_cam (optional, host) and *total_points are host-known: FLOOR(n_points / downsample) —
+ * the reference sizes its cloud with size / downsample, rounded down (:230); when size % downsample != 0 its loop writes one
+ * element past the vector (:235-246, undefined behaviour that never grows it), and transformPointCloud, += and
+ * convertPointCloudXYZRGBToBuffer (`i < cloud->width`, :253) all iterate the width: the last partial stride's record is not
+ * sent. (pcs_stitch_device keeps CEIL(n / downsample): that is the other program's loop, `j += 5 * downsample` while
+ * j < buf_len, src/pcs-multicamera-client.cpp:388.) 20 B of HBM traffic per kept record.                                      */
 typedef struct pcs_payload_desc {
     const int16_t* d_payload;      /* the camera's packed records (no header), device memory                             */
     int32_t        n_points;

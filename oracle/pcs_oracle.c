@@ -213,7 +213,11 @@ int pcs_oracle_transform_payload(const int16_t* in, int n_points, int downsample
 {
     int count = 0;
     if (downsample < 1) downsample = 1;
-    for (int i = 0; i < n_points; i++) {
+    /* :230-233 the cloud is sized width = size / downsample, rounded DOWN; when size % downsample != 0 the loop of :235-246 writes
+     * one element past points[] (undefined behaviour that never grows the vector), and everything downstream — transformPointCloud
+     * (:289), += (:361-364), convertPointCloudXYZRGBToBuffer (:253, `i < cloud->width`) — iterates the width: floor(n / d) records */
+    const int width = n_points / downsample;
+    for (int i = 0; i < n_points && count < width; i++) {
         if (i % downsample != 0) continue;                                               /* :236 */
         const float x = (float)in[i * 5 + 0] / 1000.0f;                                  /* :237 */
         const float y = (float)in[i * 5 + 1] / 1000.0f;                                  /* :238 */

@@ -351,7 +351,7 @@ int ensure(pcs_ctx* c, T*& p, size_t& cap, size_t bytes)
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 256));
-    if (e != hipSuccess) return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
     p = static_cast<T*>(q);
     cap = std::max<size_t>(bytes, 256);
     return PCS_OK;
@@ -392,13 +392,16 @@ int ensure_rasters(pcs_ctx* c)
 int ensure_voxel_ws(pcs_ctx* c, size_t need)
 {
     if (need <= c->s_voxel_ws_cap && c->s_voxel_ws) return PCS_OK;
+    const size_t exact = need;
     if (c->s_voxel_ws) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         need += need / 4;
     }
     c->vox_state.clean = false;                                                   // (a new one may land on the same address)
     c->vox_state.spl_leaf = 0;
-    return ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    int rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, need);
+    if (rc == PCS_ERR_NOMEM && need != exact) rc = ensure(c, c->s_voxel_ws, c->s_voxel_ws_cap, exact);      // the headroom is a wish
+    return rc;
 }
 
 struct DeviceGuard {
@@ -1493,7 +1496,9 @@ int pcs_transform_payloads_device(pcs_ctx* c, int n_cams, const pcs_payload_desc
         if (cams[i].n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "camera %d: negative point count", i);
         if (cams[i].n_points > 0 && !cams[i].d_payload) return fail(c, PCS_ERR_INVALID_ARG, "camera %d: NULL payload", i);
         first[i] = need;
-        kept[i] = ((size_t)cams[i].n_points + downsample - 1) / downsample;
+        // floor: the reference sizes the decoded cloud with size / downsample (src/pcs-multicamera-optimized.cpp:230) and every
+        // later step iterates that width; pcs_stitch_device's ceiling is the OTHER program's loop (pcs-multicamera-client.cpp:388)
+        kept[i] = (size_t)cams[i].n_points / (size_t)downsample;
         need += kept[i];
     }
     if (need * PCS_POINT_BYTES > 0x7FFFFFFFull)
@@ -1546,7 +1551,7 @@ static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_po
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every point its own voxel) needs %zu",
                     out_shorts, (size_t)n_points * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
-    const size_t need = voxel_workspace_bytes((uint32_t)n_points);
+    const size_t need = voxel_workspace_bytes((uint32_t)n_points, voxel_workspace_level((uint32_t)n_points, leaf_mm, c->vox_state, false));
     int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, d_n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out,
@@ -1625,7 +1630,7 @@ try {
         if (rc) return rc;
         return voxel_grid_device_impl(c, c->s_payload, (int)cap, c->d_counts + S, leaf_mm, d_out, out_shorts, d_out_points);
     }
-    const size_t need = voxel_workspace_bytes((uint32_t)cap);
+    const size_t need = voxel_workspace_bytes((uint32_t)cap, voxel_workspace_level((uint32_t)cap, leaf_mm, c->vox_state, false));
     int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev{};
@@ -1737,7 +1742,7 @@ try {
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every partial its own voxel) needs %zu",
                     out_shorts, (size_t)n_partials * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
-    const size_t need = voxel_workspace_bytes((uint32_t)n_partials);
+    const size_t need = voxel_workspace_bytes((uint32_t)n_partials, voxel_workspace_level((uint32_t)n_partials, leaf_mm, c->vox_state, true));
     int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,

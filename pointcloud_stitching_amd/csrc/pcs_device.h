@@ -162,7 +162,9 @@ hipError_t launch_deproject(const StreamParams* d_params, int stream, uint32_t n
                             float* d_vertices, float* d_texcoords, hipStream_t st);
 
 // Voxel-grid downsample (pcs_voxel.hip).
-size_t     voxel_workspace_bytes(uint32_t n_points);
+struct VoxelWsState;
+size_t     voxel_workspace_bytes(uint32_t n_points, int level = 2);      // level: voxel_workspace_level (0 LSD .. 2 warm bucket)
+int        voxel_workspace_level(uint32_t n_points, int leaf_mm, const VoxelWsState& ws, bool from_partials);
 // What the owner of a voxel workspace keeps between calls (pcs_voxel.hip: plan_for): which of the workspace's two control
 // blocks the next call uses, and whether both are known to be in the state that call expects.
 struct VoxelWsState {

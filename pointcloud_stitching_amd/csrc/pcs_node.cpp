@@ -97,7 +97,8 @@ struct pcs_node {
     void* d_stitched = nullptr; size_t stitched_cap_shorts = 0;      // host forms
     void* d_vox_out = nullptr;
     void* d_vox_n[2] = {nullptr, nullptr};        // root: voxel count per slot
-    bool voxel_ready = false;
+    bool voxel_ready = false, voxel_counts_ready = false;
+    bool one_call = true;                 // a one-peer node enqueues rasters -> voxels at submit (PCS_NODE_ONE_CALL, latched at create; pcs_node_set_one_call)
     size_t vcap_total = 0;
     // root: a second context of libpcs_hip (own stream, own sort workspace) that runs the sort + segmented mean of frame-set k
     // while the root's kernel stream pre-aggregates frame-set k+1: the tail is a dozen latency-bound launches that leave the GPU
@@ -222,9 +223,27 @@ int pick_concurrent_stream(pcs_node* n, hipStream_t busy, hipStream_t* out)
     return PCS_OK;
 }
 
-// Voxel route buffers, on first use: two slots of key / partial arrays per peer (the root's take everybody's partials).
+// What every voxel ticket needs, on first use: the page-locked count words and the root's device count per slot.
+int ensure_voxel_counts(pcs_node* n)
+{
+    if (n->voxel_counts_ready) return PCS_OK;
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
+    for (int sl = 0; sl < 2; sl++) {
+        if (!n->h_vcount[sl]) HIPCHK(n, hipHostMalloc((void**)&n->h_vcount[sl], sizeof(int32_t) * (size_t)(n->n_peers + 1), hipHostMallocPortable));
+        if (!n->d_vox_n[sl]) PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_vox_n[sl], 64));
+    }
+    n->voxel_counts_ready = true;
+    return PCS_OK;
+}
+
+// What the partials pipeline needs on top, on ITS first use (a one-peer node on the one-call route, or route PAYLOADS, never
+// pays for it): two slots of key / partial arrays per peer (the root's take everybody's partials), the root's second context and
+// a stream that is seen to run beside its kernel stream.
 int ensure_voxel_buffers(pcs_node* n)
 {
+    int rc0 = ensure_voxel_counts(n);
+    if (rc0 != PCS_OK) return rc0;
     if (n->voxel_ready) return PCS_OK;
     for (int r = 0; r < n->n_peers; r++) {
         Peer& p = n->peers[r];
@@ -260,10 +279,6 @@ int ensure_voxel_buffers(pcs_node* n)
         int rc2 = pick_concurrent_stream(n, kstream(root), &n->reduce_stream);
         if (rc2 != PCS_OK) return rc2;
         if (n->reduce_stream) PCSCHK(n, n->reduce_ctx, pcs_set_stream(n->reduce_ctx, n->reduce_stream));
-    }
-    for (int sl = 0; sl < 2; sl++) {
-        if (!n->h_vcount[sl]) HIPCHK(n, hipHostMalloc((void**)&n->h_vcount[sl], sizeof(int32_t) * (size_t)(n->n_peers + 1), hipHostMallocPortable));
-        if (!n->d_vox_n[sl]) PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_vox_n[sl], 64));
     }
     n->voxel_ready = true;
     return PCS_OK;
@@ -501,6 +516,7 @@ int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int
     pcs_node* n = new pcs_node;
     n->n_peers = n_devices; n->per_dev = streams_per_device; n->n_streams = n_devices * streams_per_device;
     n->flags = flags; n->downsample = downsample; n->node_flags = node_flags;
+    { const char* e = getenv("PCS_NODE_ONE_CALL"); n->one_call = !(e && e[0] == '0'); }      // latched here, not read in the frame loop
     n->cfg.assign(streams, streams + n->n_streams);
     n->pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
     n->peers.resize(n_devices);
@@ -890,10 +906,11 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     Ticket* tkp = nullptr; int slot = 0;
     int rc = check_submit(n, tkp, slot);
     if (rc != PCS_OK) return rc;
-    rc = ensure_voxel_buffers(n);
+    const int S = n->per_dev, P = n->n_peers;
+    const bool one_call = P == 1 && n->one_call;
+    rc = one_call ? ensure_voxel_counts(n) : ensure_voxel_buffers(n);
     if (rc != PCS_OK) return rc;
     Ticket& tk = *tkp;
-    const int S = n->per_dev, P = n->n_peers;
     const double t_host0 = now_ms();
     tk = Ticket{};
     tk.kind = kVoxel; tk.id = n->next_ticket; tk.leaf = leaf_mm; tk.d_voxels = d_voxels; tk.voxels_shorts = voxels_shorts;
@@ -902,8 +919,7 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     // call that goes from the rasters to the voxel cloud (warm bucket tail: two launches) on the peer's own stream. Two frame-sets
     // in flight then simply queue behind each other: 16 x 1080p at 50 mm 0.174 ms per frame-set, against 0.205 for the
     // partials / reduce-on-a-second-context pipeline below (its tail beside the next pre-aggregation; PCS_NODE_ONE_CALL=0 keeps it).
-    const char* env_one = getenv("PCS_NODE_ONE_CALL");          // (read at every submit: the tests run both ways in one process)
-    if (P == 1 && !(env_one && env_one[0] == '0')) {
+    if (one_call) {
         Peer& p = n->peers[0];
         HIPCHK(n, hipSetDevice(p.dev));
         hipStream_t ks = kstream(p);
@@ -979,6 +995,14 @@ int pcs_node_wait_voxel(pcs_node* n, int ticket, int* n_voxels)
 
 int pcs_node_voxel_reruns(const pcs_node* n) { return n ? n->voxel_reruns : 0; }
 
+int pcs_node_set_one_call(pcs_node* n, int enable)
+{
+    if (!n) return PCS_ERR_INVALID_ARG;
+    if (n->inflight[0].busy || n->inflight[1].busy) return nfail(n, PCS_ERR_INVALID_ARG, "wait for the frame-sets in flight first");
+    n->one_call = enable != 0;
+    return PCS_OK;
+}
+
 int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int route, int16_t* d_voxels, size_t voxels_shorts, int* n_voxels, pcs_node_voxel_stats* stats)
 {
@@ -1008,7 +1032,7 @@ int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, c
         st = n->last;
     } else {
         // the reference's shape: camera-order concatenation of the (compacted) payloads on the root, downsample there
-        rc = ensure_voxel_buffers(n);
+        rc = ensure_voxel_counts(n);
         if (rc != PCS_OK) return rc;
         Peer& root = n->peers[0];
         const size_t max_sh = pcs_node_max_payload_shorts(n);

@@ -1676,7 +1676,10 @@ struct Workspace {
     size_t bytes;
 };
 
-inline Workspace carve(uint8_t* base, size_t n)
+// level: what the call's tail needs. 0 = LSD sort + segmented mean (~56 B per point); 1 = + the bucket tail's cold chain (chunk
+// table, scattered partials, parked records: ~98 B); 2 = + the regions a warm bucket call's pre-aggregation fills (~219 B). The
+// arrays of a higher level lie BEHIND those of the lower ones, so a workspace sized for a level holds every lower one unchanged.
+inline Workspace carve(uint8_t* base, size_t n, int level = 2)
 {
     Workspace w{};
     uint8_t* p = base;
@@ -1703,12 +1706,14 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.super = (unsigned int*)take(((((n + kSegThreads - 1) / kSegThreads) >> kSuperShift) + 2) * (size_t)kSuperStride * 4);
     w.lead = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
     w.trail = (BlockPiece*)take(((n + kSegThreads - 1) / kSegThreads) * sizeof(BlockPiece));
+    const size_t bytes0 = (size_t)(p - base);
     w.btable = (unsigned int*)take(((n + kBktChunk - 1) / kBktChunk + 1) * (size_t)kBkt * 4);
     w.part_s = (VoxelPartial*)take(n * sizeof(VoxelPartial));
     w.tmp_rec = (int16_t*)take(n * (size_t)PCS_POINT_BYTES + 16);      // records of buckets that take several passes
     // any cloud's regions fit: B x (2 (m / B) + 64) slots with m <= n partials in B <= kBkt buckets; behind them (region_tail) a
     // stretch of n slots: a warm call's scratch for the ranges of split buckets (the cold chain's is keys_a / part, where a warm
     // call keeps the partials that found their region full)
+    const size_t bytes1 = (size_t)(p - base);
     w.region_slots = 2 * n + 64 * (size_t)kBkt + 64;
     w.region_tail = w.region_slots;
     w.keys_r = (unsigned long long*)take((w.region_slots + n) * 8);
@@ -1716,14 +1721,14 @@ inline Workspace carve(uint8_t* base, size_t n)
     w.part_ws = w.part;
     w.keys_s = w.keys_b;
     w.bucket_of = (unsigned short*)w.idx_a;
-    w.bytes = (size_t)(p - base);
+    w.bytes = level >= 2 ? (size_t)(p - base) : level == 1 ? bytes1 : bytes0;
     return w;
 }
 
 }  // namespace
 
 // worst case: every point its own partial
-size_t voxel_workspace_bytes(uint32_t n_points) { return carve(nullptr, n_points).bytes + 256; }
+size_t voxel_workspace_bytes(uint32_t n_points, int level) { return carve(nullptr, n_points, level).bytes + 256; }
 
 namespace {
 
@@ -1759,6 +1764,12 @@ bool choose_bucket_tail(int leaf_mm, int pref, bool stalled)
     return leaf_mm >= 34;
 }
 
+// (a bucket publishes its voxel count in 26 bits beside a 6-bit tag: clouds of 2^26 points and more take the LSD tail)
+bool takes_bucket_tail(uint32_t n_points, int leaf_mm, const VoxelWsState& ws)
+{
+    return choose_bucket_tail(leaf_mm, ws.tail_pref, ws.stalled) && n_points < (1u << 26);
+}
+
 // The constants of floor(v / leaf) + bias for one leaf (pcs_voxel_agg.h: VoxelDiv) + the bits one axis takes.
 hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
 {
@@ -1788,9 +1799,10 @@ hipError_t div_for(int leaf_mm, VoxelDiv& dv, unsigned int& bits)
 // clears the other one for call k + 1 (nothing of call k touches that block; call k - 1, which used it, is behind on the
 // stream). `ws` remembers the parity; a workspace it has not seen, or one whose last call may not have been enqueued
 // completely (ws.clean == false), gets both blocks cleared by a memset first.
-hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState& ws, Plan& pl, hipStream_t st)
+hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes, VoxelWsState& ws, Plan& pl, hipStream_t st,
+                    bool from_partials = false)
 {
-    if (ws_bytes < voxel_workspace_bytes(n_points)) return hipErrorInvalidValue;
+    if (ws_bytes < voxel_workspace_bytes(n_points, voxel_workspace_level(n_points, leaf_mm, ws, from_partials))) return hipErrorInvalidValue;
     uint8_t* base = static_cast<uint8_t*>(d_ws);
     base += (256 - ((uintptr_t)base & 255)) & 255;
     pl.w = carve(base, n_points);
@@ -1825,8 +1837,7 @@ hipError_t plan_for(uint32_t n_points, int leaf_mm, void* d_ws, size_t ws_bytes,
     static const int track_env = [] { const char* v = getenv("PCS_VOXEL_TRACK"); return v ? atoi(v) : -1; }();
     pl.track_bits = 3u * pl.bits > 3u * kRadixBits;
     if (track_env >= 0) pl.track_bits = track_env != 0;
-    // (a bucket publishes its voxel count in 26 bits beside a 6-bit tag: clouds of 2^26 points and more take the LSD tail)
-    pl.bucket = choose_bucket_tail(leaf_mm, ws.tail_pref, ws.stalled) && n_points < (1u << 26);
+    pl.bucket = takes_bucket_tail(n_points, leaf_mm, ws);
     if (pl.bucket) {
         pl.idx_bits = 0;              // raw keys, as in the exchange format: the bucket tail moves the partials themselves
         pl.track_bits = false;
@@ -1944,6 +1955,14 @@ hipError_t finish_call(VoxelWsState& ws, hipError_t e, int bucket_leaf = 0)
 
 }  // namespace
 
+// What a call on `ws` for this leaf needs of the workspace (carve): the owner sizes it with voxel_workspace_bytes(n, level).
+// Caller-held partials (from_partials) never fill regions.
+int voxel_workspace_level(uint32_t n_points, int leaf_mm, const VoxelWsState& ws, bool from_partials)
+{
+    if (!takes_bucket_tail(n_points, leaf_mm, ws)) return 0;
+    return from_partials ? 1 : 2;
+}
+
 void inject_voxel_stall(int launches) { g_stall_left.store(launches < 0 ? 0 : launches); }
 
 // d_n_points != nullptr: the number of points is read from device memory (<= n_points, which then is the capacity that
@@ -2043,7 +2062,7 @@ hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const vo
         return hipSuccess;
     }
     Plan pl;
-    hipError_t e = plan_for(n_partials, leaf_mm, d_ws, ws_bytes, *ws, pl, st);
+    hipError_t e = plan_for(n_partials, leaf_mm, d_ws, ws_bytes, *ws, pl, st, true);
     if (e != hipSuccess) return e;
     pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
     pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place

@@ -86,13 +86,23 @@ class PcsBuildError(RuntimeError):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libpcs_hip.so and libpcs_node.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
     Always defers to make — a no-op when both libraries are newer than every source, header and the Makefile — so a
-    library left over from before a source change cannot be loaded; a lock keeps concurrent processes from building at once."""
+    library left over from before a source change cannot be loaded; a lock keeps concurrent processes from building at once.
+    An install that cannot run make at all (read-only tree: no lock file; a box without make) loads the library it ships, with
+    a warning that it could not be checked against the sources; with no library there either the error is PcsBuildError."""
     import fcntl
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
-        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    import warnings
+    try:
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            cmd = ["make", "-C", CSRC_DIR] + (["-B"] if force else [])
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    except OSError as e:          # PermissionError (read-only install), FileNotFoundError (no make)
+        if os.path.exists(LIB_PATH) and not force:
+            warnings.warn(f"pointcloud_stitching_amd: cannot run make here ({e}); loading {LIB_PATH} as shipped, unchecked against "
+                          "the sources", RuntimeWarning)
+            return LIB_PATH
+        raise PcsBuildError(f"cannot build libpcs_hip.so: {e} — the HIP extension is required, there is no fallback") from e
     if verbose:
         print(proc.stdout)
     if proc.returncode != 0 or not os.path.exists(LIB_PATH):

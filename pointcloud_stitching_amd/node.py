@@ -69,6 +69,7 @@ SYMBOLS = [
     ("pcs_node_submit_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_node_wait_voxel", C.c_int, [_VP, C.c_int, _P(C.c_int)]),
     ("pcs_node_voxel_reruns", C.c_int, [_VP]),
+    ("pcs_node_set_one_call", C.c_int, [_VP, C.c_int]),
     ("pcs_node_process_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int), _P(VoxelStats)]),
     ("pcs_node_process_voxel", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(VoxelStats)]),
 ]
@@ -229,6 +230,11 @@ class PcsNode:
         nv = C.c_int(0)
         self._check(self._lib.pcs_node_wait_voxel(self._h, int(ticket), C.byref(nv)))
         return nv.value
+
+    def set_one_call(self, enable: bool) -> None:
+        """A one-peer node: rasters -> voxels enqueued at submit (True, the default) or the partials pipeline of a node of several
+        peers (False). pcs_node_set_one_call; nothing may be in flight."""
+        self._check(self._lib.pcs_node_set_one_call(self._h, 1 if enable else 0))
 
     def voxel_reruns(self) -> int:
         """Voxel frame-sets this node ran again on the LSD tail after a flagged bucket tail (pcs_node_voxel_reruns)."""

@@ -92,7 +92,9 @@ def transform_payload_np(payload, m16, downsample=1):
     """The centre's decode / affine / re-encode (src/pcs-multicamera-optimized.cpp:226-265, 289) in numpy float32: division by
     1000.0f, ((m0*x + m1*y) + m2*z) + m3 with every product and sum rounded to float32, * 1000.0f, truncation, low 16 bits."""
     f32 = np.float32
-    p = np.asarray(payload, np.int16).reshape(-1, 5)[::max(int(downsample), 1)]
+    d = max(int(downsample), 1)
+    p = np.asarray(payload, np.int16).reshape(-1, 5)
+    p = p[::d][:p.shape[0] // d]          # the cloud's width is size / downsample, rounded down (:230)
     M = np.asarray(m16, f32).reshape(-1)
     out = np.empty_like(p)
     with np.errstate(all="ignore"):

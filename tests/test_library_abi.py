@@ -101,3 +101,34 @@ def test_node_library_exports_its_header():
     nm = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
     exported = set(re.findall(r" T (pcs_node_[a-z0-9_]+)", nm))
     assert set(declared) == exported and len(declared) >= 6
+
+
+def test_build_falls_back_to_the_shipped_library_when_make_cannot_run(monkeypatch):
+    """A read-only install (no lock file can be opened) or a box without make: the shipped library is loaded with a warning; with
+    no library either, the error is PcsBuildError — not a bare OSError."""
+    import builtins
+    import subprocess
+    from pointcloud_stitching_amd import lib as L
+    L.build()                                                        # make sure the library exists
+
+    def no_make(*a, **k):
+        raise FileNotFoundError(2, "No such file or directory: 'make'")
+    monkeypatch.setattr(subprocess, "run", no_make)
+    with pytest.warns(RuntimeWarning, match="as shipped"):
+        assert L.build() == L.LIB_PATH
+    with pytest.raises(L.PcsBuildError):                             # a forced rebuild cannot be satisfied by what is there
+        L.build(force=True)
+    monkeypatch.undo()
+
+    real_open = builtins.open
+
+    def read_only(path, mode="r", *a, **k):
+        if str(path).endswith(".build.lock"):
+            raise PermissionError(13, "Read-only file system")
+        return real_open(path, mode, *a, **k)
+    monkeypatch.setattr(builtins, "open", read_only)
+    with pytest.warns(RuntimeWarning, match="as shipped"):
+        assert L.build() == L.LIB_PATH
+    monkeypatch.setattr(L, "LIB_PATH", L.LIB_PATH + ".absent")
+    with pytest.raises(L.PcsBuildError):
+        L.build()

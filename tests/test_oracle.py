@@ -201,6 +201,7 @@ def test_centre_transform_restatement_agrees_with_numpy(oracle):
             got = oracle.transform_payload(p, m, d)
             want = transform_payload_np(p, m, d)
             assert got.shape == want.shape and (got == want).all()
+            assert got.shape[0] == p.shape[0] // d and p.shape[0] % 3 != 0        # floor: the decoded cloud's width (:230)
     # the round trip through the identity is NOT lossless: x/1000*1000 truncates below some integers (the reference's known loss)
     back = oracle.transform_payload(p, ident, 1)
     assert (back[:, 3] == p[:, 3]).all() and (back[:, 4] == (p[:, 4] & 0xFF)).all()
