@@ -582,6 +582,7 @@ struct VertexSource {
 // 16-byte aligned. Interior goes out as lane-contiguous 16-byte stores; the ragged ends (which may
 // share a 16-byte line with a neighbouring tile's bytes) go out as 2-byte stores.
 // ------------------------------------------------------------------------------------------------
+template <uint32_t THREADS = kBlockThreads>
 __device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, uint32_t nbytes, uint8_t* g)
 {
     uint8_t* g0 = g - head;                                  // 16-byte aligned
@@ -591,15 +592,15 @@ __device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, 
     // nontemporal: the payload is written once and never re-read by this kernel; keeping it out of the
     // caches' way measured +7 % on the store-dominated stream (tools/lab/kernel_lab.hip, skeleton nt-store)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (uint32_t j = first_full + threadIdx.x; j < last_full; j += kBlockThreads)
+    for (uint32_t j = first_full + threadIdx.x; j < last_full; j += THREADS)
         __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(lds)[j], reinterpret_cast<u32x4*>(g0) + j);
     // ragged head: shorts in [head, min(first_full*16, end)); ragged tail: [max(last_full*16, head), end)
     const uint32_t head_end = min(first_full << 4, end);
-    for (uint32_t b = head + 2u * threadIdx.x; b < head_end; b += 2u * kBlockThreads)
+    for (uint32_t b = head + 2u * threadIdx.x; b < head_end; b += 2u * THREADS)
         *reinterpret_cast<uint16_t*>(g0 + b) = *reinterpret_cast<const uint16_t*>(lds + b);
     if (last_full >= first_full) {
         const uint32_t tail_begin = max(last_full << 4, head_end);
-        for (uint32_t b = tail_begin + 2u * threadIdx.x; b < end; b += 2u * kBlockThreads)
+        for (uint32_t b = tail_begin + 2u * threadIdx.x; b < end; b += 2u * THREADS)
             *reinterpret_cast<uint16_t*>(g0 + b) = *reinterpret_cast<const uint16_t*>(lds + b);
     }
 }
@@ -610,7 +611,9 @@ __device__ __forceinline__ void store_staged(const uint8_t* lds, uint32_t head, 
 // Lane l of the workgroup produces 8 records = 5 x uint4 and parks them at LDS[l*80]; the workgroup
 // then streams the tile's 20 480 bytes out with lane-contiguous 16-byte stores.
 // ------------------------------------------------------------------------------------------------
-template <class Src>
+// THREADS: lanes per workgroup = 8-point runs per tile (kBlockThreads: 2048-point tiles; 64: one wavefront per 512-point tile, what
+// a launch that cannot fill the chip with 256-lane workgroups takes — launch_fused_dense).
+template <class Src, uint32_t THREADS = kBlockThreads>
 __device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src, const uint8_t* __restrict__ color,
                                            uint32_t tile0, uint32_t n, uint8_t* __restrict__ out_bytes,
                                            uint4* stage)
@@ -650,9 +653,9 @@ __device__ __forceinline__ void dense_tile(const StreamParams& P, const Src& src
     for (int k = 0; k < 5; k++) mine[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     __syncthreads();
 
-    const uint32_t pts = min(kTilePoints, n - tile0);
-    store_staged(reinterpret_cast<const uint8_t*>(stage), 0u, pts * PCS_POINT_BYTES,
-                 out_bytes + (size_t)tile0 * PCS_POINT_BYTES);
+    const uint32_t pts = min(THREADS * kPointsPerLane, n - tile0);
+    store_staged<THREADS>(reinterpret_cast<const uint8_t*>(stage), 0u, pts * PCS_POINT_BYTES,
+                          out_bytes + (size_t)tile0 * PCS_POINT_BYTES);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -954,20 +957,20 @@ __device__ __forceinline__ void request_constants(const StreamParams& P, const v
 // ------------------------------------------------------------------------------------------------
 #if !PCS_TU_VOXEL
 
-template <bool DDIST, bool CDIST, class Mth>
-__global__ __launch_bounds__(kBlockThreads, 7)     // <= 72 VGPRs for every instantiation (one landed on 73 -> 6 waves/SIMD); A/B on one box: no measurable change, 8 spills and is slower
+template <bool DDIST, bool CDIST, class Mth, uint32_t THREADS = kBlockThreads>
+__global__ __launch_bounds__(THREADS, 7)     // <= 72 VGPRs for every instantiation (one landed on 73 -> 6 waves/SIMD); A/B on one box: no measurable change, 8 spills and is slower
 void pcs_fused_dense_kernel(const StreamParams* __restrict__ params, int stream0, FramePtrs fp,
                             uint8_t* __restrict__ payload_bytes)
 {
-    __shared__ uint4 stage[kDenseStageBytes / 16];
+    __shared__ uint4 stage[THREADS * kPointsPerLane * PCS_POINT_BYTES / 16];
     const int s = blockIdx.y;
     const StreamParams& P = params[stream0 + s];
     request_constants(P, fp.depth[s], fp.color[s], payload_bytes);
     const uint32_t n = P.n_points;
-    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    const uint32_t tile0 = blockIdx.x * (THREADS * kPointsPerLane);
     if (tile0 >= n) return;
     DepthSource<DDIST, CDIST, Mth> src{fp.depth[s]};
-    dense_tile(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage);
+    dense_tile<DepthSource<DDIST, CDIST, Mth>, THREADS>(P, src, fp.color[s], tile0, n, payload_bytes + (size_t)P.out_base * PCS_POINT_BYTES, stage);
 }
 
 // K frame-sets of the same streams in one launch: blockIdx.z = frame-set, blockIdx.y = stream. Same tile code, same
@@ -1817,17 +1820,18 @@ void pcs_payload_voxel_partials_kernel(const int16_t* __restrict__ payload, uint
 
 #if !PCS_TU_VOXEL
 // ---- a2 twin -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads)
+template <uint32_t THREADS = kBlockThreads>
+__global__ __launch_bounds__(THREADS)
 void pcs_pack_dense_kernel(const StreamParams* __restrict__ params, int stream, VertexPtrs vp,
                                   uint8_t* __restrict__ out_bytes)
 {
-    __shared__ uint4 stage[kDenseStageBytes / 16];
+    __shared__ uint4 stage[THREADS * kPointsPerLane * PCS_POINT_BYTES / 16];
     const StreamParams& P = params[stream];
     const uint32_t n = vp.n_points;
-    const uint32_t tile0 = blockIdx.x * kTilePoints;
+    const uint32_t tile0 = blockIdx.x * (THREADS * kPointsPerLane);
     if (tile0 >= n) return;
     VertexSource src{vp.vertices, vp.texcoords};
-    dense_tile(P, src, vp.color, tile0, n, out_bytes, stage);
+    dense_tile<VertexSource, THREADS>(P, src, vp.color, tile0, n, out_bytes, stage);
 }
 
 __global__ __launch_bounds__(kBlockThreads)
@@ -2095,6 +2099,18 @@ void pcs_verify_div_const_kernel(float c, float rc, int32_t dim, unsigned long l
 
 #endif  // !PCS_TU_VOXEL
 
+// small-launch shape of the dense kernels (dense_tile<Src, 64>)
+constexpr uint32_t kSmallThreads = 64, kSmallTilePoints = kSmallThreads * kPointsPerLane;
+constexpr uint32_t kResidentWorkgroups = 7u * 256u;        // 256-lane workgroups the chip holds at the dense kernels' 7 waves / SIMD
+inline bool small_launch(uint32_t max_points, int n_launch)
+{
+    if (const char* v = getenv("PCS_SMALL_TILES")) {      // A/B (read at every call: bench.py times both in one process): 0 never, 1 always
+        if (v[0] == '0') return false;
+        if (v[0] == '1') return true;
+    }
+    return (uint64_t)((max_points + kTilePoints - 1) / kTilePoints) * (uint64_t)n_launch < kResidentWorkgroups;
+}
+
 inline dim3 tile_grid(uint32_t max_points, int n_launch)
 {
     return dim3((max_points + kTilePoints - 1) / kTilePoints, (unsigned)n_launch, 1);
@@ -2112,9 +2128,15 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
                               hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
-    const dim3 grid = tile_grid(max_points, n_launch);
-#define L(DD, CD, M) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD, M>), grid, dim3(kBlockThreads), 0, st, \
-                                        d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload))
+    // A launch whose 2048-point tiles cannot fill the chip's workgroup slots (one 1280 x 720 stream: 450 of 1 792) runs one wavefront
+    // per 512-point tile instead: same bytes, four times the workgroups to spread over the CUs (BASELINE configs[1], the shape the
+    // reference deploys: one camera per process)
+    const bool small = small_launch(max_points, n_launch);
+    const dim3 grid = small ? dim3((max_points + kSmallTilePoints - 1) / kSmallTilePoints, (unsigned)n_launch, 1) : tile_grid(max_points, n_launch);
+#define L(DD, CD, M) do { if (small) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD, M, kSmallThreads>), grid, dim3(kSmallThreads), 0, st, \
+                                        d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload)); \
+                          else hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD, M>), grid, dim3(kBlockThreads), 0, st, \
+                                        d_params, stream0, fp, reinterpret_cast<uint8_t*>(d_payload)); } while (0)
     if (math != MathSel::Ieee && !any_ddist) {
         const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
         const bool noovf = (math == MathSel::CertNoOvf || math == MathSel::CertIdentRNoOvf) && !any_cdist;
@@ -2349,8 +2371,12 @@ hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const Ver
                              int16_t* d_out, hipStream_t st)
 {
     if (vp.n_points == 0) return hipSuccess;
-    hipLaunchKernelGGL(pcs_pack_dense_kernel, tile_grid(vp.n_points, 1), dim3(kBlockThreads), 0, st,
-                       d_params, stream, vp, reinterpret_cast<uint8_t*>(d_out));
+    if (small_launch(vp.n_points, 1))       // one cloud per call is what INTEGRATION.md section 2's minimal patch makes: 450 workgroups of 1 792
+        hipLaunchKernelGGL((pcs_pack_dense_kernel<kSmallThreads>), dim3((vp.n_points + kSmallTilePoints - 1) / kSmallTilePoints),
+                           dim3(kSmallThreads), 0, st, d_params, stream, vp, reinterpret_cast<uint8_t*>(d_out));
+    else
+        hipLaunchKernelGGL((pcs_pack_dense_kernel<kBlockThreads>), tile_grid(vp.n_points, 1), dim3(kBlockThreads), 0, st,
+                           d_params, stream, vp, reinterpret_cast<uint8_t*>(d_out));
     return hipGetLastError();
 }
 

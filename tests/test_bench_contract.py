@@ -62,6 +62,20 @@ def test_bench_line_has_the_contract_keys():
     assert d["pack_twin"]["per_stream_launches_frac"] > 0.4          # round 3: the arrays are read straight into registers
     c1080 = d["color_1080p"]                                          # the real-camera geometry (depth 720p, colour 1080p, distortion)
     assert 0.2 < c1080["frac"] < d["general_rotation"]["frac"] and "1920x1080" in c1080["workload"]
+    # two clocks on one region, both on the line: the event bracket (frac) and the wall clock value is computed from (frac_wall)
+    assert abs(rf["frac_wall"] - rf["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / rf["peak"]) < 2e-3 and "clocks" in rf
+    assert "unpinned" in d["parity"]
+    # BASELINE configs[1]: ONE 720p stream, device-resident, cold ring, oracle-checked, with its own roofline
+    ss = d["single_stream"]
+    assert "configs[1]" in ss["workload"] and ss["ring_cold"] is True and ss["check"]["oracle_compared"]["slots"] == [0, 1]
+    assert ss["roofline"]["kernel"] == "pcs_fused_dense_kernel" and ss["roofline"]["algorithmic_bytes_per_launch"] == 15 * 1280 * 720
+    assert abs(ss["roofline"]["frac"] - ss["roofline"]["achieved"] / 8000.0) < 1e-3 and ss["roofline"]["frac"] > 0.2
+    assert ss["tile_2048_points_ms"] > 0 and ss["tile_512_points_ms"] > 0
+    assert d["pack_twin"]["single"]["roofline"]["algorithmic_bytes_per_launch"] == 33 * 1280 * 720 and d["pack_twin"]["single"]["roofline"]["frac"] > 0.2
+    # the drop-in where the reference lives: one camera, host pointers, beside the CPU port for ONE frame
+    hs = d["host_api_single"]
+    assert hs["a2_twin_ms_per_frame"]["pageable"] > 0 and hs["fused_ms_per_frame"]["pipelined_submit_collect"] > 0
+    assert hs["cpu_port_ms_per_frame"]["t1"] > hs["cpu_port_ms_per_frame"]["best"] > 0 and hs["a2_twin_vs_cpu_best"] > 0
     assert "leg_errors" not in d, d.get("leg_errors")
 
 
@@ -195,6 +209,37 @@ def test_bench_leg_guard_records_and_swallows_exceptions():
     with pytest.raises(KeyboardInterrupt):          # not an Exception: must propagate
         with b.Leg(out, "interrupted"):
             raise KeyboardInterrupt
+
+
+def test_a_swallowed_leg_is_named_on_the_line():
+    """Every leg of the line is a function (benchlegs/legs_*.py) run through run_leg: what it returns lands under its name, a leg
+    that does not apply (returns None) leaves nothing, and a leg that raises is NAMED under leg_errors — silently missing is not an
+    outcome. The legs bench.py wires are importable without a GPU, and each is a plain function of the rig."""
+    b = _load_bench_module()
+    out = {"roofline": {}}
+
+    def good(x, y=1):
+        return {"sum": x + y}
+
+    def broken():
+        raise ValueError("no such ring slot")
+    assert b.run_leg(out, "good", good, 2, y=3) == {"sum": 5} and out["good"] == {"sum": 5}
+    assert b.run_leg(out, "not_applicable", lambda: None) is None and "not_applicable" not in out
+    assert b.run_leg(out, "broken", broken) is None and "broken" not in out
+    assert out["leg_errors"] == {"broken": "ValueError: no such ring slot"}
+    b.run_leg(out, "per_launch_ms", lambda: {"n": 3}, into=out["roofline"])          # a leg may report into another leg's object
+    assert out["roofline"]["per_launch_ms"] == {"n": 3} and "per_launch_ms" not in out
+    import inspect
+    from benchlegs import legs_dense, legs_config5, legs_host, legs_single
+    src = open(BENCH).read()
+    for mod, names in ((legs_dense, ("compaction", "batched_dense", "pack_twin", "centre_transform", "infinity_cache_resident_inputs",
+                                     "two_stream_overlap", "general_rotation", "color_1080p", "per_launch_ms")),
+                       (legs_config5, ("config5_one_gpu",)), (legs_host, ("host_api", "host_api_single")), (legs_single, ("single_stream",))):
+        for n in names:
+            fn = getattr(mod, n)
+            assert inspect.isfunction(fn) and list(inspect.signature(fn).parameters)[0] == "g"
+            assert f'run_leg(out, "{n}"' in src, n            # wired under its own name: that is the name leg_errors would show
+    assert "with Leg(" not in src                            # no leg body lives in bench.py any more
 
 
 def test_cpu_sample_reports_physical_cores():
