@@ -146,7 +146,7 @@ def pack_twin(g):
                         "note": "copyPointCloudXYZRGBToBufferSIMD's twin on device-resident rs2::points arrays "
                                 "(12 B vertex + 8 B texcoord + 3 B RGB in, 10 B out): pcs_copy_pointclouds_xyzrgb_to_buffer_device "
                                 "(one launch for all cameras) vs pcs_copy_pointcloud_xyzrgb_to_buffer_device per camera"}    # one cloud per call, back to back over the ring's slots and cameras (each call reads arrays nobody touched for >= 2 x the
-    # Infinity Cache): the launch INTEGRATION's per-camera patch makes — 450 workgroups at 2048-point tiles, 1 800 at 512
+    # Infinity Cache): the launch INTEGRATION's per-camera patch makes — 450 workgroups of 2048 points
     pr = g.build_pack_ring()
     k1 = [0]
 
@@ -166,7 +166,7 @@ def pack_twin(g):
                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "pcs_pack_dense_kernel",
                                   "avg_launch_ms": round(ms_1, 5), "algorithmic_bytes_per_launch": npts * PACK_BYTES_PER_POINT,
                                   "timing": "hipEvent pair around back-to-back single-cloud calls over the cold ring / calls"},
-                     "tile": os.environ.get("PCS_SMALL_TILES", "auto (512-point tiles: the launch cannot fill the chip with 2048-point ones)"),
+                     "tile": "512 points (PCS_SMALL_TILES=1)" if os.environ.get("PCS_SMALL_TILES") == "1" else "2048 points (default)",
                      "note": "pcs_copy_pointcloud_xyzrgb_to_buffer_device for ONE 1280x720 cloud: the reference's call shape "
                              "(src/pcs-camera-optimized.cpp:363, once per frame per camera process)"}
     return res

@@ -11,8 +11,8 @@ def single_stream(g):
     """One camera per launch — the reference's real deployment (one camera per process, src/pcs-camera-optimized.cpp:286-293, 363).
     Device-resident rasters in a ring of its own whose inputs are > 2 x the Infinity Cache apart (4.6 MB per frame: ~120 slots),
     slots 0 and 1 compared with the oracle before anything is timed, then back-to-back launches under one hipEvent pair. The launch
-    is 450 workgroups at 2048-point tiles on a chip that holds 1 792: the library takes 512-point tiles (one wavefront each) for
-    it; both shapes are timed (PCS_SMALL_TILES is read at every call)."""
+    is 450 workgroups at 2048-point tiles on a chip that holds 1 792; the 512-point shape (one wavefront per tile, PCS_SMALL_TILES=1,
+    read at every call) is timed beside the default — it measured no faster, so the default stays 2048."""
     from oracle import pcs_oracle as O          # the checker
     torch, dev, Syn, W, H, npts, lib = g.torch, g.dev, g.Syn, g.W, g.H, g.npts, g.lib
     cfg1 = [Syn.synth_stream_config(W, H, 0, single=True)]
@@ -68,7 +68,7 @@ def single_stream(g):
                     os.environ["PCS_SMALL_TILES"] = prev
         ms_2048, _ = measure(False)
         ms_512, _ = measure(True)
-        ms, n = measure(None)                   # the library's own choice: what a caller gets
+        ms, n = measure(None)                   # the library's default: what a caller gets
         algo = npts * ALGO_BYTES_PER_POINT
         gbs = algo / (ms * 1e-3) / 1e9
         return {"workload": f"ONE synthetic {W}x{H} Z16+RGB8 stream on one GPU (BASELINE.json configs[1]), device-resident, fused kernel",

@@ -2099,16 +2099,17 @@ void pcs_verify_div_const_kernel(float c, float rc, int32_t dim, unsigned long l
 
 #endif  // !PCS_TU_VOXEL
 
-// small-launch shape of the dense kernels (dense_tile<Src, 64>)
+// The small-launch shape of the dense kernels (dense_tile<Src, 64>: one wavefront per 512-point tile) — an A/B knob, NOT taken by
+// default. One 1280 x 720 stream is 450 workgroups of 2048 points on a chip that holds 1 792; four times as many one-wavefront
+// workgroups were measured on it (round 6, rocprofv3 average over 3 000 cold launches): fused 6.95 -> 7.44 us, two streams 8.54 ->
+// 8.30 us, the a2 twin 7.28 -> 7.77 us; hipEvent period of back-to-back launches 6.09 -> 6.22 us. The lone launch is a chain of
+// dependent round trips (constants, Z16 + LUT, the colour gather, the store drain: ~5 us before the first stream's bytes count,
+// ~2.3 us per further stream), which the tile size does not shorten. PCS_SMALL_TILES=1 forces it (the parity suite runs under it).
 constexpr uint32_t kSmallThreads = 64, kSmallTilePoints = kSmallThreads * kPointsPerLane;
-constexpr uint32_t kResidentWorkgroups = 7u * 256u;        // 256-lane workgroups the chip holds at the dense kernels' 7 waves / SIMD
-inline bool small_launch(uint32_t max_points, int n_launch)
+inline bool small_launch(uint32_t, int)
 {
-    if (const char* v = getenv("PCS_SMALL_TILES")) {      // A/B (read at every call: bench.py times both in one process): 0 never, 1 always
-        if (v[0] == '0') return false;
-        if (v[0] == '1') return true;
-    }
-    return (uint64_t)((max_points + kTilePoints - 1) / kTilePoints) * (uint64_t)n_launch < kResidentWorkgroups;
+    const char* v = getenv("PCS_SMALL_TILES");      // (read at every call: bench.py times both shapes in one process)
+    return v && v[0] == '1';
 }
 
 inline dim3 tile_grid(uint32_t max_points, int n_launch)
@@ -2128,9 +2129,7 @@ hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_l
                               hipStream_t st)
 {
     if (n_launch <= 0 || max_points == 0) return hipSuccess;
-    // A launch whose 2048-point tiles cannot fill the chip's workgroup slots (one 1280 x 720 stream: 450 of 1 792) runs one wavefront
-    // per 512-point tile instead: same bytes, four times the workgroups to spread over the CUs (BASELINE configs[1], the shape the
-    // reference deploys: one camera per process)
+    // (PCS_SMALL_TILES=1: one wavefront per 512-point tile — measured no faster on the launches it was meant for, see small_launch)
     const bool small = small_launch(max_points, n_launch);
     const dim3 grid = small ? dim3((max_points + kSmallTilePoints - 1) / kSmallTilePoints, (unsigned)n_launch, 1) : tile_grid(max_points, n_launch);
 #define L(DD, CD, M) do { if (small) hipLaunchKernelGGL((pcs_fused_dense_kernel<DD, CD, M, kSmallThreads>), grid, dim3(kSmallThreads), 0, st, \
@@ -2371,7 +2370,7 @@ hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const Ver
                              int16_t* d_out, hipStream_t st)
 {
     if (vp.n_points == 0) return hipSuccess;
-    if (small_launch(vp.n_points, 1))       // one cloud per call is what INTEGRATION.md section 2's minimal patch makes: 450 workgroups of 1 792
+    if (small_launch(vp.n_points, 1))       // (A/B knob only)
         hipLaunchKernelGGL((pcs_pack_dense_kernel<kSmallThreads>), dim3((vp.n_points + kSmallTilePoints - 1) / kSmallTilePoints),
                            dim3(kSmallThreads), 0, st, d_params, stream, vp, reinterpret_cast<uint8_t*>(d_out));
     else
