@@ -271,20 +271,26 @@ def run_node(args):
     if config5:
         out["partials_reduced_per_step"] = int(reduced)
         out["config"]["leaf_mm"] = LEAF
-        if P == 1 and os.environ.get("PCS_NODE_ONE_CALL", "1") != "0":
-            # one peer: submit enqueued the rasters -> voxels call (no partials leave the library). Beside it, the same loop with the
-            # partials pipeline a node of several peers runs (pre-aggregation of k+1 beside the root's sort + mean of k)
+        if P == 1 and os.environ.get("PCS_NODE_ONE_CALL", "2") == "2":
+            # one peer: submit enqueued the rasters -> voxels call (no partials leave the library), the two slots on two contexts in
+            # turn. Beside it, the same loop on ONE context (frame-sets queue behind each other) and with the partials pipeline a node
+            # of several peers runs (pre-aggregation of k+1 beside the root's sort + mean of k)
             node.set_timing(False)
-            node.set_one_call(False)
-            try:
-                run(max(args.warmup, 4)); sync_all()
-                t1 = time.perf_counter(); run(args.steps); sync_all()
-                out["one_peer"] = {"route": "pcs_process_frames_voxel_device enqueued at submit (warm bucket tail: 2 launches per frame-set)",
-                                   "partials_pipeline_ms_per_step": round((time.perf_counter() - t1) * 1e3 / args.steps, 5),
-                                   "note": "partials_pipeline = PCS_NODE_ONE_CALL=0: partials to caller-held arrays, sort + mean on a second "
-                                           "context beside the next frame-set's pre-aggregation (what a node of several peers runs on its root)"}
-            finally:
-                node.set_one_call(True)
+            other = {}
+            for mode, key in ((1, "one_context_ms_per_step"), (0, "partials_pipeline_ms_per_step")):
+                node.set_one_call(mode)
+                try:
+                    run(max(args.warmup, 4)); sync_all()
+                    t1 = time.perf_counter(); run(args.steps); sync_all()
+                    other[key] = round((time.perf_counter() - t1) * 1e3 / args.steps, 5)
+                finally:
+                    node.set_one_call(2)
+            out["one_peer"] = {"route": "pcs_process_frames_voxel_device enqueued at submit (warm bucket tail: 2 launches per frame-set), the two "
+                                        "slots on two contexts of the peer used in turn: the tail of k runs beside the pre-aggregation of k+1",
+                               **other,
+                               "note": "one_context = PCS_NODE_ONE_CALL=1 (round 5's route); partials_pipeline = PCS_NODE_ONE_CALL=0: partials to "
+                                       "caller-held arrays, sort + mean on a second context beside the next frame-set's pre-aggregation (what a "
+                                       "node of several peers runs on its root)"}
     else:
         out["per_stream_fps"] = round(args.steps / elapsed, 1)
         out["points_per_stream"] = counts

@@ -169,14 +169,17 @@ int  pcs_node_process_voxel_device(pcs_node* node, const uint16_t* const* d_dept
  * pcs_node_wait_voxel. Written as  submit(k+1); wait(k);  the pre-aggregation of k+1 overlaps the exchange and the root's
  * sort of k. The two frame-sets need different d_voxels_root buffers. pcs_node_process_voxel_device(PARTIALS) = submit + wait.
  * A node of ONE peer has nothing to exchange: submit enqueues pcs_process_frames_voxel_device (rasters -> voxel cloud, two launches
- * on a warm context) on the peer's stream and wait only waits; stats report partials = 0 (they never leave the library's
- * workspace), and such a node never allocates the partials pipeline's arrays, second context or stream. PCS_NODE_ONE_CALL=0 in
- * the environment WHEN THE NODE IS CREATED, or pcs_node_set_one_call(node, 0) with nothing in flight, keeps the partials pipeline
- * for such a node (A/B; tests). Its stats then read like a node of several peers (partials / reduced > 0, root_ms > 0).        */
+ * on a warm context) and wait only waits; stats report partials = 0 (they never leave the library's workspace), and such a node
+ * never allocates the partials pipeline's arrays. Its two slots run on TWO contexts of the peer used in turn — each with its own
+ * stream, workspace, splitters and regions (the splitters a frame-set partitions by are then two frame-sets old) — so that the bucket
+ * tail of frame-set k, a latency chain that leaves the chip almost empty, runs beside the pre-aggregation of k+1: 16 x 1080p at 50 mm
+ * 0.155 ms per frame-set instead of 0.174. pcs_node_set_one_call(node, mode) with nothing in flight, or PCS_NODE_ONE_CALL=<mode> in
+ * the environment WHEN THE NODE IS CREATED: 2 (default) as described, 1 one context (frame-sets queue behind each other), 0 the
+ * partials pipeline of a node of several peers (its stats then read like theirs: partials / reduced > 0, root_ms > 0). A/B; tests.  */
 int  pcs_node_submit_voxel_device(pcs_node* node, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int16_t* d_voxels_root, size_t voxels_shorts, int* ticket);
 int  pcs_node_wait_voxel(pcs_node* node, int ticket, int* n_voxels);
-int  pcs_node_set_one_call(pcs_node* node, int enable);
+int  pcs_node_set_one_call(pcs_node* node, int mode);
 /* A voxel frame-set whose bucket tail ended flagged (device count -1: include/pcs_hip.h, pcs_voxel_grid_device) is run again by
  * the wait that finds it, on the LSD tail, which is then latched for that context; *n_voxels is never negative, and PCS_ERR_HIP is
  * returned if the second run is flagged too. For that the rasters handed to pcs_node_submit_voxel_device stay the caller's to

@@ -1742,7 +1742,11 @@ try {
         return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every partial its own voxel) needs %zu",
                     out_shorts, (size_t)n_partials * PCS_POINT_SHORTS);
     DeviceGuard guard(c->device);
-    const size_t need = voxel_workspace_bytes((uint32_t)n_partials, voxel_workspace_level((uint32_t)n_partials, leaf_mm, c->vox_state, true));
+    // (a quarter more than this call's count + 64 Ki: the regions a warm call fills were sized by the PREVIOUS call's count, and a root's
+    // count moves from frame-set to frame-set — launch_voxel_from_partials carves the workspace for what it holds)
+    const uint32_t n_size = (uint32_t)std::min<uint64_t>((uint64_t)n_partials + (uint64_t)n_partials / 4u + 65536u,
+                                                         (uint32_t)n_partials < (1u << 26) ? (1u << 26) - 1u : 0xFFFFFFF0u);
+    const size_t need = voxel_workspace_bytes(n_size, voxel_workspace_level((uint32_t)n_partials, leaf_mm, c->vox_state, true));
     int rc = ensure_voxel_ws(c, need);
     if (rc) return rc;
     HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,

@@ -62,6 +62,7 @@ struct Ticket {
     int leaf = 0;
     int16_t* d_voxels = nullptr;
     size_t voxels_shorts = 0;
+    pcs_ctx* vox_ctx = nullptr;           // one-call voxel ticket: the context it was enqueued on
     std::vector<const uint16_t*> d_depth; // one-call voxel ticket: the rasters, should the call have to be run again (flagged bucket tail)
     std::vector<const uint8_t*> d_color;
     int64_t exchanged_bytes = 0;          // moved by the grouped RCCL exchange
@@ -98,7 +99,10 @@ struct pcs_node {
     void* d_vox_out = nullptr;
     void* d_vox_n[2] = {nullptr, nullptr};        // root: voxel count per slot
     bool voxel_ready = false, voxel_counts_ready = false;
-    bool one_call = true;                 // a one-peer node enqueues rasters -> voxels at submit (PCS_NODE_ONE_CALL, latched at create; pcs_node_set_one_call)
+    int one_call = 2;                     // a one-peer node enqueues rasters -> voxels at submit: 0 no (partials pipeline), 1 on the peer's context,
+                                          // 2 on two contexts used in turn (PCS_NODE_ONE_CALL, latched at create; pcs_node_set_one_call)
+    pcs_ctx* alt_ctx = nullptr;           // one-call tickets of slot 1: a second context of the peer (own stream, workspace, splitters, regions),
+    hipStream_t alt_stream = nullptr;     // so that the bucket tail of frame-set k runs beside the pre-aggregation of k+1
     size_t vcap_total = 0;
     // root: a second context of libpcs_hip (own stream, own sort workspace) that runs the sort + segmented mean of frame-set k
     // while the root's kernel stream pre-aggregates frame-set k+1: the tail is a dozen latency-bound launches that leave the GPU
@@ -234,6 +238,22 @@ int ensure_voxel_counts(pcs_node* n)
         if (!n->d_vox_n[sl]) PCSCHK(n, root.ctx, pcs_device_malloc(root.ctx, &n->d_vox_n[sl], 64));
     }
     n->voxel_counts_ready = true;
+    return PCS_OK;
+}
+
+// One-call tickets of slot 1 (one-peer node, mode 2): a second context of the peer on a stream that is seen to run beside its kernel stream.
+int ensure_alt_context(pcs_node* n)
+{
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
+    pcs_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.device = root.dev; cfg.n_streams = n->per_dev; cfg.streams = n->cfg.data(); cfg.flags = n->flags; cfg.downsample = n->downsample;
+    const int rc = pcs_create(&n->alt_ctx, &cfg);
+    if (rc != PCS_OK) return nfail(n, rc, "second context of the peer: %s", pcs_last_error(nullptr));
+    const int rc2 = pick_concurrent_stream(n, kstream(root), &n->alt_stream);
+    if (rc2 != PCS_OK) return rc2;
+    if (n->alt_stream) PCSCHK(n, n->alt_ctx, pcs_set_stream(n->alt_ctx, n->alt_stream));
     return PCS_OK;
 }
 
@@ -483,6 +503,8 @@ void pcs_node_destroy(pcs_node* n)
     }
     if (n->reduce_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); pcs_destroy(n->reduce_ctx);
                          if (n->reduce_stream) (void)hipStreamDestroy(n->reduce_stream); }
+    if (n->alt_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->alt_ctx); pcs_destroy(n->alt_ctx);
+                      if (n->alt_stream) (void)hipStreamDestroy(n->alt_stream); }
     for (Peer& p : n->peers) if (p.ctx) pcs_destroy(p.ctx);
     delete n;
 }
@@ -516,7 +538,7 @@ int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int
     pcs_node* n = new pcs_node;
     n->n_peers = n_devices; n->per_dev = streams_per_device; n->n_streams = n_devices * streams_per_device;
     n->flags = flags; n->downsample = downsample; n->node_flags = node_flags;
-    { const char* e = getenv("PCS_NODE_ONE_CALL"); n->one_call = !(e && e[0] == '0'); }      // latched here, not read in the frame loop
+    { const char* e = getenv("PCS_NODE_ONE_CALL"); n->one_call = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }      // latched here, not read in the frame loop
     n->cfg.assign(streams, streams + n->n_streams);
     n->pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
     n->peers.resize(n_devices);
@@ -907,9 +929,13 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     int rc = check_submit(n, tkp, slot);
     if (rc != PCS_OK) return rc;
     const int S = n->per_dev, P = n->n_peers;
-    const bool one_call = P == 1 && n->one_call;
+    const bool one_call = P == 1 && n->one_call != 0;
     rc = one_call ? ensure_voxel_counts(n) : ensure_voxel_buffers(n);
     if (rc != PCS_OK) return rc;
+    if (one_call && n->one_call == 2 && slot == 1 && !n->alt_ctx) {
+        rc = ensure_alt_context(n);
+        if (rc != PCS_OK) return rc;
+    }
     Ticket& tk = *tkp;
     const double t_host0 = now_ms();
     tk = Ticket{};
@@ -920,12 +946,18 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     // in flight then simply queue behind each other: 16 x 1080p at 50 mm 0.174 ms per frame-set, against 0.205 for the
     // partials / reduce-on-a-second-context pipeline below (its tail beside the next pre-aggregation; PCS_NODE_ONE_CALL=0 keeps it).
     if (one_call) {
+        // Two frame-sets in flight then run on two contexts in turn (slot 0: the peer's own, slot 1: alt_ctx), each with its own stream,
+        // workspace, splitters and regions: the bucket tail of frame-set k — a latency chain that leaves the chip almost empty — runs
+        // beside the pre-aggregation of k+1 (16 x 1080p, 50 mm: 0.155 ms per frame-set instead of 0.174 with one context; the
+        // partials / reduce-on-a-second-context pipeline below: 0.205; PCS_NODE_ONE_CALL=1 / 0 keep those).
         Peer& p = n->peers[0];
         HIPCHK(n, hipSetDevice(p.dev));
-        hipStream_t ks = kstream(p);
+        pcs_ctx* oc = (n->one_call == 2 && slot == 1 && n->alt_ctx) ? n->alt_ctx : p.ctx;
+        hipStream_t ks = static_cast<hipStream_t>(pcs_get_stream(oc));
+        tk.vox_ctx = oc;
         if (tk.timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
-        PCSCHK(n, p.ctx, pcs_process_frames_voxel_device(p.ctx, d_depth, d_color, leaf_mm, d_voxels, voxels_shorts,
-                                                         static_cast<int32_t*>(n->d_vox_n[slot])));
+        PCSCHK(n, oc, pcs_process_frames_voxel_device(oc, d_depth, d_color, leaf_mm, d_voxels, voxels_shorts,
+                                                      static_cast<int32_t*>(n->d_vox_n[slot])));
         HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, ks));
         if (tk.timing) { HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks)); HIPCHK(n, hipEventRecord(n->ev_r0[slot], ks)); }
         HIPCHK(n, hipEventRecord(p.packed[slot], ks));
@@ -973,7 +1005,7 @@ int pcs_node_wait_voxel(pcs_node* n, int ticket, int* n_voxels)
         // Once more on the LSD tail, which waits for nobody, latched for that context; what the tail read is still where it was
         // (the rasters of a one-call ticket are the caller's until this wait returns; the merged partials sit in this slot's
         // arrays until the slot's next submit). It queues behind whatever the next submit already enqueued on that stream.
-        pcs_ctx* vc = tk->one_call ? root.ctx : n->reduce_ctx;
+        pcs_ctx* vc = tk->one_call ? tk->vox_ctx : n->reduce_ctx;
         PCSCHK(n, vc, pcs_set_voxel_tail(vc, PCS_VOXEL_TAIL_LSD_LATCHED));
         n->voxel_reruns++;
         hipStream_t vs = static_cast<hipStream_t>(pcs_get_stream(vc));
@@ -995,11 +1027,12 @@ int pcs_node_wait_voxel(pcs_node* n, int ticket, int* n_voxels)
 
 int pcs_node_voxel_reruns(const pcs_node* n) { return n ? n->voxel_reruns : 0; }
 
-int pcs_node_set_one_call(pcs_node* n, int enable)
+int pcs_node_set_one_call(pcs_node* n, int mode)
 {
     if (!n) return PCS_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 2) return nfail(n, PCS_ERR_INVALID_ARG, "one-call mode %d outside 0..2", mode);
     if (n->inflight[0].busy || n->inflight[1].busy) return nfail(n, PCS_ERR_INVALID_ARG, "wait for the frame-sets in flight first");
-    n->one_call = enable != 0;
+    n->one_call = mode;
     return PCS_OK;
 }
 

@@ -1091,6 +1091,89 @@ void pcs_vox_bkt_scatter_kernel(const unsigned long long* __restrict__ keys, con
     }
 }
 
+// PLACE: the warm form of P1 - P3 for CALLER-HELD partials (the root of a multi-GPU voxel grid: pcs_voxel_grid_from_partials_device on
+// a workspace whose previous call left splitters, region sizes and zeroed cursors): every (key, partial) of the list straight into its
+// bucket's region, exactly what the raster reader's flush does for its own partials (pcs_kernels.hip: vox_table_flush_regions) — the
+// bucket by binary search in the splitters (8 KiB of LDS per workgroup, ten dependent LDS reads per key, a lane's keys side by side), a
+// returning LDS add ranks the element among its chunk's for that bucket, ONE returning global add per bucket a chunk touches reserves
+// the slots. An element that finds its region full goes to the general list (keys_l / part_l, its bucket in bucket_of, counted in
+// ctl[0]) — regions only ever cost speed. One launch in place of histogram + column scan + scatter; the tail is then G1 alone.
+__global__ __launch_bounds__(kBktThreads)
+void pcs_vox_bkt_place_kernel(RawKeys raw, const VoxelPartial* __restrict__ part_in, const unsigned long long* __restrict__ spl_g,
+                              const unsigned int* __restrict__ reg, unsigned int* __restrict__ cursor,
+                              unsigned long long* __restrict__ keys_r, VoxelPartial* __restrict__ part_r, const unsigned int region_slots,
+                              unsigned long long* __restrict__ keys_l, VoxelPartial* __restrict__ part_l,
+                              unsigned short* __restrict__ bucket_of, unsigned int* __restrict__ ctl)
+{
+    __shared__ unsigned long long spl[kBkt];
+    __shared__ unsigned int hist[kBkt], rbase[kBkt];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned int m = raw.count();
+    const unsigned int chunks = (m + kBktChunk - 1u) / kBktChunk;
+    if (blockIdx.x >= chunks) return;
+    unsigned int B = reg[0], cap = reg[1];
+    if (B == 0u || B > kBkt) B = kBkt;
+    if ((unsigned long long)B * cap > region_slots) cap = 0u;              // (as the raster reader and the tail decide)
+    const unsigned int stride = kBkt / B;
+    for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) {
+        spl[j] = (j + 1u < B) ? spl_g[(j + 1u) * stride - 1u] : kEmptyKey;   // bucket j ends below splitter j (the last one is open)
+        hist[j] = 0u;
+    }
+    __syncthreads();
+    for (unsigned int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const unsigned int c0 = chunk * kBktChunk;
+        unsigned long long kk[kBktPer];
+        u32x4 pa[kBktPer], pb[kBktPer];
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            const unsigned int e = c0 + q * kBktThreads + threadIdx.x;
+            const bool live = e < m;
+            kk[q] = live ? raw.keys[e] : kEmptyKey;
+            const u32x4* p4 = reinterpret_cast<const u32x4*>(part_in + (live ? e : 0u));
+            pa[q] = p4[0]; pb[q] = p4[1];
+        }
+        unsigned int bk[kBktPer], rk[kBktPer];
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) bk[q] = 0u;
+#pragma unroll
+        for (unsigned int step = kBkt / 2; step; step >>= 1) {
+#pragma unroll
+            for (unsigned int q = 0; q < kBktPer; q++)
+                if (spl[bk[q] + step - 1u] <= kk[q]) bk[q] += step;
+        }
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            const bool live = c0 + q * kBktThreads + threadIdx.x < m;
+            rk[q] = live ? atomicAdd(&hist[bk[q]], 1u) : 0u;
+        }
+        __syncthreads();
+        for (unsigned int j = threadIdx.x; j < kBkt; j += kBktThreads) {
+            const unsigned int c = hist[j];
+            rbase[j] = c ? atomicAdd(&cursor[j], c) : 0u;
+            hist[j] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned int q = 0; q < kBktPer; q++) {
+            if (!(c0 + q * kBktThreads + threadIdx.x < m)) continue;
+            const unsigned int at = rbase[bk[q]] + rk[q];
+            if (at < cap) {
+                const size_t dst = (size_t)bk[q] * cap + at;
+                keys_r[dst] = kk[q];
+                u32x4* o4 = reinterpret_cast<u32x4*>(part_r + dst);
+                o4[0] = pa[q]; o4[1] = pb[q];
+            } else {
+                const unsigned int e = atomicAdd(ctl, 1u);
+                keys_l[e] = kk[q];
+                u32x4* o4 = reinterpret_cast<u32x4*>(part_l + e);
+                o4[0] = pa[q]; o4[1] = pb[q];
+                bucket_of[e] = (unsigned short)bk[q];
+            }
+        }
+        __syncthreads();                                                   // rbase is rewritten by the next chunk
+    }
+}
+
 // G1's table: key + six 64-bit sums per slot (a voxel may collect every point of the cloud: 2^25 points x 2^16 overflow 32
 // bits in every field); blue and the count share a word (b < 2^34, n < 2^30).
 __device__ __forceinline__ void bkt_hash(unsigned long long key, unsigned int& first, unsigned int& step)
@@ -1956,11 +2039,12 @@ hipError_t finish_call(VoxelWsState& ws, hipError_t e, int bucket_leaf = 0)
 }  // namespace
 
 // What a call on `ws` for this leaf needs of the workspace (carve): the owner sizes it with voxel_workspace_bytes(n, level).
-// Caller-held partials (from_partials) never fill regions.
+// (Caller-held partials are placed into regions too from a workspace's second bucket call on — pcs_vox_bkt_place_kernel — so both
+// forms size alike; `from_partials` is kept for the day they do not.)
 int voxel_workspace_level(uint32_t n_points, int leaf_mm, const VoxelWsState& ws, bool from_partials)
 {
-    if (!takes_bucket_tail(n_points, leaf_mm, ws)) return 0;
-    return from_partials ? 1 : 2;
+    (void)from_partials;
+    return takes_bucket_tail(n_points, leaf_mm, ws) ? 2 : 0;
 }
 
 void inject_voxel_stall(int launches) { g_stall_left.store(launches < 0 ? 0 : launches); }
@@ -2061,12 +2145,39 @@ hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const vo
         if (d_out_points) return hipMemsetAsync(d_out_points, 0, sizeof(int32_t), st);
         return hipSuccess;
     }
+    // The workspace is carved for as many partials as it HOLDS, not for this call's count: a root's count moves a little from frame-set
+    // to frame-set, and regions sized by the previous call's (2 m' + 64 Ki slots) must fit the capacity this call carves (the owner
+    // sizes the workspace with headroom: pcs_capi.cpp). Nothing below reads more than n_partials elements.
+    uint32_t n_carve = n_partials;
+    {
+        const int level = voxel_workspace_level(n_partials, leaf_mm, *ws, true);
+        uint32_t lo = n_partials, hi = (uint32_t)std::min<uint64_t>(4ull * n_partials + (1u << 20), level ? (1u << 26) - 1u : 0xFFFFFFF0u);
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+            if (voxel_workspace_bytes(mid, level) <= ws_bytes) lo = mid; else hi = mid - 1u;
+        }
+        n_carve = lo;
+    }
     Plan pl;
-    hipError_t e = plan_for(n_partials, leaf_mm, d_ws, ws_bytes, *ws, pl, st, true);
+    hipError_t e = plan_for(n_carve, leaf_mm, d_ws, ws_bytes, *ws, pl, st, true);
     if (e != hipSuccess) return e;
     pl.track_bits = false;                 // nobody recorded which key bits vary across the sources: every bit counts
+    if (pl.bucket && pl.regions) {
+        // WARM: the previous bucket call on this workspace left splitters for this leaf, region sizes and zeroed cursors — one launch
+        // places the caller's partials into the regions (what the raster reader does for its own), the tail is G1 alone: 2 launches
+        // instead of 4. The caller's arrays are only read; partials that find their region full land in the workspace's own list.
+        const Workspace& w = pl.w;
+        const unsigned int max_chunks = (n_partials + kBktChunk - 1u) / kBktChunk;
+        const unsigned int grid = std::max(1u, std::min(max_chunks, kBktGrid));
+        hipLaunchKernelGGL(pcs_vox_bkt_place_kernel, dim3(grid), dim3(kBktThreads), 0, st, RawKeys{d_keys, d_n_partials, n_partials},
+                           static_cast<const VoxelPartial*>(d_partials), w.spl, w.reg + 64 * pl.bpar, w.cursor + kBkt * pl.bpar, w.keys_r, w.part_r,
+                           (unsigned int)std::min<size_t>(w.region_slots, 0xFFFFFFFFu), w.keys_a, w.part, w.bucket_of, w.ctl);
+        e = hipGetLastError();
+        if (e != hipSuccess) return finish_call(*ws, e);
+        return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st), leaf_mm);
+    }
     pl.w.part = const_cast<VoxelPartial*>(static_cast<const VoxelPartial*>(d_partials));      // read in place
-    pl.regions = false;                    // caller-held partials: nobody filled regions
+    pl.regions = false;                    // cold: the chain partitions the caller's list itself
     pl.raw = RawKeys{d_keys, d_n_partials, n_partials};
     return finish_call(*ws, sort_and_reduce(pl, n_partials, d_out, d_out_points, st), pl.bucket ? leaf_mm : 0);
 }

@@ -231,10 +231,10 @@ class PcsNode:
         self._check(self._lib.pcs_node_wait_voxel(self._h, int(ticket), C.byref(nv)))
         return nv.value
 
-    def set_one_call(self, enable: bool) -> None:
-        """A one-peer node: rasters -> voxels enqueued at submit (True, the default) or the partials pipeline of a node of several
-        peers (False). pcs_node_set_one_call; nothing may be in flight."""
-        self._check(self._lib.pcs_node_set_one_call(self._h, 1 if enable else 0))
+    def set_one_call(self, mode: int) -> None:
+        """A one-peer node: 2 (default) rasters -> voxels enqueued at submit on two contexts used in turn, 1 on one context, 0 the
+        partials pipeline of a node of several peers. pcs_node_set_one_call; nothing may be in flight."""
+        self._check(self._lib.pcs_node_set_one_call(self._h, int(mode)))
 
     def voxel_reruns(self) -> int:
         """Voxel frame-sets this node ran again on the LSD tail after a flagged bucket tail (pcs_node_voxel_reruns)."""

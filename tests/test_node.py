@@ -128,17 +128,18 @@ def test_a_failed_submit_leaves_the_node_usable(oracle, flags):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], "one peer, partials pipeline"])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], "one peer, partials pipeline", "one peer, one context"])
 def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, devices, monkeypatch):
     """pcs_node_submit_voxel_device / pcs_node_wait_voxel: partials pre-aggregated per peer, ONE grouped exchange of keys +
     partials, sort + segmented mean on the root — byte-identical to the voxel grid of the stitched cloud, frame after frame,
     with the pre-aggregation of k+1 queued before the exchange of k. A node of ONE peer enqueues the rasters -> voxels call at
-    submit instead (no partials leave the library: stats say 0); PCS_NODE_ONE_CALL=0 keeps the partials pipeline for it."""
+    submit instead (no partials leave the library: stats say 0) — its two slots on two contexts of the peer in turn, or
+    (PCS_NODE_ONE_CALL=1) on one; PCS_NODE_ONE_CALL=0 keeps the partials pipeline for it."""
     from pointcloud_stitching_amd.node import PcsNode, VOXEL_PARTIALS, VOXEL_PAYLOADS
-    one_call = devices == [0]
+    one_call = devices == [0] or devices == "one peer, one context"
     if isinstance(devices, str):
+        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0" if "partials" in devices else "1")
         devices = [0]
-        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0")
     n, w, h, frames, leaf = 4, 320, 240, 5, 40
     cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
     sets = [([S.synth_depth(w, h, s, seed=S.SEED + 17 * f) for s in range(n)],
@@ -170,7 +171,7 @@ def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, dev
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", [[0], [0] * 8, "one peer, partials pipeline"])
+@pytest.mark.parametrize("devices", [[0], [0] * 8, "one peer, partials pipeline", "one peer, one context"])
 def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices, monkeypatch):
     """BASELINE configs[4] at full size — 16 x 1920x1080, invalid-depth compaction, 50 mm voxel grid — through the pipelined node
     call with two frame-sets in flight; [0]*8 is the configuration's own shape (2 cameras per peer, 8 peers) with the
@@ -182,8 +183,8 @@ def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices, m
     color = [S.synth_color(W, H, s) for s in range(N)]
     gold = GOLD["voxel"][str(leaf)]
     if isinstance(devices, str):
+        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0" if "partials" in devices else "1")
         devices = [0]
-        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0")
     with PcsNode(cfgs, devices=devices, flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
         cap = node.max_payload_shorts
         dd, dc = _upload(mem, depth, color)

@@ -632,3 +632,74 @@ def test_voxel_tail_preference_per_context(oracle, monkeypatch):
         with pytest.raises(PcsError) as e:
             ctx.set_voxel_tail(7)
         assert e.value.status == -1
+
+
+def _points_as_partials(p, leaf):
+    """Every point its own partial, in the exchange format (include/pcs_hip.h: pcs_voxel_partial + raw key): key = voxel indices
+    (floor(v / leaf) + ceil(32768 / leaf)) packed z | y | x with axis_bits(leaf) bits each; sums = the point, n = 1."""
+    max_index = 32767 // leaf + (32768 + leaf - 1) // leaf
+    bits = 1
+    while (1 << bits) <= max_index:
+        bits += 1
+    bias = (32768 + leaf - 1) // leaf
+    v = np.floor_divide(p[:, :3].astype(np.int64), leaf) + bias
+    keys = ((v[:, 2] << (2 * bits)) | (v[:, 1] << bits) | v[:, 0]).astype(np.uint64)
+    parts = np.zeros((p.shape[0], 8), np.uint32)
+    parts[:, 0:3] = p[:, :3].astype(np.int32).view(np.uint32)
+    c = p[:, 3].view(np.uint16).astype(np.uint32)
+    parts[:, 3], parts[:, 4], parts[:, 5] = c & 0xFF, c >> 8, p[:, 4].view(np.uint16).astype(np.uint32) & 0xFF
+    parts[:, 6] = 1
+    return keys, parts
+
+
+@pytest.mark.gpu
+def test_caller_held_partials_take_the_warm_path_from_the_second_call(oracle, voxel_tail):
+    """pcs_voxel_grid_from_partials_device on ONE context, call after call (what the root of a multi-GPU voxel grid does): the first
+    bucket call partitions the caller's list itself (histogram, column scan, scatter), every later one PLACES it into the regions the
+    previous call sized (pcs_vox_bkt_place_kernel) and runs the bucket reduce alone. Sequence: a cloud, the same again (steady
+    state), a cloud 30 % larger (regions sized for less: some overflow to the list), a cloud that moved (stale splitters), a dense
+    slab inside the old key range (regions overflow massively), nothing at all, one partial, the first cloud again with its count
+    read from DEVICE memory beside a larger capacity, and a different leaf (no splitters for it: cold again). The caller's arrays
+    must come back untouched; every result against the oracle."""
+    rng = np.random.default_rng(777)
+
+    def cloud(n, lo, hi):
+        p = np.zeros((n, 5), np.int16)
+        p[:, :3] = rng.integers(lo, hi, (n, 3))
+        p[:, 3] = rng.integers(0, 65536, n).astype(np.uint16).view(np.int16)
+        p[:, 4] = rng.integers(0, 256, n)
+        return p
+    a = cloud(200000, -2500, 2500)
+    bigger = np.concatenate([a, cloud(60000, -2500, 2500)])
+    moved = cloud(200000, 4000, 9000)
+    slab = np.concatenate([a, cloud(400000, -300, 300)])
+    leaf = 40
+    cap = 700000
+    cfgs, _, _ = S.synth_frame_set(1, 64, 48)
+    with PcsContext(cfgs) as ctx:
+        d_keys = ctx.device_malloc(cap * 8 + 64); d_parts = ctx.device_malloc(cap * 32 + 64)
+        d_out = ctx.device_malloc(cap * 10 + 64); d_nv = ctx.device_malloc(64); d_m = ctx.device_malloc(64)
+        seq = [("a", a, leaf, False), ("a", a, leaf, False), ("bigger", bigger, leaf, False), ("moved", moved, leaf, False),
+               ("slab", slab, leaf, False), ("empty", a[:0], leaf, False), ("one", a[:1], leaf, False), ("a, device count", a, leaf, True),
+               ("a, other leaf", a, 55, False), ("a", a, leaf, False)]
+        for name, p, lf, dev_count in seq:
+            keys, parts = _points_as_partials(p, lf)
+            if p.shape[0]:
+                ctx.memcpy_h2d(d_keys, keys); ctx.memcpy_h2d(d_parts, parts)
+            n = p.shape[0]
+            if dev_count:
+                ctx.memcpy_h2d(d_m, np.array([n], np.int32))
+                ctx.voxel_grid_from_partials_device(d_keys, d_parts, cap, lf, d_out, cap * 5, d_nv, d_n_partials=d_m)
+            else:
+                ctx.voxel_grid_from_partials_device(d_keys, d_parts, n, lf, d_out, max(n, 1) * 5, d_nv)
+            ctx.synchronize()
+            nv = np.empty(1, np.int32); ctx.memcpy_d2h(nv, d_nv)
+            want = oracle.voxel_grid(p, lf)
+            assert int(nv[0]) == want.shape[0], (name, voxel_tail)
+            if want.shape[0]:
+                got = np.empty(want.size, np.int16); ctx.memcpy_d2h(got, d_out)
+                assert (got.reshape(-1, 5) == want).all(), (name, voxel_tail)
+            if n:
+                back_k = np.empty_like(keys); back_p = np.empty_like(parts)
+                ctx.memcpy_d2h(back_k, d_keys); ctx.memcpy_d2h(back_p, d_parts)
+                assert (back_k == keys).all() and (back_p == parts).all(), name
