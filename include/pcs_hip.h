@@ -138,6 +138,10 @@ int          pcs_set_cam_to_world(pcs_ctx* ctx, int stream, const float m16[16])
  * (conversions cannot reach 2^31, so no running maximum is kept) (DESIGN.md "Certified arithmetic"). The
  * results are bit-identical; this is a diagnostic. */
 int          pcs_stream_math(const pcs_ctx* ctx, int stream);
+/* 1 when the stream's colour ROW is certified independent of the depth value (depth->colour R = I, t_y = t_z = 0, no distortion, and a
+ * sweep over every raster row x every Z16 value on the device at pcs_create found no exception): the voxel reader then takes the row
+ * from a per-row table instead of computing it per pixel. Same bytes either way; PCS_ROW_CONST=0 at pcs_create turns it off (A/B). */
+int          pcs_stream_color_row_const(const pcs_ctx* ctx, int stream);
 
 /* Number of points one frame of `stream` deprojects to (= depth width*height). */
 int          pcs_stream_points(const pcs_ctx* ctx, int stream);

@@ -97,6 +97,10 @@ class PcsContext:
         """0 = IEEE expansion, 1 = certified reduced-instruction arithmetic, 2 = + identity-R shortcut."""
         return int(self._lib.pcs_stream_math(self._h, stream))
 
+    def stream_color_row_const(self, stream: int) -> bool:
+        """The stream's colour row is certified independent of depth (pcs_stream_color_row_const)."""
+        return bool(self._lib.pcs_stream_color_row_const(self._h, stream))
+
     @property
     def max_payload_shorts(self) -> int:
         return int(self._lib.pcs_max_payload_shorts(self._h))

@@ -683,7 +683,8 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         float *dmx = nullptr, *dmy = nullptr;
         CREATE_CHK(hipMalloc((void**)&dmx, sizeof(float) * ((size_t)p.W + 8)));
         c->d_lut[2 * s] = dmx;
-        CREATE_CHK(hipMalloc((void**)&dmy, sizeof(float) * ((size_t)p.H + 8)));
+        CREATE_CHK(hipMalloc((void**)&dmy, sizeof(float) * (2 * (size_t)p.H + 8)));      // + the colour-row table of CertRowConst
+        CREATE_CHK(hipMemset(dmy, 0, sizeof(float) * (2 * (size_t)p.H + 8)));
         c->d_lut[2 * s + 1] = dmy;
         CREATE_CHK(hipMemcpy(dmx, mx.data(), sizeof(float) * p.W, hipMemcpyHostToDevice));
         CREATE_CHK(hipMemcpy(dmy, my.data(), sizeof(float) * p.H, hipMemcpyHostToDevice));
@@ -765,6 +766,30 @@ int pcs_create(pcs_ctx** out, const pcs_config* cfg)
         c->math[s] = q.cert_fast ? ((q.ident_r ? 2 : 1) + (q.no_overflow ? 2 : 0)) : 0;
     }
     CREATE_CHK(hipMemcpy(c->d_params, c->h_params.data(), sizeof(StreamParams) * c->n_streams, hipMemcpyHostToDevice));
+    {   // CertRowConst (pcs_kernels.hip): for a stream with R = I, t_y = t_z = 0 and no distortion the colour ROW of a pixel is — up to
+        // the rounding of (z * my) / z — a function of its raster row. Swept on the device over every row x every Z16 value 1 .. 65 535
+        // through the IEEE chain (H x 65 535 evaluations: 47 M for 720 rows, under a millisecond); where no pair disagrees the table
+        // behind the my LUT is valid and ident_r becomes 2. PCS_ROW_CONST=0 leaves every stream at 1 (A/B; the tests run both).
+        const char* env = getenv("PCS_ROW_CONST");
+        const bool want = !(env && env[0] == '0');
+        unsigned long long* d_bad = nullptr;
+        bool any = false;
+        for (int s = 0; want && s < c->n_streams; s++) {
+            StreamParams& p = c->h_params[s];
+            const float* t = c->cfg[s].depth_to_color.translation;
+            if (p.ident_r != 1 || p.ddist || p.cdist || p.tex_half || t[1] != 0.0f || t[2] != 0.0f || !p.z_zero_iff_d_zero) continue;
+            if (!d_bad) CREATE_CHK(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+            CREATE_CHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream));
+            int32_t* d_crow = reinterpret_cast<int32_t*>(const_cast<float*>(p.my) + p.H);
+            CREATE_CHK(launch_certify_color_row(c->d_params, s, p.H, d_crow, d_bad, c->stream));
+            unsigned long long h = 1;
+            CREATE_CHK(hipMemcpyAsync(&h, d_bad, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            CREATE_CHK(hipStreamSynchronize(c->stream));
+            if (h == 0) { p.ident_r = 2; any = true; }
+        }
+        if (d_bad) (void)hipFree(d_bad);
+        if (any) CREATE_CHK(hipMemcpy(c->d_params, c->h_params.data(), sizeof(StreamParams) * c->n_streams, hipMemcpyHostToDevice));
+    }
 #undef CREATE_CHK
     } catch (const std::exception& ex) {
         const int rc = fail(nullptr, PCS_ERR_NOMEM, "pcs_create: host allocation failed (%s)", ex.what());
@@ -826,6 +851,12 @@ int pcs_stream_math(const pcs_ctx* c, int stream)
 {
     if (!c || stream < 0 || stream >= c->n_streams) return PCS_ERR_INVALID_ARG;
     return c->math[stream];
+}
+
+int pcs_stream_color_row_const(const pcs_ctx* c, int stream)
+{
+    if (!c || stream < 0 || stream >= c->n_streams) return PCS_ERR_INVALID_ARG;
+    return c->h_params[stream].ident_r == 2 ? 1 : 0;
 }
 
 size_t pcs_max_payload_shorts(const pcs_ctx* c)
@@ -1645,16 +1676,16 @@ try {
         const int nl = std::min(kLaunchStreams, S - s0);
         FramePtrs fp{};
         uint32_t mp = 0, mw = 0, mh = 0;
-        bool fast = true, ident = true, patch_ok = true;
+        bool fast = true, ident = true, rowc = true, patch_ok = true;
         for (int k = 0; k < nl; k++) {
             const StreamParams& q = c->h_params[s0 + k];
             fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
             mp = std::max(mp, q.n_points);
             mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
             patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
-            fast &= q.cert_fast != 0; ident &= q.ident_r != 0;
+            fast &= q.cert_fast != 0; ident &= q.ident_r != 0; rowc &= q.ident_r == 2;
         }
-        const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
+        const MathSel sel = !fast ? MathSel::Ieee : (ident ? (rowc ? MathSel::CertRowConst : MathSel::CertIdentR) : MathSel::Cert);
         HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
     }
     HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
@@ -1708,16 +1739,16 @@ try {
             const int nl = std::min(kLaunchStreams, S - s0);
             FramePtrs fp{};
             uint32_t mp = 0, mw = 0, mh = 0;
-            bool fast = true, ident = true, patch_ok = true;
+            bool fast = true, ident = true, rowc = true, patch_ok = true;
             for (int k = 0; k < nl; k++) {
                 const StreamParams& q = c->h_params[s0 + k];
                 fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
                 mp = std::max(mp, q.n_points);
                 mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
                 patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
-                fast &= q.cert_fast != 0; ident &= q.ident_r != 0;
+                fast &= q.cert_fast != 0; ident &= q.ident_r != 0; rowc &= q.ident_r == 2;
             }
-            const MathSel sel = !fast ? MathSel::Ieee : (ident ? MathSel::CertIdentR : MathSel::Cert);
+            const MathSel sel = !fast ? MathSel::Ieee : (ident ? (rowc ? MathSel::CertRowConst : MathSel::CertIdentR) : MathSel::Cert);
             HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
         }
     }

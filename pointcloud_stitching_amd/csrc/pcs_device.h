@@ -43,13 +43,14 @@ struct alignas(16) StreamParams {
     uint32_t tile_base;      // index of this stream's first tile in the per-tile count arrays
     uint32_t w_magic, w_shift; // floor(i / W) == umulhi(i, w_magic) >> w_shift for i < 2^31 (0 = use '/')
     int32_t  cert_fast;      // host+device certified for CertMath (see pcs_capi.cpp)
-    int32_t  ident_r;        // depth->colour rotation is exactly I, translation has no -0
+    int32_t  ident_r;        // depth->colour rotation is exactly I, translation has no -0; 2: and the colour ROW of a pixel is certified
+                             // independent of its depth value — my[H .. 2H) holds the row of every raster row (CertRowConst)
     int32_t  no_overflow;    // certified: no converted value (world mm, colour column/row) can reach 2^31
     int32_t  z_zero_iff_d_zero; // depth_scale finite and depth_scale*1 != 0: (z == 0) == (d == 0)
     uint32_t cut_dmax;       // -c from the Z16 word alone: in range <=> 1 <= d <= cut_dmax (0 = not certified, deproject)
     int32_t  tex_half;       // PCS_FLAG_TEXCOORD_HALF_PIXEL: u = (px + 0.5)/W (handled on the CDIST code path)
     const float* mx;         // [W]  (c - ppx) / fx   — IEEE division done once on the host
-    const float* my;         // [H]  (r - ppy) / fy
+    const float* my;         // [H]  (r - ppy) / fy; behind it [H] int32: the colour row of raster row r (valid when ident_r == 2)
 };
 
 // Per-call raster pointers, passed by value in the kernarg segment (no per-frame H2D of a table).
@@ -89,7 +90,8 @@ struct PackBatch {
 };
 
 // Which arithmetic policy a launch may use (the AND over the streams of the launch).
-enum class MathSel { Ieee = 0, Cert = 1, CertIdentR = 2, CertNoOvf = 3, CertIdentRNoOvf = 4 };
+enum class MathSel { Ieee = 0, Cert = 1, CertIdentR = 2, CertNoOvf = 3, CertIdentRNoOvf = 4,
+                     CertRowConst = 5 /* voxel reader only: CertIdentR + the colour row from a per-row table (ident_r == 2) */ };
 
 // Launchers (defined in pcs_kernels.hip). All enqueue on `st` and return the hipError of the launch.
 hipError_t launch_fused_dense(const StreamParams* d_params, int stream0, int n_launch, uint32_t max_points,
@@ -142,6 +144,9 @@ hipError_t launch_compact_batch(const StreamParams* d_params, int n_streams, int
                                 const BatchCounts& bc, uint32_t* d_tile_counts, uint32_t* d_tile_prefix,
                                 uint32_t* d_stream_kept, hipStream_t st);
 hipError_t launch_verify_div_const(float c, float rc, int32_t dim, unsigned long long* d_bad, hipStream_t st);
+// CertRowConst's certificate for one stream of an uploaded parameter table: d_crow[rows] = colour row of every raster row at depth 1,
+// *d_bad += (row, depth) pairs over all 65 535 depth values whose row differs (pcs_kernels.hip)
+hipError_t launch_certify_color_row(const StreamParams* d_params, int stream, int rows, int32_t* d_crow, unsigned long long* d_bad, hipStream_t st);
 
 // a2 twin.
 hipError_t launch_pack_dense(const StreamParams* d_params, int stream, const VertexPtrs& vp,

@@ -36,6 +36,7 @@
 #define PCS_TU_VOXEL 0
 #endif
 
+
 #ifndef EMIT_WAVES
 #define EMIT_WAVES 6      // 7 fits 72 VGPRs only with scratch spills in some instantiations and measured no faster
 #endif
@@ -162,6 +163,7 @@ struct VoxCvt : FastCvt<TRACK> {
 // tools/lab/kernel_lab.hip holds the exhaustive / fuzz checks and the measurements behind each choice.
 struct IeeeMath {
     static constexpr bool kIdentR = false;
+    static constexpr bool kRowConst = false;
     // 0 exact conversions, 1 fast with overflow tracking, 2 fast, overflow certified impossible.
     // The tracked fast form is exact for every input (its redo path IS the exact form), so even the
     // fallback policy uses it; only the quotients stay on the IEEE expansion here.
@@ -205,6 +207,7 @@ struct IeeeMath {
 template <bool IDENT_R, bool NO_OVERFLOW = false>
 struct CertMath {
     static constexpr bool kIdentR = IDENT_R;
+    static constexpr bool kRowConst = false;
     static constexpr int kCvtMode = NO_OVERFLOW ? 2 : 1;
     static __device__ __forceinline__ void d2c(const StreamParams& P, float X, float Y, float Z,
                                                float& P0, float& P1, float& P2)
@@ -243,6 +246,17 @@ struct CertMath {
 
 using CertNoOvf = CertMath<false, true>;
 using CertIdentNoOvf = CertMath<true, true>;
+
+// CertRowConst: CertMath<IDENT_R> for streams whose COLOUR ROW does not depend on the depth value (StreamParams::ident_r == 2). With
+// R = I and t_y = t_z = 0 a pixel's colour row is trunc(fma(((z * my) / z * fy + ppy) / H, H, 0.5)) clamped — mathematically a function of
+// its raster row alone, in floats almost one: the rounding of (z * my) / z moves py by ~1e-4 of a pixel, which changes the integer only for a
+// row whose py lies that close to k - 0.5. Whether any row of a stream does is not argued but SWEPT when the context is created
+// (pcs_certify_color_row_kernel: every row x every Z16 value 1 .. 65 535 through the IEEE chain); where none does, the row index of each
+// raster row is a table (behind the my LUT) and the second quotient, its projection, texture coordinate, scale, clamp and conversion —
+// 13 of the ~70 VALU instructions of a pixel — are one load per lane and one select per pixel. Used by the voxel reader (VALU-bound).
+struct CertRowConst : CertMath<true, false> {
+    [[maybe_unused]] static constexpr bool kRowConst = true;
+};
 
 // a2 colour lookup (src/pcs-camera-optimized.cpp:431-452, 584-585): texcoord -> byte index of the pixel.
 __device__ __forceinline__ void color_coords(const StreamParams& P, float u, float v, float& xf, float& yf)
@@ -348,8 +362,9 @@ __device__ __forceinline__ float bc_tangential(float a, float kA, float kB, floa
 }
 
 // a5 for one pixel: depth value d, normalised ray (mx,my) from the LUTs.
+// (crow: the pixel's colour row under Mth::kRowConst — then p.v carries that INTEGER, 0 for an invalid pixel, instead of v)
 template <bool DDIST, bool CDIST, class Mth>
-__device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32_t d, float mx, float my)
+__device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32_t d, float mx, float my, int crow = 0)
 {
     const float z = __fmul_rn(P.depth_scale, (float)d);
     if (DDIST && P.ddist) {   // template gate compiles it in; the per-stream flag is wave-uniform
@@ -386,10 +401,14 @@ __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32
     // unconditionally and then selected: a conditional here becomes a divergent branch per pixel, which
     // stops the scheduler from interleaving the 8 pixels of a lane.
     const float qu = Mth::div_const(px, P.c_w_f, P.c_rw);
-    const float qv = Mth::div_const(py, P.c_h_f, P.c_rh);
     const bool valid = (z != 0.0f);
     p.u = valid ? qu : 0.0f;
-    p.v = valid ? qv : 0.0f;
+    if (Mth::kRowConst) {         // (y, py and everything behind them are dead code in this instantiation)
+        p.v = __int_as_float(valid ? crow : 0);
+    } else {
+        const float qv = Mth::div_const(py, P.c_h_f, P.c_rh);
+        p.v = valid ? qv : 0.0f;
+    }
     return p;
 }
 
@@ -485,7 +504,7 @@ struct DepthSource {
     // The fast path in two steps, for kernels that want to do something between requesting a lane's inputs and using them
     // (the single-pass compaction counts and publishes from the raw Z16 words first): fast() says whether it applies
     // (uniform over the launch's stream), fetch() issues the loads, deproject() consumes them.
-    struct Raw { uint4 dv; f32x4 ma, mb; float my; };
+    struct Raw { uint4 dv; f32x4 ma, mb; float my; int crow; };
     __device__ __forceinline__ bool fast(const StreamParams& P) const { return (P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0; }
     __device__ __forceinline__ Raw fetch(const StreamParams& P, uint32_t i0) const
     {
@@ -499,6 +518,7 @@ struct DepthSource {
         q.ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
         q.mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
         q.my = as_global(P.my)[r];
+        q.crow = Mth::kRowConst ? __float_as_int(as_global(P.my)[(uint32_t)P.H + r]) : 0;       // the row table lies behind the H floats of my
         return q;
     }
     template <bool DD, bool CD>
@@ -509,7 +529,7 @@ struct DepthSource {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
-            p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], q.my);
+            p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], q.my, q.crow);
         }
     }
 
@@ -524,7 +544,8 @@ struct DepthSource {
                 const uint32_t i = min(i0 + k, n - 1);
                 const uint32_t r = i / (uint32_t)P.W;
                 const uint32_t c = i - r * (uint32_t)P.W;
-                p[k] = deproject_pixel<DD, CD, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+                p[k] = deproject_pixel<DD, CD, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r],
+                                                    Mth::kRowConst ? __float_as_int(as_global(P.my)[(uint32_t)P.H + r]) : 0);
             }
         }
     }
@@ -1288,7 +1309,7 @@ struct VoxPoint {
     int32_t x, y, z;
     uint32_t w;
 };
-template <class Cvt>
+template <bool ROWC = false, class Cvt>
 __device__ __forceinline__ VoxPoint make_vox_point(const StreamParams& P, const uint8_t* __restrict__ color,
                                                    const PointIn& p, Cvt& cv)
 {
@@ -1297,9 +1318,11 @@ __device__ __forceinline__ VoxPoint make_vox_point(const StreamParams& P, const 
     const float az = world_mm(P.M + 8, p.X, p.Y, p.Z);
     float xf, yf;
     color_coords(P, p.u, p.v, xf, yf);
-    cv.note(ax, ay, az, xf, yf);
+    cv.note(ax, ay, az, xf, ROWC ? xf : yf);
     const int32_t x = cv.cvt(ax), y = cv.cvt(ay), z = cv.cvt(az);
-    const uint32_t w = color_fetch(P, color, cv.pixel(xf, P.cW - 1, P.c_wm1_f), cv.pixel(yf, P.cH - 1, P.c_hm1_f), cv);
+    // (ROWC: p.v IS the row, certified at pcs_create for every depth value — whatever conversion policy the lane runs under)
+    const int32_t yi = ROWC ? __float_as_int(p.v) : cv.pixel(yf, P.cH - 1, P.c_hm1_f);
+    const uint32_t w = color_fetch(P, color, cv.pixel(xf, P.cW - 1, P.c_wm1_f), yi, cv);
     if (Cvt::kCoordsInShort) return VoxPoint{x, y, z, w};
     return VoxPoint{(int32_t)(int16_t)x, (int32_t)(int16_t)y, (int32_t)(int16_t)z, w};
 }
@@ -1753,7 +1776,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             VoxPoint rec[8];
             auto fill = [&](auto& cv) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) rec[k] = make_vox_point(P, color, p[k], cv);
+                for (int k = 0; k < 8; k++) rec[k] = make_vox_point<Mth::kRowConst>(P, color, p[k], cv);
             };
             if (Mth::kCvtMode == 2) {
                 VoxCvt<false> fast;
@@ -2075,6 +2098,32 @@ void pcs_stitch_kernel(const uint16_t* __restrict__ src, uint32_t out_points, ui
     store_staged(stage, head, pts * PCS_POINT_BYTES, gdst);
 }
 
+// Certificate of CertRowConst for one stream: row r's colour row through the IEEE chain for EVERY Z16 value 1 .. 65 535 (one workgroup
+// per raster row). crow[r] = the row for d = 1; *bad counts the (row, depth) pairs that give another one. The chain is the product's
+// own code (deproject_pixel + color_coords + the exact conversion), so the sweep cannot disagree with what the kernels would compute.
+__global__ __launch_bounds__(256)
+void pcs_certify_color_row_kernel(const StreamParams* __restrict__ params, int stream, int32_t* __restrict__ crow,
+                                  unsigned long long* __restrict__ bad)
+{
+    const StreamParams& P = params[stream];
+    const uint32_t r = blockIdx.x;
+    if (r >= (uint32_t)P.H) return;
+    const float my = as_global(P.my)[r];
+    auto row_of = [&](uint32_t d) {
+        const PointIn p = deproject_pixel<false, false, IeeeMath>(P, d, 0.0f, my);
+        float xf, yf;
+        color_coords(P, p.u, p.v, xf, yf);
+        ExactCvt ex;
+        return ex.pixel(yf, P.cH - 1, P.c_hm1_f);
+    };
+    const int32_t want = row_of(1u);
+    uint32_t local = 0;
+    for (uint32_t d = 1u + threadIdx.x; d < 65536u; d += 256u) local += row_of(d) != want;
+    if (local) atomicAdd(bad, (unsigned long long)local);
+    if (threadIdx.x == 0) crow[r] = want;
+}
+
+
 // Device-side certificate for CertMath::div_const: over ALL 2^32 numerators a, the pixel coordinate that
 // the pack derives from a quotient by the raster dimension c — clamp(cvttss2si(fma(a/c, c, 0.5)), 0, c-1)
 // — is the same with Markstein's quotient as with the IEEE one. Run once per distinct dimension when a
@@ -2317,8 +2366,9 @@ hipError_t launch_fused_voxel_partials(const StreamParams* d_params, int stream0
     // no stream of the context has a distortion model (or the half-pixel texture convention): the instantiation without
     // their (uniform, but not free in a VALU-bound kernel) tests
 #define L(D, M) hipLaunchKernelGGL((pcs_fused_voxel_partials_kernel<D, D, M>), grid, dim3(kVoxThreads), 0, st, d_params, stream0, fp, flags, vs, rounds, tl, vs.leaf < 30u ? 1 : 0)
-    const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf);
+    const bool ident = (math == MathSel::CertIdentR || math == MathSel::CertIdentRNoOvf || math == MathSel::CertRowConst);
     if (math == MathSel::Ieee) L(true, IeeeMath);
+    else if (math == MathSel::CertRowConst && !any_dist) L(false, CertRowConst);
     else if (any_dist) { if (ident) L(true, CertMath<true>); else L(true, CertMath<false>); }
     else               { if (ident) L(false, CertMath<true>); else L(false, CertMath<false>); }
 #undef L
@@ -2357,6 +2407,13 @@ hipError_t launch_pack_batch(const StreamParams* d_params, const PackBatch& pb, 
     const dim3 grid = tile_grid(max_points, n);
     if (aligned) hipLaunchKernelGGL((pcs_pack_batch_kernel<true>), grid, dim3(kBlockThreads), 0, st, d_params, pb);
     else         hipLaunchKernelGGL((pcs_pack_batch_kernel<false>), grid, dim3(kBlockThreads), 0, st, d_params, pb);
+    return hipGetLastError();
+}
+
+hipError_t launch_certify_color_row(const StreamParams* d_params, int stream, int rows, int32_t* d_crow, unsigned long long* d_bad, hipStream_t st)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pcs_certify_color_row_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_params, stream, d_crow, d_bad);
     return hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ SYMBOLS = [
     ("pcs_set_cam_to_world", C.c_int, [_VP, C.c_int, _P(C.c_float)]),
     ("pcs_stream_points", C.c_int, [_VP, C.c_int]),
     ("pcs_stream_math", C.c_int, [_VP, C.c_int]),
+    ("pcs_stream_color_row_const", C.c_int, [_VP, C.c_int]),
     ("pcs_max_payload_shorts", C.c_size_t, [_VP]),
     ("pcs_copy_pointcloud_xyzrgb_to_buffer", C.c_int,
      [_VP, C.c_int, _VP, _VP, C.c_int, _VP, _VP, _P(C.c_int)]),
