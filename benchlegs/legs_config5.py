@@ -89,6 +89,42 @@ def config5_one_gpu(g):
         else:
             os.environ["PCS_VOXEL_REGIONS"] = regions_default
     bucket_default = tail_default in (None, "bucket")
+    # ... and as a FRAME LOOP over two contexts used in turn (each its own stream, workspace, splitters, regions): the bucket tail of
+    # frame-set k — a latency chain that leaves the chip almost empty — runs beside the pre-aggregation of k+1. What libpcs_node does
+    # for a one-peer node (pcs_node_submit_voxel_device / pcs_node_wait_voxel) and what a caller's own loop can do with two pcs_ctx.
+    ctx5b = g.new_context(cfg5, flags=FLAG_DROP_INVALID, own_stream=True)
+    ctx5.set_stream(0)                                   # its own stream again: the two contexts must not share one
+    vox5b = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
+    nv5b = torch.zeros(1, dtype=torch.int32, device=dev)
+    pair = ((ctx5, vox5, nv5), (ctx5b, vox5b, nv5b))
+    torch.cuda.synchronize(dev)
+
+    def turn():
+        c, v, nvx = pair[k5[0] & 1]
+        dp, cp = args5[k5[0] % 4]; k5[0] += 1
+        check(lib.pcs_process_frames_voxel_device(c._h, dp, cp, LEAF, VP(v.data_ptr()), v.numel(), VP(nvx.data_ptr())), c._h)
+    import time
+    for _ in range(8):
+        turn()
+    ctx5.synchronize(); ctx5b.synchronize()
+    ms_pair = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(60):
+            turn()
+        ctx5.synchronize(); ctx5b.synchronize()
+        ms_pair = min(ms_pair, (time.perf_counter() - t0) * 1e3 / 60)
+    pair_ok = True
+    for c, v, nvx in pair:
+        m = int(nvx.item())
+        dg = hashlib.sha256(v[:m * POINT_SHORTS].cpu().numpy().tobytes()).hexdigest()
+        pair_ok = pair_ok and bool(gold5) and gold5["voxels"] == m and gold5["sha256"] == dg
+    if gold5 and not pair_ok:
+        raise RuntimeError("config5 two-context frame loop: a voxel cloud differs from the oracle digest")
+    row_const = all(ctx5.stream_color_row_const(s) for s in range(S5))
+    ctx5b.close()
+    del vox5b
+    ctx5.set_stream(g.stream.cuda_stream)
     res = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
                               "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
                               "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
@@ -105,7 +141,9 @@ def config5_one_gpu(g):
                                                    "rasters; the stitched cloud is never written to HBM. Warm bucket tail: the "
                                                    "pre-aggregation puts every partial into its bucket's region (the previous "
                                                    "call's splitters), one reduce launch follows: 2 kernels per call. "
-                                                   "cold_chain_*: PCS_VOXEL_REGIONS=0, every call partitions (histogram, column "
+                                                   "frame_loop_two_contexts_*: the same call on two contexts used in turn (host clock over 3 x 60 calls, best): the bucket tail of k "
+                                                               "runs beside the pre-aggregation of k+1; colour_row_from_table: CertRowConst certified for every stream. "
+                                                               "cold_chain_*: PCS_VOXEL_REGIONS=0, every call partitions (histogram, column "
                                                    "scan, scatter, reduce: 5 kernels); lsd_tail_*: the round-4 tail (13 kernels) "
                                                    "forced for the same call; the timed loop's cloud is hashed against the "
                                                    "committed oracle digest"},

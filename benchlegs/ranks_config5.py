@@ -98,7 +98,7 @@ def run_config5(args):
     step(); torch.cuda.synchronize(dev)
     check = {}
     if rank == 0:
-        nv = int(svg.n_vox[0].item())
+        nv = svg.voxels(vox.data_ptr(), out_shorts) if world > 1 else int(svg.n_vox[0].item())
         digest = hashlib.sha256(vox[:nv * POINT_SHORTS].cpu().numpy().tobytes()).hexdigest()
         check = {"voxels": nv, "voxel_sha256": digest, "golden": None}
         gpath = os.path.join(ROOT, "tests", "golden", "config5_digests.json")

@@ -220,6 +220,24 @@ class ShardedVoxelGrid:
         self.ctx.voxel_grid_from_partials_device(self.keys.data_ptr(), self.parts.data_ptr(), sum(self.counts), self.leaf,
                                                  d_out, out_shorts, self.n_vox.data_ptr())
 
+    def voxels(self, d_out: int, out_shorts: int) -> int:
+        """Root: the voxel count of the last reduce(), read back (synchronises the context's stream) — never negative. A bucket tail
+        that gave up waiting for one of its own workgroups leaves -1 there (include/pcs_hip.h, pcs_voxel_grid_device): the partials
+        are still in the root's arrays, so the reduce is run again on the LSD tail, which is then latched for the context. A negative
+        length must never reach a caller's size arithmetic or the wire (src/pcs-multicamera-client.cpp:394-403)."""
+        if self.st.rank != self.st.root:
+            return 0
+        self.ctx.synchronize()
+        nv = int(self.n_vox[0].item())
+        if nv < 0:
+            self.ctx.set_voxel_tail(3)                # PCS_VOXEL_TAIL_LSD_LATCHED
+            self.reduce(d_out, out_shorts)
+            self.ctx.synchronize()
+            nv = int(self.n_vox[0].item())
+            if nv < 0:
+                raise RuntimeError("the voxel pipeline reported a negative count on the LSD tail too (device stalled?)")
+        return nv
+
     def run(self, d_depth: Sequence[int], d_color: Sequence[int], d_out: int, out_shorts: int) -> None:
         self.pre_aggregate(d_depth, d_color)
         self.exchange()

@@ -341,6 +341,17 @@ with PcsContext(cfgs, device=0, flags=FLAG_DROP_INVALID) as ctx:
     nv = int(sv.n_vox[0].item())
     want = O.voxel_grid(stitched, 50)
     assert nv == want.shape[0] and (vox[:nv * 5].cpu().numpy().reshape(-1, 5) == want).all()
+    assert sv.voxels(vox.data_ptr(), vox.numel()) == nv
+    # a flagged bucket tail (fault injection): the device word says -1, voxels() runs the reduce again on the LSD tail
+    import os
+    os.environ["PCS_VOXEL_TAIL"] = "bucket"
+    ctx.inject_voxel_stall(1)
+    sv.run([t.data_ptr() for t in dd], [t.data_ptr() for t in dc], vox.data_ptr(), vox.numel())
+    torch.cuda.synchronize()
+    assert int(sv.n_vox[0].item()) == -1
+    assert sv.voxels(vox.data_ptr(), vox.numel()) == nv and ctx.voxel_tail_reruns() == 1
+    assert (vox[:nv * 5].cpu().numpy().reshape(-1, 5) == want).all()
+    ctx.inject_voxel_stall(0)
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_WORLD1_OK")

@@ -368,6 +368,74 @@ def test_two_physical_gpus_direct_store_and_rccl(oracle, flags):
             assert ms[1] > 0
 
 
+def _two_gpus_or_skip():
+    from pointcloud_stitching_amd import lib as L
+    ngpu = int(L.load().pcs_device_count())
+    if ngpu < 2:
+        pytest.skip(f"needs two physical GPUs; this box shows {ngpu}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["partials", "payloads"])
+def test_two_physical_gpus_voxel_partials_exchange(oracle, route):
+    """BASELINE configs[4]'s exchange across a link: two DISTINCT device ids, every GPU pre-aggregates its own cameras, the partials
+    (or, route payloads, the compacted payloads) cross to GPU 0 in one grouped RCCL exchange, sort + segmented mean there — pipelined
+    with two frame-sets in flight, then the synchronous form — against the oracle; and at the configuration's own size (16 x 1080p,
+    8 cameras per GPU here) against the committed digest. Skips with a reason on a one-GPU box."""
+    _two_gpus_or_skip()
+    from pointcloud_stitching_amd.node import PcsNode, VOXEL_PARTIALS, VOXEL_PAYLOADS
+    n, w, h, frames, leaf = 4, 320, 240, 4, 40
+    cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
+    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 17 * f) for s in range(n)],
+             [S.synth_color(w, h, s, seed=S.SEED + 17 * f) for s in range(n)]) for f in range(frames)]
+    want = [oracle.voxel_grid(oracle.process_frames(cfgs, d, c, FLAG_DROP_INVALID, 1)[0], leaf) for d, c in sets]
+    with PcsNode(cfgs, devices=[0, 1], flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1], device=0) as mem0, \
+            PcsContext(cfgs[:1], device=1) as mem1:
+        assert node.rccl_ranks == 2
+        cap = node.max_payload_shorts
+        per = n // 2
+        dev_sets = []
+        for d, c in sets:                       # cameras 0..per-1 live on GPU 0, the rest on GPU 1
+            d0, c0 = _upload(mem0, d[:per], c[:per]); d1, c1 = _upload(mem1, d[per:], c[per:])
+            dev_sets.append((d0 + d1, c0 + c1))
+        vox = [mem0.device_malloc(cap * 2 + 64) for _ in range(2)]
+        if route == "partials":
+            tickets = [node.submit_voxel_device(*dev_sets[0], leaf, vox[0], cap)]
+            for k in range(1, frames + 1):
+                if k < frames:
+                    tickets.append(node.submit_voxel_device(*dev_sets[k], leaf, vox[k & 1], cap))
+                nv = node.wait_voxel(tickets[k - 1])
+                assert nv == want[k - 1].shape[0] and (_fetch(mem0, vox[(k - 1) & 1], nv) == want[k - 1]).all(), k - 1
+                st = node.last_stats()
+                assert st["exchanged_bytes"] > 0 and st["exchanged_bytes"] % 40 == 0
+        nv, stats = node.process_voxel_device(*dev_sets[1], leaf, vox[0], cap, VOXEL_PARTIALS if route == "partials" else VOXEL_PAYLOADS)
+        assert nv == want[1].shape[0] and (_fetch(mem0, vox[0], nv) == want[1]).all()
+        assert stats["exchanged_bytes"] > 0
+    if route == "partials":                     # the configuration's own size against the digest
+        W, H, N = 1920, 1080, 16
+        cfg5 = [S.synth_stream_config(W, H, s) for s in range(N)]
+        d5 = [S.synth_depth(W, H, s) for s in range(N)]; c5 = [S.synth_color(W, H, s) for s in range(N)]
+        gold = GOLD["voxel"]["50"]
+        with PcsNode(cfg5, devices=[0, 1], flags=FLAG_DROP_INVALID) as node:
+            got, stats = node.process_voxel(d5, c5, 50)
+            assert got.shape[0] == gold["voxels"] and hashlib.sha256(got.tobytes()).hexdigest() == gold["sha256"]
+
+
+@pytest.mark.gpu
+def test_two_physical_gpus_bench_config5_prints_a_line():
+    """`bench.py --gpus 2 --workload config5` on two real GPUs: the node route, 8 cameras per GPU, the digest checked by the script."""
+    _two_gpus_or_skip()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "config5", "--steps", "6", "--warmup", "2",
+                        "--preheat-ms", "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["check"]["golden"] is True and d["config"]["devices"] == [0, 1]
+    assert d["bytes_into_root_per_step"] > 0 and "virtual peers" not in d.get("debug", "")
+
+
 # ---- no GPU needed ------------------------------------------------------------------------------------------------------------
 def test_node_refuses_bad_arguments_without_a_device():
     from pointcloud_stitching_amd.node import PcsNode

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): the round's closing record on ONE build — GPU test-suite, randomised soaks, bench lines of every
 # route, rocprofv3 stats + PMC (tools/profile_gpu.sh). Everything lands in gpurun_out/final_<tag>/ ; copy what is kept to profiles/.
 #   tools/final_run.sh <tag> [soak_seconds=60]
-TAG=${1:-r05}; SOAK=${2:-60}
+TAG=${1:-r06}; SOAK=${2:-60}
 OUT=$PWD/gpurun_out/final_$TAG
 mkdir -p $OUT
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|^E " | tail -5 > $OUT/pytest.txt; cat $OUT/pytest.txt
@@ -32,6 +32,12 @@ for t in default cold lsd; do
   python tools/voxel_probe.py 20,32,36,40,50,100,200 60 | grep leaf
 done > $OUT/voxel_by_leaf.txt 2>&1
 unset PCS_VOXEL_TAIL PCS_VOXEL_REGIONS
+# BASELINE configs[4] as a frame loop: one context, two in turn (the tail of k beside the pre-aggregation of k+1), each with and without
+# the colour-row table; BASELINE configs[1]: one 720p stream per launch, both tile shapes, and the a2 twin's one-cloud call
+{ for c in 1 2; do python tools/voxel_overlap_probe.py $c 50 300; PCS_ROW_CONST=0 python tools/voxel_overlap_probe.py $c 50 300; done
+  python tools/voxel_overlap_probe.py 2 200 300
+  for t in 0 1; do PCS_SMALL_TILES=$t python tools/single_probe.py 1 5000; PCS_SMALL_TILES=$t python tools/single_probe.py 1 5000 twin; done
+} 2>&1 | grep -E "context|per launch" > $OUT/probes.txt; cat $OUT/probes.txt
 { PCS_VOXEL_TAIL=bucket python tools/lab/bkt_cliff.py; PCS_VOXEL_TAIL=bucket PCS_VOXEL_REGIONS=0 python tools/lab/bkt_cliff.py | sed 's/\[bucket\]/[bucket, cold chain]/'; PCS_VOXEL_TAIL=lsd python tools/lab/bkt_cliff.py; } > $OUT/bkt_cliff.txt 2>&1
 bash tools/profile_gpu.sh $TAG 200 > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log
 echo final_run done

@@ -8,7 +8,7 @@
 # Runs: the headline line (dense, --no-extra-legs so the average is over cold launches of ONE kernel), then one
 # run per other kernel family (bench.py --mode ...), the config-5 tail (tools/voxel_bench.py) and the config-5 workload
 # (bench.py --workload config5: partials + sort + segmented mean from caller-held partials).
-TAG=${1:-r03}
+TAG=${1:-r06}
 STEPS=${2:-200}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -33,10 +33,18 @@ RUNS[node_config5]="python $PWD/bench.py --workload config5 --gpus 8 --node-devi
 RUNS[voxel_one_call]="python $PWD/tools/voxel_probe.py 50 80"
 RUNS[voxel_one_call_cold]="env PCS_VOXEL_REGIONS=0 python $PWD/tools/voxel_probe.py 50 80"
 RUNS[voxel_one_call_lsd]="env PCS_VOXEL_TAIL=lsd python $PWD/tools/voxel_probe.py 50 80"
+# BASELINE configs[1]: ONE 1280x720 stream per launch over a cold ring (fused kernel; the a2 twin's one-cloud call), both tile shapes
+RUNS[single]="python $PWD/tools/single_probe.py 1 3000"
+RUNS[single_512]="env PCS_SMALL_TILES=1 python $PWD/tools/single_probe.py 1 3000"
+RUNS[twin_single]="python $PWD/tools/single_probe.py 1 3000 twin"
+# BASELINE configs[4] as a frame loop over two contexts used in turn (the tail of k beside the pre-aggregation of k+1); the same with
+# the colour row computed per pixel (PCS_ROW_CONST=0)
+RUNS[voxel_two_ctx]="python $PWD/tools/voxel_overlap_probe.py 2 50 80"
+RUNS[voxel_one_call_norowc]="env PCS_ROW_CONST=0 python $PWD/tools/voxel_probe.py 50 80"
 # every leg of the default line (incl. centre_transform, config5_one_gpu, color_1080p): one row per kernel of the library
 RUNS[all_legs]="python $PWD/bench.py --steps $STEPS --warmup 20 --no-cpu-baseline --no-host-api"
-ORDER=${PROFILE_RUNS:-"dense all_legs drop_invalid cutoff pack pack_batch batch batch_drop_invalid voxel voxel_one_call voxel_one_call_cold voxel_one_call_lsd config5 node_stitch node_config5"}
-PMC_ORDER=${PROFILE_PMC_RUNS:-"dense all_legs voxel_one_call voxel_one_call_cold voxel_one_call_lsd config5"}
+ORDER=${PROFILE_RUNS:-"dense all_legs single single_512 twin_single drop_invalid cutoff pack pack_batch batch batch_drop_invalid voxel voxel_one_call voxel_one_call_norowc voxel_one_call_cold voxel_one_call_lsd voxel_two_ctx config5 node_stitch node_config5"}
+PMC_ORDER=${PROFILE_PMC_RUNS:-"dense all_legs single voxel_one_call voxel_one_call_norowc voxel_one_call_cold voxel_one_call_lsd config5"}
 cd /tmp
 for R in $ORDER; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$R -- ${RUNS[$R]} > $OUT/stats_$R.log 2>&1
@@ -51,7 +59,7 @@ for R in $PMC_ORDER; do
 done
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  for R in dense voxel_one_call; do      # the headline kernel (HBM-bound) and the voxel pipeline (VALU-bound front end)
+  for R in dense voxel_one_call voxel_one_call_norowc; do      # the headline kernel (HBM-bound) and the voxel pipeline (VALU-bound front end), with and without the colour-row table
     timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${R}_$N -- ${RUNS[$R]} > $OUT/pmc_${R}_$N.log 2>&1
     echo "pmc $R $N rc=$?"
   done
