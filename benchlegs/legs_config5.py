@@ -93,7 +93,8 @@ def config5_one_gpu(g):
     # frame-set k — a latency chain that leaves the chip almost empty — runs beside the pre-aggregation of k+1. What libpcs_node does
     # for a one-peer node (pcs_node_submit_voxel_device / pcs_node_wait_voxel) and what a caller's own loop can do with two pcs_ctx.
     ctx5b = g.new_context(cfg5, flags=FLAG_DROP_INVALID, own_stream=True)
-    ctx5.set_stream(0)                                   # its own stream again: the two contexts must not share one
+    ctx5.set_stream(0)                                   # its own stream again: the two contexts must not share one ...
+    beside = ctx5b.use_stream_beside(ctx5)               # ... nor one hardware queue (streams are dealt onto a few queues round robin)
     vox5b = torch.empty(S5 * n5 * POINT_SHORTS, dtype=torch.int16, device=dev)
     nv5b = torch.zeros(1, dtype=torch.int32, device=dev)
     pair = ((ctx5, vox5, nv5), (ctx5b, vox5b, nv5b))
@@ -126,30 +127,35 @@ def config5_one_gpu(g):
     del vox5b
     ctx5.set_stream(g.stream.cuda_stream)
     res = {"workload": f"{S5} x {W5}x{H5} synthetic streams, PCS_FLAG_DROP_INVALID, voxel leaf {LEAF} mm",
-                              "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
-                              "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
-                              "pipeline_ms_per_frame_set": round(ms_b5, 4),
-                              "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
-                              "one_call": {"ms_per_frame_set": round(ms_o5, 4), "value": round(S5 * n5 / ms_o5 / 1e3, 1),
-                                           "voxels": nvox5_one, "oracle_digest_ok": bool(gold5 is not None),
-                                           "kernels_per_call": (2 if regions_default != "0" else 5) if bucket_default else 13,
-                                           "cold_chain_ms_per_frame_set": round(ms_o5_cold, 4),
-                                           "lsd_tail_ms_per_frame_set": round(ms_o5_lsd, 4),
-                                           "algorithmic_bytes": int(5 * S5 * n5 + 10 * nvox5_one),
-                                           "frac": round((5 * S5 * n5 + 10 * nvox5_one) / (ms_o5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "note": "pcs_process_frames_voxel_device: the same voxel cloud straight from the "
-                                                   "rasters; the stitched cloud is never written to HBM. Warm bucket tail: the "
-                                                   "pre-aggregation puts every partial into its bucket's region (the previous "
-                                                   "call's splitters), one reduce launch follows: 2 kernels per call. "
-                                                   "frame_loop_two_contexts_*: the same call on two contexts used in turn (host clock over 3 x 60 calls, best): the bucket tail of k "
-                                                               "runs beside the pre-aggregation of k+1; colour_row_from_table: CertRowConst certified for every stream. "
-                                                               "cold_chain_*: PCS_VOXEL_REGIONS=0, every call partitions (histogram, column "
-                                                   "scan, scatter, reduce: 5 kernels); lsd_tail_*: the round-4 tail (13 kernels) "
-                                                   "forced for the same call; the timed loop's cloud is hashed against the "
-                                                   "committed oracle digest"},
-                              "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
-                                      "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}
+           "points_in": S5 * n5, "points_kept": kept5, "voxels": nvox5,
+           "compaction_ms": round(ms_c5, 4), "voxel_grid_ms": round(ms_v5, 4),
+           "pipeline_ms_per_frame_set": round(ms_b5, 4),
+           "value": round(S5 * n5 / ms_b5 / 1e3, 1), "unit": "Mpoints/s in",
+           "one_call": {"ms_per_frame_set": round(ms_o5, 4), "value": round(S5 * n5 / ms_o5 / 1e3, 1),
+                        "voxels": nvox5_one, "oracle_digest_ok": bool(gold5 is not None),
+                        "kernels_per_call": (2 if regions_default != "0" else 5) if bucket_default else 13,
+                        "cold_chain_ms_per_frame_set": round(ms_o5_cold, 4),
+                        "lsd_tail_ms_per_frame_set": round(ms_o5_lsd, 4),
+                        "frame_loop_two_contexts_ms_per_frame_set": round(ms_pair, 4),
+                        "frame_loop_two_contexts_digest_ok": bool(pair_ok),
+                        "frame_loop_frac": round((5 * S5 * n5 + 10 * nvox5_one) / (ms_pair * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "frame_loop_streams_seen_to_overlap": bool(beside),
+                        "colour_row_from_table": bool(row_const),
+                        "algorithmic_bytes": int(5 * S5 * n5 + 10 * nvox5_one),
+                        "frac": round((5 * S5 * n5 + 10 * nvox5_one) / (ms_o5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "pcs_process_frames_voxel_device: the same voxel cloud straight from the "
+                                "rasters; the stitched cloud is never written to HBM. Warm bucket tail: the "
+                                "pre-aggregation puts every partial into its bucket's region (the previous "
+                                "call's splitters), one reduce launch follows: 2 kernels per call. "
+                                "frame_loop_two_contexts_*: the same call on two contexts used in turn (host clock over 3 x 60 calls, best): the bucket tail of k "
+                                "runs beside the pre-aggregation of k+1; colour_row_from_table: CertRowConst certified for every stream. "
+                                "cold_chain_*: PCS_VOXEL_REGIONS=0, every call partitions (histogram, column "
+                                "scan, scatter, reduce: 5 kernels); lsd_tail_*: the round-4 tail (13 kernels) "
+                                "forced for the same call; the timed loop's cloud is hashed against the "
+                                "committed oracle digest"},
+           "compaction_frac_of_hbm_peak": round(S5 * n5 * (5 + 10 * kept5 / (S5 * n5)) / (ms_c5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "note": "BASELINE.json configs[4] without the 2-per-GPU sharding: compaction + stitch + voxel grid "
+                   "as two asynchronous device calls (pcs_process_frames_device, pcs_voxel_grid_device_counted)"}
     ctx5.close()
     del dep5, col5, sets5, pay5, vox5
     return res

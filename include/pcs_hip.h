@@ -394,6 +394,15 @@ int pcs_voxel_grid_from_partials_device(pcs_ctx* ctx, const uint64_t* d_keys, co
 /* ---- stream / timing plumbing ----------------------------------------------------------- */
 int   pcs_set_stream(pcs_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL = own stream) */
 void* pcs_get_stream(pcs_ctx* ctx);
+/* Two contexts of one device used IN TURN overlap — the tail of one call beside the head of the next (BASELINE configs[4]: the voxel
+ * pipeline's bucket tail beside the next frame-set's pre-aggregation, 0.169 -> 0.153 ms per 16 x 1080p frame-set) — only if their streams
+ * sit on different hardware queues; the runtime deals streams onto a few queues round robin, so that is luck. pcs_use_stream_beside
+ * replaces ctx's OWN stream by one that is SEEN to run beside other's current stream (a no-op must finish while a 300 us spin occupies
+ * the other; up to six candidates; ~2 ms, once). Returns 1 when such a stream was found and taken, 0 when none was (ctx keeps its
+ * stream), a negative status on error. pcs_pick_concurrent_stream is the same probe on raw hipStream_t handles of the CURRENT device
+ * (*out_stream = NULL when none overlapped; the caller owns the stream it gets). libpcs_node uses both.                              */
+int   pcs_use_stream_beside(pcs_ctx* ctx, pcs_ctx* other);
+int   pcs_pick_concurrent_stream(void* busy_hip_stream, void** out_stream);
 int   pcs_synchronize(pcs_ctx* ctx);
 /* hipEvent bracket on the context stream: begin; enqueue work; end; elapsed = GPU ms between them. */
 int   pcs_timer_begin(pcs_ctx* ctx);

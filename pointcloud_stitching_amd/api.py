@@ -360,6 +360,14 @@ class PcsContext:
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))
 
+    def use_stream_beside(self, other: "PcsContext") -> bool:
+        """Replace this context's own stream by one that is seen to run beside `other`'s (pcs_use_stream_beside): what two contexts
+        used in turn need to overlap. True when such a stream was found."""
+        rc = self._lib.pcs_use_stream_beside(self._h, other._h)
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
+
     def get_stream(self) -> int:
         return int(self._lib.pcs_get_stream(self._h) or 0)
 

@@ -1835,6 +1835,65 @@ int pcs_set_stream(pcs_ctx* c, void* hip_stream)
 
 void* pcs_get_stream(pcs_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
 
+// ---- a stream that really runs beside another one ---------------------------------------------------------------------------
+// The HIP runtime maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), round robin as they are created,
+// and two streams on one queue do not overlap at all: two contexts used in turn then run exactly as one. So a stream is not assumed
+// to be concurrent, it is SEEN to be: a no-op launched on the candidate must finish while a 300 us spin still occupies the other.
+namespace {
+__global__ void pcs_spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();                    // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void pcs_nop_kernel() {}
+}  // namespace
+
+int pcs_pick_concurrent_stream(void* busy_stream, void** out_stream)
+{
+    if (!out_stream) return PCS_ERR_INVALID_ARG;
+    *out_stream = nullptr;
+    hipStream_t busy = static_cast<hipStream_t>(busy_stream);
+    hipEvent_t spun = nullptr, done = nullptr;
+    if (hipEventCreateWithFlags(&spun, hipEventDisableTiming) != hipSuccess) return PCS_ERR_HIP;
+    if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(spun); return PCS_ERR_HIP; }
+    std::vector<hipStream_t> rejected;
+    hipStream_t found = nullptr;
+    for (int attempt = 0; attempt < 6 && !found; attempt++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        hipLaunchKernelGGL(pcs_spin_kernel, dim3(1), dim3(64), 0, busy, 30000ll);       // ~300 us
+        (void)hipEventRecord(spun, busy);
+        hipLaunchKernelGGL(pcs_nop_kernel, dim3(1), dim3(64), 0, cand);
+        (void)hipEventRecord(done, cand);
+        (void)hipEventSynchronize(done);
+        const bool beside = hipEventQuery(spun) == hipErrorNotReady;      // the spin was still going when the other stream finished
+        (void)hipEventSynchronize(spun);
+        (void)hipGetLastError();
+        if (beside) found = cand; else rejected.push_back(cand);           // (kept alive until the search ends: the next stream then takes another queue)
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipEventDestroy(spun); (void)hipEventDestroy(done);
+    *out_stream = found;
+    return PCS_OK;
+}
+
+int pcs_use_stream_beside(pcs_ctx* c, pcs_ctx* other)
+{
+    if (!c || !other || c == other) return PCS_ERR_INVALID_ARG;
+    if (c->device != other->device) return fail(c, PCS_ERR_INVALID_ARG, "the two contexts are on different devices (%d, %d)", c->device, other->device);
+    if (c->stream != c->own_stream) return fail(c, PCS_ERR_INVALID_ARG, "the context runs on an adopted stream (pcs_set_stream): its owner picks it");
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    void* found = nullptr;
+    const int rc = pcs_pick_concurrent_stream(other->stream, &found);
+    if (rc != PCS_OK) return fail(c, rc, "could not probe for a concurrent stream");
+    if (!found) return 0;                                   // none of six candidates overlapped: the context keeps its stream
+    (void)hipStreamDestroy(c->own_stream);
+    c->own_stream = static_cast<hipStream_t>(found);
+    c->stream = c->own_stream;
+    return 1;
+}
+
 int pcs_synchronize(pcs_ctx* c)
 {
     if (!c) return PCS_ERR_INVALID_ARG;

@@ -362,9 +362,8 @@ __device__ __forceinline__ float bc_tangential(float a, float kA, float kB, floa
 }
 
 // a5 for one pixel: depth value d, normalised ray (mx,my) from the LUTs.
-// (crow: the pixel's colour row under Mth::kRowConst — then p.v carries that INTEGER, 0 for an invalid pixel, instead of v)
 template <bool DDIST, bool CDIST, class Mth>
-__device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32_t d, float mx, float my, int crow = 0)
+__device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32_t d, float mx, float my)
 {
     const float z = __fmul_rn(P.depth_scale, (float)d);
     if (DDIST && P.ddist) {   // template gate compiles it in; the per-stream flag is wave-uniform
@@ -401,14 +400,34 @@ __device__ __forceinline__ PointIn deproject_pixel(const StreamParams& P, uint32
     // unconditionally and then selected: a conditional here becomes a divergent branch per pixel, which
     // stops the scheduler from interleaving the 8 pixels of a lane.
     const float qu = Mth::div_const(px, P.c_w_f, P.c_rw);
+    const float qv = Mth::div_const(py, P.c_h_f, P.c_rh);
     const bool valid = (z != 0.0f);
     p.u = valid ? qu : 0.0f;
-    if (Mth::kRowConst) {         // (y, py and everything behind them are dead code in this instantiation)
-        p.v = __int_as_float(valid ? crow : 0);
-    } else {
-        const float qv = Mth::div_const(py, P.c_h_f, P.c_rh);
-        p.v = valid ? qv : 0.0f;
-    }
+    p.v = valid ? qv : 0.0f;
+    return p;
+}
+
+// The same pixel under CertRowConst (R = I, t_y = t_z = 0, no distortion; see the policy): X, Y, Z and u as above, and in place of v the
+// pixel's colour ROW itself — `crow`, the table's entry for the raster row, 0 for an invalid pixel — carried in p.v as an INTEGER. A
+// function of its own, so that the instantiations every other kernel uses keep exactly the code they had (an if inside deproject_pixel
+// cost the distortion instantiation of the dense kernel 800 instructions: the two copies of its tail no longer merged).
+template <class Mth>
+__device__ __forceinline__ PointIn deproject_pixel_rowc(const StreamParams& P, uint32_t d, float mx, float my, int crow)
+{
+    const float z = __fmul_rn(P.depth_scale, (float)d);
+    PointIn p;
+    p.X = __fmul_rn(z, mx);
+    p.Y = __fmul_rn(z, my);
+    p.Z = z;
+    const float P0 = __fadd_rn(p.X, P.t[0]);
+    const float P2 = __fadd_rn(p.Z, P.t[2]);
+    float x, y_unused;
+    Mth::div2(P0, P0, P2, x, y_unused);                  // (the second quotient is dead code)
+    const float px = __fadd_rn(__fmul_rn(x, P.c_fx), P.c_ppx);
+    const float qu = Mth::div_const(px, P.c_w_f, P.c_rw);
+    const bool valid = (z != 0.0f);
+    p.u = valid ? qu : 0.0f;
+    p.v = __int_as_float(valid ? crow : 0);
     return p;
 }
 
@@ -504,7 +523,7 @@ struct DepthSource {
     // The fast path in two steps, for kernels that want to do something between requesting a lane's inputs and using them
     // (the single-pass compaction counts and publishes from the raw Z16 words first): fast() says whether it applies
     // (uniform over the launch's stream), fetch() issues the loads, deproject() consumes them.
-    struct Raw { uint4 dv; f32x4 ma, mb; float my; int crow; };
+    struct Raw { uint4 dv; f32x4 ma, mb; float my; };
     __device__ __forceinline__ bool fast(const StreamParams& P) const { return (P.W & 7) == 0 && ((uintptr_t)depth & 15) == 0; }
     __device__ __forceinline__ Raw fetch(const StreamParams& P, uint32_t i0) const
     {
@@ -518,7 +537,6 @@ struct DepthSource {
         q.ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
         q.mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
         q.my = as_global(P.my)[r];
-        q.crow = Mth::kRowConst ? __float_as_int(as_global(P.my)[(uint32_t)P.H + r]) : 0;       // the row table lies behind the H floats of my
         return q;
     }
     template <bool DD, bool CD>
@@ -529,7 +547,7 @@ struct DepthSource {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
-            p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], q.my, q.crow);
+            p[k] = deproject_pixel<DD, CD, Mth>(P, d, mxs[k], q.my);
         }
     }
 
@@ -544,8 +562,33 @@ struct DepthSource {
                 const uint32_t i = min(i0 + k, n - 1);
                 const uint32_t r = i / (uint32_t)P.W;
                 const uint32_t c = i - r * (uint32_t)P.W;
-                p[k] = deproject_pixel<DD, CD, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r],
-                                                    Mth::kRowConst ? __float_as_int(as_global(P.my)[(uint32_t)P.H + r]) : 0);
+                p[k] = deproject_pixel<DD, CD, Mth>(P, depth[i], as_global(P.mx)[c], as_global(P.my)[r]);
+            }
+        }
+    }
+
+    // CertRowConst: the colour row of raster row r lies behind the H floats of the my LUT (StreamParams::my)
+    __device__ __forceinline__ void load8_rowc(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8]) const
+    {
+        const gptr<float> lut_y = as_global(P.my);
+        if (fast(P)) {
+            const Raw q = fetch(P, i0);
+            const uint32_t r = P.w_magic ? (__umulhi(i0, P.w_magic) >> P.w_shift) : i0 / (uint32_t)P.W;
+            const int crow = __float_as_int(lut_y[(uint32_t)P.H + r]);
+            const uint32_t dw[4] = {q.dv.x, q.dv.y, q.dv.z, q.dv.w};
+            const float mxs[8] = {q.ma.x, q.ma.y, q.ma.z, q.ma.w, q.mb.x, q.mb.y, q.mb.z, q.mb.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+                p[k] = deproject_pixel_rowc<Mth>(P, d, mxs[k], q.my, crow);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t i = min(i0 + k, n - 1);
+                const uint32_t r = i / (uint32_t)P.W;
+                const uint32_t c = i - r * (uint32_t)P.W;
+                p[k] = deproject_pixel_rowc<Mth>(P, depth[i], as_global(P.mx)[c], lut_y[r], __float_as_int(lut_y[(uint32_t)P.H + r]));
             }
         }
     }
@@ -557,8 +600,12 @@ struct DepthSource {
             for (int k = 0; k < 8; k++) p[k] = PointIn{0, 0, 0, 0, 0};
             return;
         }
-        if ((DDIST || CDIST) && (P.ddist | P.cdist | P.tex_half)) load8_impl<DDIST, CDIST>(P, i0, n, p);
-        else load8_impl<false, false>(P, i0, n, p);
+        if constexpr (Mth::kRowConst) {
+            load8_rowc(P, i0, n, p);
+        } else {
+            if ((DDIST || CDIST) && (P.ddist | P.cdist | P.tex_half)) load8_impl<DDIST, CDIST>(P, i0, n, p);
+            else load8_impl<false, false>(P, i0, n, p);
+        }
     }
 };
 

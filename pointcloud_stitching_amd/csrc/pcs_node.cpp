@@ -192,38 +192,15 @@ int upload_rasters(pcs_node* n, const uint16_t* const* depth, const uint8_t* con
     return PCS_OK;
 }
 
-// ---- a stream that really runs beside another one -------------------------------------------------------------------------
-__global__ void pcs_node_spin_kernel(long long ticks)
-{
-    const long long t0 = wall_clock64();                    // 100 MHz
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-__global__ void pcs_node_nop_kernel() {}
-
-// Tries up to six new streams on the current device; *out = the first one on which a launch completes while a spin kernel still
-// occupies `busy` (the others are destroyed), or nullptr if none did (the caller then keeps what it has).
+// ---- a stream that really runs beside another one: pcs_pick_concurrent_stream / pcs_use_stream_beside (libpcs_hip) ---------------------
+// *out = a new stream of the current device on which a launch completes while a spin kernel still occupies `busy`, or nullptr if none of
+// six candidates did (the caller then keeps what it has).
 int pick_concurrent_stream(pcs_node* n, hipStream_t busy, hipStream_t* out)
 {
-    *out = nullptr;
-    hipEvent_t spun = nullptr, done = nullptr;
-    HIPCHK(n, hipEventCreateWithFlags(&spun, hipEventDisableTiming));
-    HIPCHK(n, hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    std::vector<hipStream_t> rejected;
-    for (int attempt = 0; attempt < 6 && !*out; attempt++) {
-        hipStream_t cand = nullptr;
-        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
-        hipLaunchKernelGGL(pcs_node_spin_kernel, dim3(1), dim3(64), 0, busy, 30000ll);       // ~300 us
-        (void)hipEventRecord(spun, busy);
-        hipLaunchKernelGGL(pcs_node_nop_kernel, dim3(1), dim3(64), 0, cand);
-        (void)hipEventRecord(done, cand);
-        (void)hipEventSynchronize(done);
-        const bool beside = hipEventQuery(spun) == hipErrorNotReady;      // the spin was still going when the other stream finished
-        (void)hipEventSynchronize(spun);
-        (void)hipGetLastError();
-        if (beside) *out = cand; else rejected.push_back(cand);            // (kept alive until the search ends: the next stream then takes another queue)
-    }
-    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-    (void)hipEventDestroy(spun); (void)hipEventDestroy(done);
+    void* found = nullptr;
+    const int rc = pcs_pick_concurrent_stream(busy, &found);
+    if (rc != PCS_OK) return nfail(n, rc, "could not probe for a concurrent stream");
+    *out = static_cast<hipStream_t>(found);
     return PCS_OK;
 }
 

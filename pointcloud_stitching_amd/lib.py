@@ -62,6 +62,8 @@ SYMBOLS = [
     ("pcs_set_stream", C.c_int, [_VP, _VP]),
     ("pcs_get_stream", _VP, [_VP]),
     ("pcs_synchronize", C.c_int, [_VP]),
+    ("pcs_use_stream_beside", C.c_int, [_VP, _VP]),
+    ("pcs_pick_concurrent_stream", C.c_int, [_VP, _P(_VP)]),
     ("pcs_timer_begin", C.c_int, [_VP]),
     ("pcs_timer_end", C.c_int, [_VP]),
     ("pcs_timer_elapsed_ms", C.c_int, [_VP, _P(C.c_float)]),

@@ -57,6 +57,9 @@ def test_bench_line_has_the_contract_keys():
     assert c5["points_in"] == 16 * 1920 * 1080 and 0.85 < c5["points_kept"] / c5["points_in"] < 0.95 and 0 < c5["voxels"] < c5["points_kept"]
     assert c5["pipeline_ms_per_frame_set"] > 0
     assert c5["one_call"]["voxels"] == c5["voxels"] and c5["one_call"]["ms_per_frame_set"] > 0
+    oc = c5["one_call"]           # the frame loop over two contexts: digest-checked, and not slower than one context queueing behind itself
+    assert oc["frame_loop_two_contexts_digest_ok"] is True and 0 < oc["frame_loop_two_contexts_ms_per_frame_set"] < 1.05 * oc["ms_per_frame_set"]
+    assert oc["colour_row_from_table"] is True
     assert comp["batched"]["frac"] > comp["frac"]
     assert comp["caller_counts"]["frac"] > 0.2 and comp["path"].startswith("three")
     assert d["pack_twin"]["per_stream_launches_frac"] > 0.4          # round 3: the arrays are read straight into registers
@@ -286,7 +289,7 @@ def test_route_choice_never_depends_on_how_the_script_was_launched():
 
 
 def test_readme_quotes_only_the_recorded_bench_line():
-    """README.md's results table is generated from ONE recorded `python bench.py` line (profiles/r05_bench.json) by
+    """README.md's results table is generated from ONE recorded `python bench.py` line (profiles/r06_bench.json) by
     tools/readme_results.py; regenerating it must give the text README holds, and no other 'Mpoints/s' figure may stand in
     README outside that block (round 4 had four different GPU/CPU ratios in four documents)."""
     import importlib.util
@@ -294,7 +297,7 @@ def test_readme_quotes_only_the_recorded_bench_line():
     spec = importlib.util.spec_from_file_location("readme_results", os.path.join(ROOT, "tools", "readme_results.py"))
     rr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rr)
-    src = os.path.join("profiles", "r05_bench.json")
+    src = os.path.join("profiles", "r06_bench.json")
     want = rr.table(rr.load(os.path.join(ROOT, src)), src)
     readme = open(os.path.join(ROOT, "README.md")).read()
     a, b = readme.index(rr.BEGIN), readme.index(rr.END) + len(rr.END)
@@ -304,6 +307,8 @@ def test_readme_quotes_only_the_recorded_bench_line():
     assert not re.search(r"GPU\s*=\s*\d+", outside)
     d = rr.load(os.path.join(ROOT, src))
     assert d["n_gpus"] == 1 and "configs[2]" in d["config"]["workload"] and "leg_errors" not in d
+    # the block carries the parity sentence of the line itself: bit-exact against this build's own restatement, unpinned
+    assert "unpinned" in d["parity"] and ("Parity: " + d["parity"]) in readme[a:b]
 
 
 def test_the_line_is_the_last_line_on_stdout_even_after_c_level_prints():

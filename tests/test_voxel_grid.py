@@ -763,3 +763,34 @@ def test_colour_row_certificate_and_the_reader_that_uses_it(oracle, monkeypatch)
         c.color.ppy = c.depth.ppy + 0.5          # py = r + 0.5 -> fma(v, H, 0.5) lands on integers: the row flips with the rounding of (z * my) / z
     decided = check(cfgs, FLAG_DROP_INVALID, None)
     assert decided == [False] * n, "a boundary configuration was certified row-constant"
+
+
+@pytest.mark.gpu
+def test_two_contexts_in_turn_on_streams_seen_to_overlap(oracle):
+    """pcs_use_stream_beside: the second context of a pair used in turn takes a stream that is SEEN to run beside the first one's (streams
+    are dealt onto a few hardware queues round robin; two on one queue do not overlap). Bytes are untouched — every call of the loop, on
+    either context, equals the oracle; the refusals: the same context twice, a context on an adopted stream."""
+    cfgs, depth, color = S.synth_frame_set(4, 640, 480)
+    stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID)
+    want = oracle.voxel_grid(stitched, 50)
+    n_max = sum(c.n_points for c in cfgs)
+    with PcsContext(cfgs, flags=FLAG_DROP_INVALID) as a, PcsContext(cfgs, flags=FLAG_DROP_INVALID) as b:
+        found = b.use_stream_beside(a)
+        assert found in (True, False)                         # (True on every box seen so far; False keeps the context's stream and is not an error)
+        assert b.get_stream() != a.get_stream()
+        dd, dc = _upload_rasters(a, depth, color)
+        outs = [(c, c.device_malloc(n_max * 10 + 64), c.device_malloc(64)) for c in (a, b)]
+        for k in range(8):                                    # calls in turn, nothing synchronised in between
+            c, d_vox, d_nv = outs[k & 1]
+            c.process_frames_voxel_device(dd, dc, 50, d_vox, n_max * 5, d_nv)
+        for c, d_vox, d_nv in outs:
+            c.synchronize()
+            nv = np.empty(1, np.int32); c.memcpy_d2h(nv, d_nv)
+            got = np.empty(max(int(nv[0]), 1) * 5, np.int16); c.memcpy_d2h(got, d_vox)
+            assert int(nv[0]) == want.shape[0] and (got[:want.size].reshape(-1, 5) == want).all()
+        with pytest.raises(PcsError):
+            a.use_stream_beside(a)
+        a.set_stream(b.get_stream())                          # adopted: its owner picks the stream
+        with pytest.raises(PcsError):
+            a.use_stream_beside(b)
+        a.set_stream(0)

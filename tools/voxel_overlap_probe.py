@@ -22,7 +22,9 @@ S, W, H = 16, 1920, 1080
 gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config5_digests.json")))["voxel"].get(str(leaf))
 dev = torch.device("cuda", 0)
 cfgs = [Syn.synth_stream_config(W, H, s) for s in range(S)]
-ctxs = [PcsContext(cfgs, flags=4) for _ in range(NC)]          # own non-blocking streams
+ctxs = [PcsContext(cfgs, flags=4) for _ in range(NC)]          # own non-blocking streams ...
+for c in ctxs[1:]:
+    c.use_stream_beside(ctxs[0])                               # ... on different hardware queues
 n = W * H
 dep0 = [torch.from_numpy(Syn.synth_depth(W, H, s).reshape(-1).view(np.uint8)).to(dev) for s in range(S)]
 col0 = [torch.from_numpy(Syn.synth_color(W, H, s)).to(dev) for s in range(S)]
