@@ -227,8 +227,10 @@ def run_node(args):
     if config5:
         cfg_name = "BASELINE.json configs[4]" if (total_streams, W, H, S) == (16, 1920, 1080, 2) else f"configs[4]'s pipeline, {S} cameras per GPU"
         metric = "Mpoints/s in (16x1920x1080 streams: deproject+transform+RGB+pack, invalid-depth compaction, voxel grid of the stitched cloud)"
+        how = ("every peer pre-aggregates into a voxel sink of the one GPU they share (nothing to exchange), one tail per frame-set"
+               if node.voxel_sink else "per-GPU voxel partials, one grouped exchange, one sort + segmented mean")
         workload = (f"{cfg_name}: {total_streams} synthetic {W}x{H} Z16+RGB8 streams on {where}, PCS_FLAG_DROP_INVALID, voxel-grid downsample "
-                    f"(leaf {LEAF} mm) of the stitched cloud on GPU 0: per-GPU voxel partials, one grouped exchange, one sort + segmented mean")
+                    f"(leaf {LEAF} mm) of the stitched cloud on GPU 0: {how}")
     else:
         cfg_name = ("BASELINE.json configs[2]" if P == 1 and total_streams == 8 else
                     "BASELINE.json configs[3]" if (S == 1 and total_streams == 8) else f"{total_streams} streams sharded {S}/GPU")
@@ -271,6 +273,35 @@ def run_node(args):
     if config5:
         out["partials_reduced_per_step"] = int(reduced)
         out["config"]["leaf_mm"] = LEAF
+        out["voxel_sink"] = bool(node.voxel_sink)
+        if node.voxel_sink:
+            # every peer shares GPU 0: the line above went through the sinks (no exchange). Beside it the route such a node exists to
+            # exercise — partials to caller-held arrays, ONE grouped RCCL exchange (self send/recv), place + tail on the root's second context
+            node.set_timing(False)
+            node.set_voxel_sink(False)
+            try:
+                run(max(args.warmup, 4)); sync_all()
+                t1 = time.perf_counter(); run(args.steps); sync_all()
+                x_ms = (time.perf_counter() - t1) * 1e3 / args.steps
+                node.set_timing(True)
+                xph = {"kernel": [], "exchange": [], "root": []}
+                t = submit()
+                for _ in range(10):
+                    t2 = submit(); wait(t); t = t2
+                    st = node.last_stats()
+                    xph["kernel"].append(st["kernels_ms"]); xph["exchange"].append(st["exchange_ms"]); xph["root"].append(st["root_ms"])
+                wait(t)
+                node.set_timing(False)
+                out["same_gpu_peers"] = {
+                    "route": "voxel sink (pcs_voxel_sink_*): the peers' pre-aggregations write into the workspace of a sink context of the GPU "
+                             "they share, two sinks in turn; no exchange, no placement",
+                    "partials_exchange": {"ms_per_step": round(x_ms, 5), "bytes_into_root_per_step": int(st["exchanged_bytes"]),
+                                          "partials_reduced_per_step": int(st["reduced"]),
+                                          "phases_ms": {k: round(float(np.median(v)), 5) for k, v in xph.items()},
+                                          "note": "PCS_NODE_VOXEL_SINK=0: the route of peers on different GPUs, here on RCCL self send/recv"}}
+            finally:
+                node.set_timing(False)
+                node.set_voxel_sink(True)
         if P == 1 and os.environ.get("PCS_NODE_ONE_CALL", "2") == "2":
             # one peer: submit enqueued the rasters -> voxels call (no partials leave the library), the two slots on two contexts in
             # turn. Beside it, the same loop on ONE context (frame-sets queue behind each other) and with the partials pipeline a node
@@ -324,7 +355,9 @@ def run_node(args):
             out["direct_store"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if virtual:
         out["debug"] = ("virtual peers: device ids repeat, the peers of one GPU share it and their transfers are RCCL self send/recv "
-                        "pairs. Exercises the N > 1 flow; says nothing about scaling")
+                        "pairs" + (" (config5: none by default — they pre-aggregate into a sink of that GPU; same_gpu_peers.partials_exchange "
+                                   "is the exchange route)" if config5 and out.get("voxel_sink") else "")
+                        + ". Exercises the N > 1 flow; says nothing about scaling")
     if note:
         out["note"] = note
     if node_error:

@@ -391,6 +391,33 @@ int pcs_voxel_grid_from_partials_device(pcs_ctx* ctx, const uint64_t* d_keys, co
                                         int n_partials, const int32_t* d_n_partials, int leaf_mm, int16_t* d_out,
                                         size_t out_shorts, int32_t* d_out_points);
 
+/* ---- voxel SINK: several contexts of ONE device pre-aggregate into one context's workspace ------------------------------ *
+ * pcs_process_frames_voxel_device in three steps, the middle one callable on OTHER contexts of the same device: the partials of
+ * every such context land where the sink context's own would — in its buckets' regions on a warm call — so nothing is exchanged,
+ * concatenated or placed, and the tail is the one launch of a warm call. libpcs_node takes this route for peers that share the
+ * root's GPU (a device id that repeats); peers on OTHER GPUs exchange partials (above): the pre-aggregation's atomics are
+ * device-scope and a sink refuses a context of another device.
+ *   pcs_voxel_sink_begin   on the sink context's stream: workspace for `capacity_points` (the sum of every participating context's
+ *                          pixels), control blocks; fills *sink (opaque; valid until the finish). One sink per context at a time — a
+ *                          second begin abandons the first.
+ *   pcs_process_frames_voxel_into_sink_device   on ctx's stream: ctx's rasters under ctx's flags (CUTOFF / DROP_INVALID / downsample,
+ *                          as pcs_process_frames_voxel_partials_device) into the sink. The CALLER orders the streams: this launch behind
+ *                          the begin (when sink->work_enqueued) and behind the sink's previous finish, the finish behind every such
+ *                          launch — events, as libpcs_node does (csrc/pcs_node.cpp: enqueue_sink_ticket).
+ *   pcs_voxel_sink_finish  on the sink context's stream: the tail; bytes, *d_out_points and the -1 convention exactly as
+ *                          pcs_process_frames_voxel_device over the union of the participating rasters. d_out needs room for
+ *                          capacity_points points.                                                                                  */
+typedef struct pcs_voxel_sink {
+    uint64_t opaque[23];
+    uint32_t work_enqueued;   /* begin put work on the sink's stream (the clear of a workspace's control blocks: its first call, or after a
+                                 call that failed half-way) that the pre-aggregations must run behind; 0: nothing to order against the begin */
+    uint32_t reserved;
+} pcs_voxel_sink;
+int pcs_voxel_sink_begin(pcs_ctx* sink_ctx, size_t capacity_points, int leaf_mm, pcs_voxel_sink* sink);
+int pcs_process_frames_voxel_into_sink_device(pcs_ctx* ctx, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                              const pcs_voxel_sink* sink);
+int pcs_voxel_sink_finish(pcs_ctx* sink_ctx, const pcs_voxel_sink* sink, int16_t* d_out, size_t out_shorts, int32_t* d_out_points);
+
 /* ---- stream / timing plumbing ----------------------------------------------------------- */
 int   pcs_set_stream(pcs_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL = own stream) */
 void* pcs_get_stream(pcs_ctx* ctx);

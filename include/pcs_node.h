@@ -180,6 +180,19 @@ int  pcs_node_submit_voxel_device(pcs_node* node, const uint16_t* const* d_depth
                                   int16_t* d_voxels_root, size_t voxels_shorts, int* ticket);
 int  pcs_node_wait_voxel(pcs_node* node, int ticket, int* n_voxels);
 int  pcs_node_set_one_call(pcs_node* node, int mode);
+/* Several peers that ALL share one GPU (a device id that repeats throughout — the development boxes' way to run the N > 1 flow, or more
+ * cameras than one context is configured for): nothing needs to travel, so by default a voxel ticket of such a node goes through a
+ * SINK (include/pcs_hip.h: pcs_voxel_sink_*): every peer's pre-aggregation, on the peer's own context and stream, writes its partials
+ * straight into the workspace of a sink context of that GPU — its buckets' regions on a warm call — and the one-launch tail follows on
+ * the sink's stream behind all of them; two sinks used in turn (slot 0 / 1) let the tail of frame-set k run beside the pre-aggregations
+ * of k+1. No exchange, no concatenation, no placement: 16 x 1080p at 50 mm, 8 peers of one GPU, 0.40 -> 0.23 ms per frame-set (the peers
+ * dealt onto PCS_NODE_SINK_STREAMS = 2 kernel streams: 1 -> 0.26, 8 -> 0.24 ms, where the host thread pays an event per peer). Stats
+ * read as a one-call ticket's (exchanged_bytes = 0, partials = 0). Peers on DIFFERENT GPUs always exchange partials (the pre-aggregation's
+ * atomics are device-scope). pcs_node_set_voxel_sink(node, 0) with nothing in flight, or PCS_NODE_VOXEL_SINK=0 in the environment when the
+ * node is created, keeps the partials exchange (RCCL self send/recv) on such a node — the route it exists to exercise; the tests run both.
+ * pcs_node_voxel_sink: 1 when the next voxel ticket takes the sink.                                                                       */
+int  pcs_node_set_voxel_sink(pcs_node* node, int on);
+int  pcs_node_voxel_sink(const pcs_node* node);
 /* A voxel frame-set whose bucket tail ended flagged (device count -1: include/pcs_hip.h, pcs_voxel_grid_device) is run again by
  * the wait that finds it, on the LSD tail, which is then latched for that context; *n_voxels is never negative, and PCS_ERR_HIP is
  * returned if the second run is flagged too. For that the rasters handed to pcs_node_submit_voxel_device stay the caller's to

@@ -356,6 +356,26 @@ class PcsContext:
                                                                   d_n_partials or None, int(leaf_mm), d_out, out_shorts,
                                                                   d_out_points or None))
 
+    # -- voxel sink: several contexts of one device pre-aggregate into this context's workspace (pcs_voxel_sink_*) -----------------
+    def voxel_sink_begin(self, capacity_points: int, leaf_mm: int):
+        """Open a sink on this context's stream for `capacity_points` pixels in all; returns the opaque sink (a ctypes buffer) the
+        other two calls take. The caller orders the streams (pcs_hip.h)."""
+        sink = (C.c_uint64 * 24)()
+        self._check(self._lib.pcs_voxel_sink_begin(self._h, int(capacity_points), int(leaf_mm), C.addressof(sink)))
+        return sink
+
+    def process_frames_voxel_into_sink_device(self, d_depth: Sequence[int], d_color: Sequence[int], sink) -> None:
+        """This context's rasters under its flags -> partials in the sink's workspace, on this context's stream."""
+        if len(d_depth) != self.n_streams or len(d_color) != self.n_streams:
+            raise ValueError("need one depth and one colour pointer per stream")
+        dp = (C.c_void_p * self.n_streams)(*d_depth)
+        cp = (C.c_void_p * self.n_streams)(*d_color)
+        self._check(self._lib.pcs_process_frames_voxel_into_sink_device(self._h, dp, cp, C.addressof(sink)))
+
+    def voxel_sink_finish(self, sink, d_out: int, out_shorts: int, d_out_points: int = 0) -> None:
+        """The tail over everything the sink received, on this context's stream (pcs_voxel_sink_finish)."""
+        self._check(self._lib.pcs_voxel_sink_finish(self._h, C.addressof(sink), d_out, out_shorts, d_out_points or None))
+
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pcs_set_stream(self._h, hip_stream or None))

@@ -84,6 +84,7 @@ struct pcs_ctx {
     float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
     void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
     VoxelWsState                    vox_state;          // which control block of s_voxel_ws the next voxel call uses
+    bool                            sink_open = false;  // pcs_voxel_sink_begin without its pcs_voxel_sink_finish yet
     int                             voxel_reruns = 0;   // calls that ended flagged (-1) and latched the LSD tail (pcs_voxel_tail_reruns)
     int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
     int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
@@ -1698,6 +1699,45 @@ try {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_device: host allocation failed (%s)", ex.what());
 }
 
+// The pre-aggregation of this context's streams under its flags into `vs`: a caller's arrays (exchange format), or the workspace of a
+// context of this device — its own, or another one's (a voxel sink, below). Fused from the rasters where that is the faster route
+// (as pcs_process_frames_voxel_device decides), else through this context's own stitched cloud.
+static int run_voxel_frontend(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm, const VoxelStage& vs)
+{
+    const int S = c->n_streams;
+    const size_t cap = c->max_payload_points;
+    static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
+    bool all_patch = true;
+    for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
+    const bool fused = fused_env >= 0 ? fused_env != 0 : (all_patch || leaf_mm >= 36);      // as pcs_process_frames_voxel_device
+    if (c->downsample != 1 || !fused) {
+        // the stride is defined on the ORDER of the kept points: build this GPU's stitched cloud, pre-aggregate that
+        int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
+        if (rc) return rc;
+        rc = run_fused_device(c, d_depth, d_color, c->s_payload, cap * PCS_POINT_SHORTS, c->d_counts, true);
+        if (rc) return rc;
+        if (cap) HIPCHK(c, launch_payload_voxel_partials(c->s_payload, (uint32_t)cap, c->d_counts + S, vs, c->stream));
+        return PCS_OK;
+    }
+    for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
+        const int nl = std::min(kLaunchStreams, S - s0);
+        FramePtrs fp{};
+        uint32_t mp = 0, mw = 0, mh = 0;
+        bool fast = true, ident = true, rowc = true, patch_ok = true;
+        for (int k = 0; k < nl; k++) {
+            const StreamParams& q = c->h_params[s0 + k];
+            fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
+            mp = std::max(mp, q.n_points);
+            mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
+            patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
+            fast &= q.cert_fast != 0; ident &= q.ident_r != 0; rowc &= q.ident_r == 2;
+        }
+        const MathSel sel = !fast ? MathSel::Ieee : (ident ? (rowc ? MathSel::CertRowConst : MathSel::CertIdentR) : MathSel::Cert);
+        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
+    }
+    return PCS_OK;
+}
+
 // ---- voxel partials (exchange format of the multi-GPU voxel grid) ------------------------------------
 int pcs_process_frames_voxel_partials_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
                                              int leaf_mm, uint64_t* d_keys, pcs_voxel_partial* d_partials, size_t capacity,
@@ -1723,35 +1763,8 @@ try {
     VoxelStage vs{};
     HIPCHK(c, voxel_partials_stage(leaf_mm, reinterpret_cast<unsigned long long*>(d_keys), d_partials,
                                    reinterpret_cast<unsigned int*>(d_n_partials), &vs, c->stream));
-    static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
-    bool all_patch = true;
-    for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
-    const bool fused = fused_env >= 0 ? fused_env != 0 : (all_patch || leaf_mm >= 36);      // as pcs_process_frames_voxel_device
-    if (c->downsample != 1 || !fused) {
-        // the stride is defined on the ORDER of the kept points: build this GPU's stitched cloud, pre-aggregate that
-        int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
-        if (rc) return rc;
-        rc = run_fused_device(c, d_depth, d_color, c->s_payload, cap * PCS_POINT_SHORTS, c->d_counts, true);
-        if (rc) return rc;
-        if (cap) HIPCHK(c, launch_payload_voxel_partials(c->s_payload, (uint32_t)cap, c->d_counts + S, vs, c->stream));
-    } else {
-        for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
-            const int nl = std::min(kLaunchStreams, S - s0);
-            FramePtrs fp{};
-            uint32_t mp = 0, mw = 0, mh = 0;
-            bool fast = true, ident = true, rowc = true, patch_ok = true;
-            for (int k = 0; k < nl; k++) {
-                const StreamParams& q = c->h_params[s0 + k];
-                fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
-                mp = std::max(mp, q.n_points);
-                mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
-                patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
-                fast &= q.cert_fast != 0; ident &= q.ident_r != 0; rowc &= q.ident_r == 2;
-            }
-            const MathSel sel = !fast ? MathSel::Ieee : (ident ? (rowc ? MathSel::CertRowConst : MathSel::CertIdentR) : MathSel::Cert);
-            HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
-        }
-    }
+    const int rc = run_voxel_frontend(c, d_depth, d_color, leaf_mm, vs);
+    if (rc) return rc;
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_partials_device: host allocation failed (%s)", ex.what());
@@ -1785,6 +1798,87 @@ try {
     return PCS_OK;
 } catch (const std::exception& ex) {
     return fail(c, PCS_ERR_NOMEM, "pcs_voxel_grid_from_partials_device: host allocation failed (%s)", ex.what());
+}
+
+// ---- voxel SINK: one context's workspace filled by the pre-aggregations of several contexts of the same device ---------
+namespace {
+struct SinkBlob {
+    VoxelStage vs;
+    uint32_t   capacity;
+    int32_t    leaf, device;
+    uint32_t   magic;
+};
+static_assert(sizeof(SinkBlob) <= sizeof(((pcs_voxel_sink*)nullptr)->opaque), "pcs_voxel_sink (include/pcs_hip.h) must hold a VoxelStage");
+constexpr uint32_t kSinkMagic = 0x50435356u;      // "PCSV"
+}  // namespace
+
+int pcs_voxel_sink_begin(pcs_ctx* c, size_t capacity_points, int leaf_mm, pcs_voxel_sink* sink)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!sink) return fail(c, PCS_ERR_INVALID_ARG, "sink is NULL");
+    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
+    if (capacity_points < 1 || capacity_points > 0xFFFFFFF0ull)
+        return fail(c, PCS_ERR_INVALID_ARG, "capacity_points %zu outside 1..2^32-16", capacity_points);
+    // (a sink that was opened and never finished — a pre-aggregation failed in between — is abandoned here: voxel_begin left the
+    // workspace marked unclean, so this call clears its control blocks again)
+    DeviceGuard guard(c->device);
+    const uint32_t cap = (uint32_t)capacity_points;
+    const size_t need = voxel_workspace_bytes(cap, voxel_workspace_level(cap, leaf_mm, c->vox_state, false));
+    const int rc = ensure_voxel_ws(c, need);
+    if (rc) return rc;
+    SinkBlob b{};
+    // (voxel_begin clears the control blocks of a workspace it has not seen, or whose last call was not enqueued completely, with a
+    // memset on this stream: the only work a begin ever enqueues)
+    const bool clears = !c->vox_state.clean || c->vox_state.base != c->s_voxel_ws;
+    HIPCHK(c, voxel_begin(cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, &b.vs, c->stream));
+    b.capacity = cap; b.leaf = leaf_mm; b.device = c->device; b.magic = kSinkMagic;
+    std::memset(sink, 0, sizeof *sink);
+    std::memcpy(sink->opaque, &b, sizeof b);
+    sink->work_enqueued = clears ? 1u : 0u;
+    c->sink_open = true;
+    return PCS_OK;
+}
+
+int pcs_process_frames_voxel_into_sink_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
+                                              const pcs_voxel_sink* sink)
+try {
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!d_depth || !d_color || !sink) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    SinkBlob b;
+    std::memcpy(&b, sink->opaque, sizeof b);
+    if (b.magic != kSinkMagic) return fail(c, PCS_ERR_INVALID_ARG, "not a sink pcs_voxel_sink_begin filled");
+    if (b.device != c->device)
+        return fail(c, PCS_ERR_INVALID_ARG, "the sink lives on device %d, this context on device %d: a sink takes contexts of its own device only "
+                    "(the pre-aggregation's atomics are device-scope; other GPUs exchange partials)", b.device, c->device);
+    const int S = c->n_streams;
+    for (int s = 0; s < S; s++) {
+        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
+        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
+    }
+    if (c->max_payload_points > b.capacity)
+        return fail(c, PCS_ERR_CAPACITY, "the sink was opened for %u points; this context alone can produce %zu", b.capacity, c->max_payload_points);
+    DeviceGuard guard(c->device);
+    return run_voxel_frontend(c, d_depth, d_color, b.leaf, b.vs);
+} catch (const std::exception& ex) {
+    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_into_sink_device: host allocation failed (%s)", ex.what());
+}
+
+int pcs_voxel_sink_finish(pcs_ctx* c, const pcs_voxel_sink* sink, int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
+{
+    if (!c) return PCS_ERR_INVALID_ARG;
+    if (!sink || !d_out) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
+    if ((uintptr_t)d_out_points & 3u) return fail(c, PCS_ERR_INVALID_ARG, "d_out_points must be 4-byte aligned");
+    SinkBlob b;
+    std::memcpy(&b, sink->opaque, sizeof b);
+    if (b.magic != kSinkMagic || !c->sink_open || b.device != c->device)
+        return fail(c, PCS_ERR_INVALID_ARG, "not the sink this context has open");
+    if (out_shorts < (size_t)b.capacity * PCS_POINT_SHORTS)
+        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every point its own voxel) needs %zu",
+                    out_shorts, (size_t)b.capacity * PCS_POINT_SHORTS);
+    DeviceGuard guard(c->device);
+    c->sink_open = false;
+    HIPCHK(c, voxel_finish(b.capacity, b.leaf, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
+    return PCS_OK;
 }
 
 int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,

@@ -63,7 +63,9 @@ struct Ticket {
     int16_t* d_voxels = nullptr;
     size_t voxels_shorts = 0;
     pcs_ctx* vox_ctx = nullptr;           // one-call voxel ticket: the context it was enqueued on
-    std::vector<const uint16_t*> d_depth; // one-call voxel ticket: the rasters, should the call have to be run again (flagged bucket tail)
+    bool sink = false;                    // voxel ticket of several peers on ONE GPU: every peer pre-aggregated into the slot's sink (no exchange)
+    pcs_voxel_sink sk{};
+    std::vector<const uint16_t*> d_depth; // one-call / sink voxel ticket: the rasters, should the call have to be run again (flagged bucket tail)
     std::vector<const uint8_t*> d_color;
     int64_t exchanged_bytes = 0;          // moved by the grouped RCCL exchange
     int64_t direct_bytes = 0;             // stored into the root's buffer by the peers' own kernels (PCS_NODE_DIRECT_STORE)
@@ -103,6 +105,17 @@ struct pcs_node {
                                           // 2 on two contexts used in turn (PCS_NODE_ONE_CALL, latched at create; pcs_node_set_one_call)
     pcs_ctx* alt_ctx = nullptr;           // one-call tickets of slot 1: a second context of the peer (own stream, workspace, splitters, regions),
     hipStream_t alt_stream = nullptr;     // so that the bucket tail of frame-set k runs beside the pre-aggregation of k+1
+    // Several peers on ONE GPU (a device id that repeats throughout): nothing needs to travel — every peer's pre-aggregation writes into
+    // the workspace of a SINK context of that GPU (pcs_voxel_sink_*: its buckets' regions on a warm call), whose tail follows on the sink's
+    // own stream. Two sinks used in turn (slot 0 / 1), each with its stream, workspace, splitters and regions, as the one-peer node's two
+    // contexts: the tail of frame-set k runs beside the pre-aggregations of k+1. PCS_NODE_VOXEL_SINK=0 at create / pcs_node_set_voxel_sink
+    // keep the partials exchange (RCCL self send/recv), which is what such a node exists to exercise.
+    int vox_sink = 1;
+    int sink_streams = 0;                 // kernel streams the peers' pre-aggregations are dealt onto (peer r: stream r % sink_streams); 0: not yet
+    bool sink_shared = false;             // peers >= sink_streams currently run on an earlier peer's stream
+    pcs_ctx* sink_ctx[2] = {nullptr, nullptr};
+    hipStream_t sink_stream[2] = {nullptr, nullptr};
+    hipEvent_t sink_open[2] = {nullptr, nullptr};   // sink stream: the sink of this slot is open (its control blocks are clear)
     size_t vcap_total = 0;
     // root: a second context of libpcs_hip (own stream, own sort workspace) that runs the sort + segmented mean of frame-set k
     // while the root's kernel stream pre-aggregates frame-set k+1: the tail is a dozen latency-bound launches that leave the GPU
@@ -281,6 +294,86 @@ int ensure_voxel_buffers(pcs_node* n)
     return PCS_OK;
 }
 
+// The two sinks of a node whose peers all share the root's GPU, on first use.
+int ensure_sinks(pcs_node* n)
+{
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
+    for (int sl = 0; sl < 2; sl++) {
+        if (n->sink_ctx[sl]) continue;
+        pcs_config cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        // (a sink pre-aggregates nothing itself: it owns the workspace and the tail; any valid configuration will do)
+        cfg.device = root.dev; cfg.n_streams = n->per_dev; cfg.streams = n->cfg.data(); cfg.flags = n->flags; cfg.downsample = n->downsample;
+        const int rc = pcs_create(&n->sink_ctx[sl], &cfg);
+        if (rc != PCS_OK) return nfail(n, rc, "voxel sink context: %s", pcs_last_error(nullptr));
+        const int rc2 = pick_concurrent_stream(n, kstream(root), &n->sink_stream[sl]);
+        if (rc2 != PCS_OK) return rc2;
+        if (n->sink_stream[sl]) PCSCHK(n, n->sink_ctx[sl], pcs_set_stream(n->sink_ctx[sl], n->sink_stream[sl]));
+        HIPCHK(n, hipEventCreateWithFlags(&n->sink_open[sl], hipEventDisableTiming));
+    }
+    // Eight peers of one GPU on eight streams cost the one host thread an event record and two stream waits per peer and frame-set, on top
+    // of the launch (0.10 ms per 8 peers: as long as the GPU needs for their kernels), and the runtime folds the streams onto four
+    // hardware queues anyway. The peers are therefore dealt onto FEWER kernel streams — peer r runs on peer (r % K)'s — and only the last
+    // peer of each stream records an event for the sink (PCS_NODE_SINK_STREAMS=<K>, read when the first sink ticket is submitted).
+    // 16 x 1080p at 50 mm, 8 peers, ms per frame-set / host ms per submit: K = 1 0.264 / 0.047 (eight launches of 510 workgroups, one
+    // after the other: each ends on its slowest workgroup), 2 0.227 / 0.054, 3 0.231, 4 0.248 / 0.068, 8 0.243 / 0.114.
+    if (!n->sink_streams) {
+        const char* e = getenv("PCS_NODE_SINK_STREAMS");
+        const int want = e ? atoi(e) : 2;
+        n->sink_streams = std::max(1, std::min(want, n->n_peers));
+    }
+    if (!n->sink_shared) {
+        for (int r = n->sink_streams; r < n->n_peers; r++)
+            PCSCHK(n, n->peers[r].ctx, pcs_set_stream(n->peers[r].ctx, kstream(n->peers[r % n->sink_streams])));
+        n->sink_shared = true;
+    }
+    return PCS_OK;
+}
+
+// The peers back on their own streams (the partials exchange, as a node of several GPUs runs it).
+int unshare_streams(pcs_node* n)
+{
+    if (!n->sink_shared) return PCS_OK;
+    HIPCHK(n, hipSetDevice(n->peers[0].dev));
+    for (int r = n->sink_streams; r < n->n_peers; r++) PCSCHK(n, n->peers[r].ctx, pcs_set_stream(n->peers[r].ctx, nullptr));
+    n->sink_shared = false;
+    return PCS_OK;
+}
+
+// A sink ticket, start to end: the sink opened on its stream, every peer's pre-aggregation behind that on the peer's own stream, the
+// tail behind all of them on the sink's stream, the voxel count on its way to page-locked memory. (The sink's previous tail — two
+// tickets ago — was waited for by the host before this slot could be submitted again.)
+int enqueue_sink_ticket(pcs_node* n, Ticket& tk, int slot)
+{
+    const int S = n->per_dev, P = n->n_peers;
+    Peer& root = n->peers[0];
+    HIPCHK(n, hipSetDevice(root.dev));
+    pcs_ctx* sc = n->sink_ctx[slot];
+    hipStream_t ss = static_cast<hipStream_t>(pcs_get_stream(sc));
+    const int K = n->sink_streams;
+    PCSCHK(n, sc, pcs_voxel_sink_begin(sc, n->vcap_total, tk.leaf, &tk.sk));
+    const bool order_begin = tk.sk.work_enqueued != 0;       // (a clear of the control blocks: the sink's first ticket, or after a failed one)
+    if (order_begin) HIPCHK(n, hipEventRecord(n->sink_open[slot], ss));
+    for (int r = 0; r < P; r++) {
+        Peer& p = n->peers[r];
+        hipStream_t ks = kstream(p);
+        if (order_begin && r < K) HIPCHK(n, hipStreamWaitEvent(ks, n->sink_open[slot], 0));
+        if (r == 0 && tk.timing) HIPCHK(n, hipEventRecord(n->ev_k0[slot], ks));
+        PCSCHK(n, p.ctx, pcs_process_frames_voxel_into_sink_device(p.ctx, tk.d_depth.data() + (size_t)r * S, tk.d_color.data() + (size_t)r * S, &tk.sk));
+        if (r == 0 && tk.timing) HIPCHK(n, hipEventRecord(n->ev_k1[slot], ks));
+        if (r + K >= P) {                                    // the last peer on its stream
+            HIPCHK(n, hipEventRecord(p.packed[slot], ks));
+            HIPCHK(n, hipStreamWaitEvent(ss, p.packed[slot], 0));
+        }
+    }
+    if (tk.timing) HIPCHK(n, hipEventRecord(n->ev_r0[slot], ss));
+    PCSCHK(n, sc, pcs_voxel_sink_finish(sc, &tk.sk, tk.d_voxels, tk.voxels_shorts, static_cast<int32_t*>(n->d_vox_n[slot])));
+    HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, ss));
+    HIPCHK(n, hipEventRecord(n->ev_done[slot], ss));
+    return PCS_OK;
+}
+
 // Everything the exchange of ticket `tk` needs from the host, then the exchange itself, then (voxel) the root's reduce.
 // Called from submit (no predicate: immediately), from the NEXT submit (after that frame-set's kernels are enqueued) or from
 // wait, whichever comes first. Always leaves drained[slot] recorded on every GPU's communication stream and tk.exchanged
@@ -444,6 +537,8 @@ void pcs_node_destroy(pcs_node* n)
         if (g.comm_stream) (void)hipStreamSynchronize(g.comm_stream);
     }
     if (n->reduce_ctx && !n->peers.empty()) { (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); }
+    for (int sl = 0; sl < 2; sl++)
+        if (n->sink_ctx[sl] && !n->peers.empty()) { (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->sink_ctx[sl]); }
     for (size_t r = 0; r < n->peers.size(); r++) {
         Peer& p = n->peers[r];
         if (!p.ctx) continue;
@@ -480,6 +575,13 @@ void pcs_node_destroy(pcs_node* n)
     }
     if (n->reduce_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->reduce_ctx); pcs_destroy(n->reduce_ctx);
                          if (n->reduce_stream) (void)hipStreamDestroy(n->reduce_stream); }
+    for (int sl = 0; sl < 2; sl++) {
+        if (!n->sink_ctx[sl]) continue;
+        if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev);
+        (void)pcs_synchronize(n->sink_ctx[sl]); pcs_destroy(n->sink_ctx[sl]);
+        if (n->sink_stream[sl]) (void)hipStreamDestroy(n->sink_stream[sl]);
+        if (n->sink_open[sl]) (void)hipEventDestroy(n->sink_open[sl]);
+    }
     if (n->alt_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->alt_ctx); pcs_destroy(n->alt_ctx);
                       if (n->alt_stream) (void)hipStreamDestroy(n->alt_stream); }
     for (Peer& p : n->peers) if (p.ctx) pcs_destroy(p.ctx);
@@ -516,6 +618,7 @@ int pcs_node_create_ex(pcs_node** out, int n_devices, const int* device_ids, int
     n->n_peers = n_devices; n->per_dev = streams_per_device; n->n_streams = n_devices * streams_per_device;
     n->flags = flags; n->downsample = downsample; n->node_flags = node_flags;
     { const char* e = getenv("PCS_NODE_ONE_CALL"); n->one_call = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }      // latched here, not read in the frame loop
+    { const char* e = getenv("PCS_NODE_VOXEL_SINK"); n->vox_sink = (e && e[0] == '0') ? 0 : 1; }
     n->cfg.assign(streams, streams + n->n_streams);
     n->pred = (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0;
     n->peers.resize(n_devices);
@@ -907,8 +1010,13 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
     if (rc != PCS_OK) return rc;
     const int S = n->per_dev, P = n->n_peers;
     const bool one_call = P == 1 && n->one_call != 0;
-    rc = one_call ? ensure_voxel_counts(n) : ensure_voxel_buffers(n);
+    const bool sink = P > 1 && n->gpus.size() == 1 && n->vox_sink != 0;
+    rc = (one_call || sink) ? ensure_voxel_counts(n) : ensure_voxel_buffers(n);
     if (rc != PCS_OK) return rc;
+    if (sink) {
+        rc = ensure_sinks(n);
+        if (rc != PCS_OK) return rc;
+    }
     if (one_call && n->one_call == 2 && slot == 1 && !n->alt_ctx) {
         rc = ensure_alt_context(n);
         if (rc != PCS_OK) return rc;
@@ -941,6 +1049,18 @@ int pcs_node_submit_voxel_device(pcs_node* n, const uint16_t* const* d_depth, co
         HIPCHK(n, hipEventRecord(n->ev_done[slot], ks));
         tk.one_call = true; tk.exchanged = true; tk.busy = true;
         tk.d_depth.assign(d_depth, d_depth + (size_t)P * S); tk.d_color.assign(d_color, d_color + (size_t)P * S);
+        tk.submit_host_ms = (float)(now_ms() - t_host0);
+        *ticket = n->next_ticket++;
+        flush_other(n, slot);
+        return PCS_OK;
+    }
+    if (sink) {
+        // every peer shares the root's GPU: its partials go straight into the slot's sink, nothing is exchanged (see pcs_node::vox_sink)
+        tk.sink = true; tk.vox_ctx = n->sink_ctx[slot];
+        tk.d_depth.assign(d_depth, d_depth + (size_t)P * S); tk.d_color.assign(d_color, d_color + (size_t)P * S);
+        rc = enqueue_sink_ticket(n, tk, slot);
+        if (rc != PCS_OK) return rc;
+        tk.exchanged = true; tk.busy = true;
         tk.submit_host_ms = (float)(now_ms() - t_host0);
         *ticket = n->next_ticket++;
         flush_other(n, slot);
@@ -982,18 +1102,21 @@ int pcs_node_wait_voxel(pcs_node* n, int ticket, int* n_voxels)
         // Once more on the LSD tail, which waits for nobody, latched for that context; what the tail read is still where it was
         // (the rasters of a one-call ticket are the caller's until this wait returns; the merged partials sit in this slot's
         // arrays until the slot's next submit). It queues behind whatever the next submit already enqueued on that stream.
-        pcs_ctx* vc = tk->one_call ? tk->vox_ctx : n->reduce_ctx;
+        pcs_ctx* vc = (tk->one_call || tk->sink) ? tk->vox_ctx : n->reduce_ctx;
         PCSCHK(n, vc, pcs_set_voxel_tail(vc, PCS_VOXEL_TAIL_LSD_LATCHED));
         n->voxel_reruns++;
         hipStream_t vs = static_cast<hipStream_t>(pcs_get_stream(vc));
-        if (tk->one_call)
+        if (tk->sink) {
+            const int rr = enqueue_sink_ticket(n, *tk, slot);          // every peer again, into the same sink, its tail now LSD
+            if (rr != PCS_OK) return rr;
+        } else if (tk->one_call)
             PCSCHK(n, vc, pcs_process_frames_voxel_device(vc, tk->d_depth.data(), tk->d_color.data(), tk->leaf, tk->d_voxels, tk->voxels_shorts,
                                                           static_cast<int32_t*>(n->d_vox_n[slot])));
         else
             PCSCHK(n, vc, pcs_voxel_grid_from_partials_device(vc, static_cast<const uint64_t*>(root.d_vkeys[slot]),
                                                               static_cast<const pcs_voxel_partial*>(root.d_vparts[slot]), (int)tk->total, nullptr,
                                                               tk->leaf, tk->d_voxels, tk->voxels_shorts, static_cast<int32_t*>(n->d_vox_n[slot])));
-        HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, vs));
+        if (!tk->sink) HIPCHK(n, hipMemcpyAsync(n->h_vcount[slot] + P, n->d_vox_n[slot], sizeof(int32_t), hipMemcpyDeviceToHost, vs));
         HIPCHK(n, hipStreamSynchronize(vs));
         if (n->h_vcount[slot][P] < 0)
             return nfail(n, PCS_ERR_HIP, "the voxel pipeline reported a negative count on the LSD tail too (device stalled?)");
@@ -1012,6 +1135,17 @@ int pcs_node_set_one_call(pcs_node* n, int mode)
     n->one_call = mode;
     return PCS_OK;
 }
+
+int pcs_node_set_voxel_sink(pcs_node* n, int on)
+{
+    if (!n) return PCS_ERR_INVALID_ARG;
+    if (n->inflight[0].busy || n->inflight[1].busy) return nfail(n, PCS_ERR_INVALID_ARG, "wait for the frame-sets in flight first");
+    n->vox_sink = on ? 1 : 0;
+    if (!on) return unshare_streams(n);
+    return PCS_OK;
+}
+
+int pcs_node_voxel_sink(const pcs_node* n) { return (n && n->n_peers > 1 && n->gpus.size() == 1 && n->vox_sink) ? 1 : 0; }
 
 int pcs_node_process_voxel_device(pcs_node* n, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
                                   int route, int16_t* d_voxels, size_t voxels_shorts, int* n_voxels, pcs_node_voxel_stats* stats)

@@ -59,6 +59,9 @@ SYMBOLS = [
     ("pcs_voxel_grid", C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int)]),
     ("pcs_process_frames_voxel_partials_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, _VP, _VP, C.c_size_t, _VP]),
     ("pcs_voxel_grid_from_partials_device", C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_size_t, _VP]),
+    ("pcs_voxel_sink_begin", C.c_int, [_VP, C.c_size_t, C.c_int, _VP]),
+    ("pcs_process_frames_voxel_into_sink_device", C.c_int, [_VP, _P(_VP), _P(_VP), _VP]),
+    ("pcs_voxel_sink_finish", C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP]),
     ("pcs_set_stream", C.c_int, [_VP, _VP]),
     ("pcs_get_stream", _VP, [_VP]),
     ("pcs_synchronize", C.c_int, [_VP]),

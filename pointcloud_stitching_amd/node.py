@@ -70,6 +70,8 @@ SYMBOLS = [
     ("pcs_node_wait_voxel", C.c_int, [_VP, C.c_int, _P(C.c_int)]),
     ("pcs_node_voxel_reruns", C.c_int, [_VP]),
     ("pcs_node_set_one_call", C.c_int, [_VP, C.c_int]),
+    ("pcs_node_set_voxel_sink", C.c_int, [_VP, C.c_int]),
+    ("pcs_node_voxel_sink", C.c_int, [_VP]),
     ("pcs_node_process_voxel_device", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, _P(C.c_int), _P(VoxelStats)]),
     ("pcs_node_process_voxel", C.c_int, [_VP, _P(_VP), _P(_VP), C.c_int, C.c_int, _VP, C.c_size_t, C.c_int, _P(C.c_int), _P(VoxelStats)]),
 ]
@@ -235,6 +237,16 @@ class PcsNode:
         """A one-peer node: 2 (default) rasters -> voxels enqueued at submit on two contexts used in turn, 1 on one context, 0 the
         partials pipeline of a node of several peers. pcs_node_set_one_call; nothing may be in flight."""
         self._check(self._lib.pcs_node_set_one_call(self._h, int(mode)))
+
+    def set_voxel_sink(self, on: bool) -> None:
+        """Several peers that all share one GPU: True (default) every peer pre-aggregates into a sink context of that GPU and nothing is
+        exchanged, False the partials exchange (RCCL self send/recv). pcs_node_set_voxel_sink; nothing may be in flight."""
+        self._check(self._lib.pcs_node_set_voxel_sink(self._h, 1 if on else 0))
+
+    @property
+    def voxel_sink(self) -> bool:
+        """Will the next voxel ticket go through a sink (pcs_node_voxel_sink)?"""
+        return bool(self._lib.pcs_node_voxel_sink(self._h))
 
     def voxel_reruns(self) -> int:
         """Voxel frame-sets this node ran again on the LSD tail after a flagged bucket tail (pcs_node_voxel_reruns)."""

@@ -127,6 +127,126 @@ def test_partials_entry_points_check_their_arguments():
         assert int(nv[0]) == 0
 
 
+def _sink_voxels(cfgs, sets, shards, leaf, flags, downsample=1, tails=None):
+    """The sink route (pcs_voxel_sink_*) with `shards` contexts of this GPU pre-aggregating into ONE more context's workspace: call after
+    call on the same sink (the second and later ones are warm: partials straight into the buckets' regions), the streams ordered by host
+    synchronisation. Returns the voxel records of every call."""
+    per = len(cfgs) // shards
+    ctxs = [PcsContext(cfgs[r * per:(r + 1) * per], flags=flags, downsample=downsample) for r in range(shards)]
+    sink_ctx = PcsContext(cfgs[:1])
+    try:
+        total = sum(c.max_payload_shorts // 5 for c in ctxs)
+        d_out = sink_ctx.device_malloc(total * 10 + 64)
+        d_nv = sink_ctx.device_malloc(64)
+        outs = []
+        for k, (depth, color) in enumerate(sets):
+            if tails:
+                sink_ctx.set_voxel_tail(tails[k % len(tails)])
+            sink = sink_ctx.voxel_sink_begin(total, leaf)
+            sink_ctx.synchronize()
+            ptrs = []
+            for r, c in enumerate(ctxs):
+                dd, dc = _upload(c, depth[r * per:(r + 1) * per], color[r * per:(r + 1) * per])
+                c.process_frames_voxel_into_sink_device(dd, dc, sink)
+                ptrs.append((c, dd + dc))
+            for c, pp in ptrs:
+                c.synchronize()
+                for q in pp:
+                    c.device_free(q)
+            sink_ctx.voxel_sink_finish(sink, d_out, total * 5, d_nv)
+            sink_ctx.synchronize()
+            nv = np.empty(1, np.int32); sink_ctx.memcpy_d2h(nv, d_nv)
+            assert 0 <= int(nv[0]) <= total
+            got = np.empty(max(int(nv[0]), 1) * 5, np.int16); sink_ctx.memcpy_d2h(got, d_out)
+            outs.append(got[:int(nv[0]) * 5].reshape(-1, 5).copy())
+        return outs
+    finally:
+        sink_ctx.close()
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID, FLAG_CUTOFF | FLAG_CUTOFF_COMPAT | FLAG_DROP_INVALID])
+@pytest.mark.parametrize("shape,shards", [((4, 320, 240), 2), ((6, 200, 96), 3), ((4, 203, 57), 4), ((8, 320, 240), 8)])
+def test_sink_of_several_contexts_is_the_voxel_grid_of_the_stitched_cloud(oracle, flags, shape, shards):
+    """pcs_voxel_sink_begin / pcs_process_frames_voxel_into_sink_device / pcs_voxel_sink_finish: several contexts of one GPU write their
+    partials into one context's workspace; the tail over the union == oracle voxel grid of the stitched cloud. Four calls per leaf on the
+    same sink (cold, then warm with regions sized by the call before), a scene that CHANGES between the calls (other seeds: regions
+    overflow into the general list), leaves on both sides of the bucket / LSD switch, a raster width that is not a multiple of 8."""
+    n, w, h = shape
+    cfgs = [S.synth_stream_config(w, h, s) for s in range(n)]
+    sets = [([S.synth_depth(w, h, s, seed=S.SEED + 31 * f) for s in range(n)], [S.synth_color(w, h, s, seed=S.SEED + 31 * f) for s in range(n)])
+            for f in (0, 0, 1, 2)]
+    stitched = [oracle.process_frames(cfgs, d, c, flags, 1)[0] for d, c in sets]
+    for leaf in (20, 50, 200):
+        got = _sink_voxels(cfgs, sets, shards, leaf, flags)
+        for k, g in enumerate(got):
+            want = oracle.voxel_grid(stitched[k], leaf)
+            assert g.shape == want.shape and (g == want).all(), (leaf, k)
+
+
+@pytest.mark.gpu
+def test_sink_with_a_stride_with_nothing_kept_and_across_tail_changes(oracle):
+    VOXEL_TAIL_BUCKET, VOXEL_TAIL_LSD = 1, 2          # include/pcs_hip.h: PCS_VOXEL_TAIL_*
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    stitched, _ = oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID, 3)
+    want = oracle.voxel_grid(stitched, 64)
+    for g in _sink_voxels(cfgs, [(depth, color)] * 3, 2, 64, FLAG_DROP_INVALID, downsample=3):      # the stride: through each context's own cloud
+        assert g.shape == want.shape and (g == want).all()
+    empty = [np.zeros_like(d) for d in depth]                                       # every pixel invalid: no partials at all
+    for g in _sink_voxels(cfgs, [(empty, color), (depth, color), (empty, color)], 2, 50, FLAG_DROP_INVALID)[::2]:
+        assert g.shape == (0, 5)
+    # bucket, bucket (warm), LSD, bucket (its splitters are still this leaf's), LSD: the sink's workspace serves whichever tail a call takes
+    stitched, _ = oracle.process_frames(cfgs, depth, color, 0, 1)
+    want = oracle.voxel_grid(stitched, 50)
+    for g in _sink_voxels(cfgs, [(depth, color)] * 5, 4, 50, 0, tails=[VOXEL_TAIL_BUCKET, VOXEL_TAIL_BUCKET, VOXEL_TAIL_LSD, VOXEL_TAIL_BUCKET, VOXEL_TAIL_LSD]):
+        assert g.shape == want.shape and (g == want).all()
+
+
+@pytest.mark.gpu
+def test_sink_entry_points_check_their_arguments():
+    cfgs, depth, color = S.synth_frame_set(2, 64, 48)
+    with PcsContext(cfgs) as ctx, PcsContext(cfgs[:1]) as sink_ctx:
+        dd, dc = _upload(ctx, depth, color)
+        cap = ctx.max_payload_shorts // 5
+        out = sink_ctx.device_malloc(cap * 10 + 64); n = sink_ctx.device_malloc(64)
+        with pytest.raises(PcsError) as e:
+            sink_ctx.voxel_sink_begin(cap, 0)
+        assert e.value.status == -1
+        with pytest.raises(PcsError) as e:
+            sink_ctx.voxel_sink_begin(0, 50)
+        assert e.value.status == -1
+        import ctypes as C
+        junk = (C.c_uint64 * 24)()
+        with pytest.raises(PcsError) as e:
+            ctx.process_frames_voxel_into_sink_device(dd, dc, junk)                          # not a sink
+        assert e.value.status == -1
+        small = sink_ctx.voxel_sink_begin(cap - 1, 50)
+        with pytest.raises(PcsError) as e:
+            ctx.process_frames_voxel_into_sink_device(dd, dc, small)                         # this context alone can exceed the sink
+        assert e.value.status == -5
+        sink = sink_ctx.voxel_sink_begin(cap, 50)                                            # (abandons the small one)
+        sink_ctx.synchronize()
+        ctx.process_frames_voxel_into_sink_device(dd, dc, sink)
+        ctx.synchronize()
+        with pytest.raises(PcsError) as e:
+            sink_ctx.voxel_sink_finish(sink, out, cap * 5 - 1, n)                            # output too small
+        assert e.value.status == -5
+        with pytest.raises(PcsError) as e:
+            ctx.voxel_sink_finish(sink, out, cap * 5, n)                                     # not the context that opened it
+        assert e.value.status == -1
+        sink_ctx.voxel_sink_finish(sink, out, cap * 5, n)
+        sink_ctx.synchronize()
+        with pytest.raises(PcsError) as e:
+            sink_ctx.voxel_sink_finish(sink, out, cap * 5, n)                                # already finished
+        assert e.value.status == -1
+        # the sink context still serves its own calls afterwards
+        d1, c1 = _upload(sink_ctx, depth[:1], color[:1])
+        sink_ctx.process_frames_voxel_device(d1, c1, 50, out, cap * 5, n)
+        sink_ctx.synchronize()
+
+
 @pytest.mark.gpu
 def test_config5_full_size_sharded_eight_plus_eight_against_oracle_digests():
     """16 x 1920x1080 split 8 + 8 over two contexts (two GPUs' worth of cameras), DROP_INVALID, 50 and 200 mm: the root's

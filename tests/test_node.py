@@ -128,16 +128,23 @@ def test_a_failed_submit_leaves_the_node_usable(oracle, flags):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, FLAG_DROP_INVALID])
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], "one peer, partials pipeline", "one peer, one context"])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], "one peer, partials pipeline", "one peer, one context",
+                                     "two peers, exchange", "four peers, exchange"])
 def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, devices, monkeypatch):
     """pcs_node_submit_voxel_device / pcs_node_wait_voxel: partials pre-aggregated per peer, ONE grouped exchange of keys +
     partials, sort + segmented mean on the root — byte-identical to the voxel grid of the stitched cloud, frame after frame,
     with the pre-aggregation of k+1 queued before the exchange of k. A node of ONE peer enqueues the rasters -> voxels call at
     submit instead (no partials leave the library: stats say 0) — its two slots on two contexts of the peer in turn, or
-    (PCS_NODE_ONE_CALL=1) on one; PCS_NODE_ONE_CALL=0 keeps the partials pipeline for it."""
+    (PCS_NODE_ONE_CALL=1) on one; PCS_NODE_ONE_CALL=0 keeps the partials pipeline for it. Several peers that all share ONE GPU take
+    the sink by default (every peer pre-aggregates into a sink context of that GPU: nothing exchanged, stats as a one-call ticket's);
+    PCS_NODE_VOXEL_SINK=0 keeps the exchange on RCCL self send/recv for them."""
     from pointcloud_stitching_amd.node import PcsNode, VOXEL_PARTIALS, VOXEL_PAYLOADS
-    one_call = devices == [0] or devices == "one peer, one context"
-    if isinstance(devices, str):
+    one_call = devices == [0] or devices == "one peer, one context" or (isinstance(devices, list) and len(devices) > 1)
+    exchange = isinstance(devices, str) and "exchange" in devices
+    if exchange:
+        monkeypatch.setenv("PCS_NODE_VOXEL_SINK", "0")
+        devices = [0] * (2 if "two" in devices else 4)
+    elif isinstance(devices, str):
         monkeypatch.setenv("PCS_NODE_ONE_CALL", "0" if "partials" in devices else "1")
         devices = [0]
     n, w, h, frames, leaf = 4, 320, 240, 5, 40
@@ -162,7 +169,8 @@ def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, dev
                 assert st["reduced"] == 0 and st["kernels_ms"] > 0
             else:
                 assert st["reduced"] >= nv and st["root_ms"] > 0
-            assert (st["exchanged_bytes"] > 0) == (len(devices) > 1) and st["exchanged_bytes"] % 40 == 0
+            assert (st["exchanged_bytes"] > 0) == exchange and st["exchanged_bytes"] % 40 == 0
+            assert node.voxel_sink == (len(devices) > 1 and not exchange)
         # the synchronous forms (both routes) on the same node afterwards
         for route in (VOXEL_PARTIALS, VOXEL_PAYLOADS):
             nv, stats = node.process_voxel_device(*dev_sets[1], leaf, vox[0], cap, route)
@@ -171,18 +179,21 @@ def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, dev
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", [[0], [0] * 8, "one peer, partials pipeline", "one peer, one context"])
+@pytest.mark.parametrize("devices", [[0], [0] * 8, "one peer, partials pipeline", "one peer, one context", "eight peers, exchange"])
 def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices, monkeypatch):
     """BASELINE configs[4] at full size — 16 x 1920x1080, invalid-depth compaction, 50 mm voxel grid — through the pipelined node
-    call with two frame-sets in flight; [0]*8 is the configuration's own shape (2 cameras per peer, 8 peers) with the
-    exchange on RCCL. Both frame-sets are the digest's frame."""
+    call with two frame-sets in flight; [0]*8 is the configuration's own shape (2 cameras per peer, 8 peers) on ONE GPU: through the
+    sinks by default, with the exchange on RCCL under PCS_NODE_VOXEL_SINK=0. Both frame-sets are the digest's frame."""
     from pointcloud_stitching_amd.node import PcsNode
     W, H, N, leaf = 1920, 1080, 16, 50
     cfgs = [S.synth_stream_config(W, H, s) for s in range(N)]
     depth = [S.synth_depth(W, H, s) for s in range(N)]
     color = [S.synth_color(W, H, s) for s in range(N)]
     gold = GOLD["voxel"][str(leaf)]
-    if isinstance(devices, str):
+    if devices == "eight peers, exchange":
+        monkeypatch.setenv("PCS_NODE_VOXEL_SINK", "0")
+        devices = [0] * 8
+    elif isinstance(devices, str):
         monkeypatch.setenv("PCS_NODE_ONE_CALL", "0" if "partials" in devices else "1")
         devices = [0]
     with PcsNode(cfgs, devices=devices, flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
@@ -248,13 +259,14 @@ def test_no_exchange_flag_packs_every_peer_but_gathers_nothing(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["stitch", "voxel"])
-def test_after_an_rccl_failure_every_later_call_fails(oracle, kind):
+def test_after_an_rccl_failure_every_later_call_fails(oracle, kind, monkeypatch):
     """include/pcs_node.h: an RCCL failure aborts the communicators and EVERY later call fails with PCS_ERR_HIP. Two tickets in
     flight under a predicate (their exchanges are deferred); the first one's exchange is made to fail: the wait for it reports
     the failure, and the wait for the SECOND one — whose exchange can no longer run — must not return PCS_OK with the whole
     node's counts over a buffer nothing was gathered into."""
     from pointcloud_stitching_amd.node import PcsNode
     cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    monkeypatch.setenv("PCS_NODE_VOXEL_SINK", "0")        # (two peers of one GPU: their voxel tickets would exchange nothing otherwise)
     with PcsNode(cfgs, devices=[0, 0], flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
         cap = node.max_payload_shorts
         dd, dc = _upload(mem, depth, color)

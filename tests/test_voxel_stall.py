@@ -79,13 +79,16 @@ def test_device_form_reports_minus_one_and_the_caller_latches(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", [[0], [0, 0, 0, 0], "one peer, partials pipeline"])
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0, 0], "one peer, partials pipeline", "four peers, exchange"])
 def test_node_wait_runs_a_flagged_frame_set_again(oracle, devices, monkeypatch):
     """submit(k+1); wait(k) with the stall injected into frame-set 2's tail: every frame-set still equals the oracle, the wait
     never returns a negative count, the node says it ran one frame-set again."""
     from pointcloud_stitching_amd.node import PcsNode, VOXEL_PAYLOADS
     from test_node import _upload, _fetch
-    if isinstance(devices, str):
+    if devices == "four peers, exchange":
+        devices = [0, 0, 0, 0]
+        monkeypatch.setenv("PCS_NODE_VOXEL_SINK", "0")        # ([0, 0, 0, 0] by itself: through the sinks, every peer run again)
+    elif isinstance(devices, str):
         devices = [0]
         monkeypatch.setenv("PCS_NODE_ONE_CALL", "0")
     n, w, h, frames, leaf = 4, 320, 240, 6, 40

@@ -90,8 +90,10 @@ def table(R):
     if ss:
         a = ss["roofline"]["algorithmic_bytes_per_launch"]
         rows.append(("same kernel, ONE stream per launch (BASELINE `configs[1]`)", f"1 × {W}×{H}, cold ring of {ss['ring_frame_sets']} frames",
-                     f"{ss['ms_per_frame'] * 1e3:.2f} (512-point tiles: {ss['tile_512_points_ms'] * 1e3:.2f})", f1(R.prof_us("single", r"fused_dense_kernel<")),
-                     mb(a), f"{ss['roofline']['frac']:.2f}", ratio(R.traffic("single", r"fused_dense_kernel<"), a),
+                     f"{ss['ms_per_frame'] * 1e3:.2f} (512-point tiles: {ss['tile_512_points_ms'] * 1e3:.2f}"
+                     + (f"; frame loop over two contexts: **{ss['frame_loop_two_contexts']['ms_per_frame'] * 1e3:.2f}**" if "frame_loop_two_contexts" in ss else "") + ")",
+                     f1(R.prof_us("single", r"fused_dense_kernel<")),
+                     mb(a), f"{ss['roofline']['frac']:.2f}" + (f"; loop {ss['frame_loop_two_contexts']['frac']:.2f}" if "frame_loop_two_contexts" in ss else ""), ratio(R.traffic("single", r"fused_dense_kernel<"), a),
                      "latency: a lone launch is a chain of dependent round trips (constants, Z16 + LUT, colour gather, store drain) — ≈ 5 µs before "
                      "the first stream's bytes count, ≈ 2.3 µs per further stream; the tile size does not shorten it (Appendix A)"))
     bd = d.get("batched_dense")
@@ -155,11 +157,18 @@ def table(R):
         a = f"{R.node1['ms_per_step'] * 1e3:.0f}" if R.node1 else "—"
         b = f"{R.node8['ms_per_step'] * 1e3:.0f}" if R.node8 else "—"
         op = (R.node1 or {}).get("one_peer", {})
-        rows.append(("**config 5 through the node** (`pcs_node_submit_voxel_device` / `pcs_node_wait_voxel`)", "one peer / 8 virtual peers of ONE GPU (RCCL self send/recv)",
-                     f"**{a}** / {b} per frame-set" + (f" (one context {op['one_context_ms_per_step'] * 1e3:.0f}, partials pipeline {op['partials_pipeline_ms_per_step'] * 1e3:.0f})"
-                                                      if "one_context_ms_per_step" in op else ""), "—", "—", "—", "—",
-                     "one peer: the one call above, the two slots on two contexts in turn. 8 virtual peers: every peer's kernels, the exchange and "
-                     "the root's place + reduce share ONE GPU — says nothing about a node of 8 (never measured across GPUs)"))
+        sink = bool((R.node8 or {}).get("voxel_sink"))
+        xr = ((R.node8 or {}).get("same_gpu_peers") or {}).get("partials_exchange", {})
+        rows.append(("**config 5 through the node** (`pcs_node_submit_voxel_device` / `pcs_node_wait_voxel`)",
+                     "one peer / 8 virtual peers of ONE GPU" + (" (through the voxel sinks; the partials exchange on RCCL self send/recv beside it)" if sink
+                                                                 else " (RCCL self send/recv)"),
+                     f"**{a}** / **{b}**" + (f" (exchange route {xr['ms_per_step'] * 1e3:.0f})" if xr else "") + " per frame-set"
+                     + (f" (one peer on one context {op['one_context_ms_per_step'] * 1e3:.0f}, partials pipeline {op['partials_pipeline_ms_per_step'] * 1e3:.0f})"
+                        if "one_context_ms_per_step" in op else ""), "—", "—", "—", "—",
+                     "one peer: the one call above, the two slots on two contexts in turn. 8 virtual peers: 8 contexts pre-aggregate into a sink of the "
+                     "GPU they share (§9), the tail of k beside the pre-aggregations of k+1; the exchange route runs every peer's kernels, RCCL's "
+                     "self-copies and the root's place + reduce one after the other on that GPU. Neither says anything about a node of 8 (never "
+                     "measured across GPUs)"))
     head = ["kernel(s)", "workload", "µs, un-profiled (`bench.py`)", "µs, `rocprofv3` avg", "algorithmic bytes", "of 8 TB/s", "PMC traffic", "what bounds it"]
     out = [BEGIN, f"(generated by `python tools/design_tables.py {R.tag} --write` from `profiles/{R.tag}_bench.json`, `{R.tag}_kernel_stats.csv`, "
                   f"`{R.tag}_pmc_summary.json`, `{R.tag}_bench_config5_node*.json`)", "", "| " + " | ".join(head) + " |", "|" + "---|" * len(head)]

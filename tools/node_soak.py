@@ -53,6 +53,8 @@ while time.time() < t_end:
     nf = DIRECT_STORE if rng.random() < 0.3 else 0          # (without a predicate the pack kernels then store into the root themselves)
     with PcsNode(cfgs, devices=[0] * peers, flags=flags, downsample=ds, node_flags=nf) as node, PcsContext(cfgs[:1]) as mem:
         cap = node.max_payload_shorts
+        if peers > 1 and rng.random() < 0.4:
+            node.set_voxel_sink(False)                # the peers share GPU 0: sinks by default, the RCCL partials exchange for the others
         dev = []
         for depth, color in sets:
             dd = [mem.device_malloc(max(d.nbytes, 16)) for d in depth]

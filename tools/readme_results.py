@@ -32,8 +32,12 @@ def table(d, src):
     rows = [
         ("8 × 1280×720 streams, fused dense kernel, one frame-set per launch (**headline `value`**)",
          us(r["avg_launch_ms"]), f"{d['value'] / 1e3:.0f} k Mpoints/s", pct(r["frac"]) + (f" (by the wall clock `value` uses: {pct(r['frac_wall'])})" if "frac_wall" in r else "")),
-        *([("ONE 1280×720 stream per launch (BASELINE `configs[1]`), cold ring, same kernel", us(d["single_stream"]["ms_per_frame"]),
-            f"{d['single_stream']['value'] / 1e3:.0f} k Mpoints/s", pct(d["single_stream"]["roofline"]["frac"]) + " (latency-bound)")] if "single_stream" in d else []),
+        *([("ONE 1280×720 stream per launch (BASELINE `configs[1]`), cold ring, same kernel"
+            + (" / as a frame loop over two contexts" if "frame_loop_two_contexts" in d["single_stream"] else ""),
+            us(d["single_stream"]["ms_per_frame"]) + (f" / {us(d['single_stream']['frame_loop_two_contexts']['ms_per_frame'])}" if "frame_loop_two_contexts" in d["single_stream"] else ""),
+            f"{d['single_stream']['value'] / 1e3:.0f} k Mpoints/s" + (f" / {d['single_stream']['frame_loop_two_contexts']['value'] / 1e3:.0f} k" if "frame_loop_two_contexts" in d["single_stream"] else ""),
+            pct(d["single_stream"]["roofline"]["frac"]) + " (latency-bound)"
+            + (f" / {pct(d['single_stream']['frame_loop_two_contexts']['frac'])}" if "frame_loop_two_contexts" in d["single_stream"] else ""))] if "single_stream" in d else []),
         (f"same tiles, {bd['frame_sets_per_launch']} frame-sets per launch (`pcs_process_frames_device_batch`)",
          us(bd["ms_per_frame_set"]) + " / frame-set", f"{bd['value'] / 1e3:.0f} k Mpoints/s", pct(bd["frac"])),
         ("same, 1° depth→colour rotation", us(d["general_rotation"]["ms_per_step"]), f"{d['general_rotation']['value'] / 1e3:.0f} k Mpoints/s",
