@@ -16,102 +16,11 @@
 #include <string>
 #include <vector>
 
-#include "pcs_device.h"
+#include "pcs_host.h"
 
-using namespace pcs;
+using namespace pcs_host;
 
-struct Certificate {
-    bool   fast = false, ident_r = false;
-    double xb = 0, yb = 0, zb = 0;      // |X|,|Y|,|Z| upper bounds over valid depths
-    double a_max[3] = {0, 0, 0};        // |P_i| upper bounds
-    double p2_low = 0;                  // P2 lower bound (> 0) over valid depths
-};
-
-struct pcs_ctx {
-    int                             device = 0;
-    int                             n_streams = 0;
-    uint32_t                        flags = 0;
-    int                             downsample = 1;
-    std::vector<pcs_stream_config>  cfg;
-    std::vector<StreamParams>       h_params;
-    StreamParams*                   d_params = nullptr;
-    std::vector<float*>             d_lut;            // 2 per stream (mx, my)
-    uint32_t                        total_tiles = 0;
-    uint32_t*                       d_tile_counts = nullptr;
-    uint32_t*                       d_tile_prefix = nullptr;
-    uint32_t*                       d_stream_base = nullptr;   // n_streams + 1 (kept points per stream)
-    uint32_t*                       d_arrive = nullptr;        // scan arrival counter (self-resetting)
-    int32_t*                        d_counts = nullptr;        // n_streams + 1 (internal, for host APIs)
-    int32_t*                        d_static_counts = nullptr; // n_streams + 1: ceil(n/downsample) per stream, total
-    // batched compaction scratch (pcs_process_frames_device_batch with a predicate): one slab, rows per frame-set
-    uint32_t*                       d_batch_scratch = nullptr;
-    int                             batch_scratch_sets = 0;
-    // single-pass compaction state (pcs_fused_compact_kernel)
-    unsigned long long*             d_ticket = nullptr;        // never reset
-    unsigned long long              tickets_issued = 0;
-    uint64_t*                       d_desc = nullptr;          // one per tile
-    uint32_t*                       d_stream_end = nullptr;    // n_streams
-    uint32_t*                       d_error = nullptr;
-    uint32_t                        compact_seq = 0;
-    bool                            single_pass_ok = true;     // cleared if a placement wait ever timed out
-    bool                            compact_tickets = false;   // tile ids by atomic ticket instead of blockIdx
-    int                             compact_path = 0;          // 0 count + scan + emit (default), 1 single pass by blockIdx (opt-in)
-    bool                            dense_ok = false;          // every stream has n % 8 == 0
-    bool                            any_ddist = false, any_cdist = false;
-    std::vector<int>                math;                      // per stream: 0 IEEE, 1 certified, 2 + identity R, 3/4 = 1/2 + no-overflow
-    std::vector<Certificate>        cert;
-    uint32_t                        max_points = 0;
-    size_t                          max_payload_points = 0;
-
-    hipStream_t                     own_stream = nullptr;
-    hipStream_t                     stream = nullptr;
-    hipEvent_t                      ev_begin = nullptr, ev_end = nullptr;
-    bool                            kernel_timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;    // recorded pairs awaiting drain
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
-
-    // lazily sized staging for the host-pointer entry points
-    // Rasters of all streams are carved from ONE slab at 256-byte granularity. Separate hipMalloc()s hand
-    // out 2 MiB-aligned bases; the streams' tiles advance in lockstep, so equal offsets from power-of-two
-    // aligned bases compete for the same sets of the memory-side Infinity Cache: with inputs that were just
-    // written (and so sit in that cache) the 8x720p launch measured 22.7 us vs 19.0 us (tools/lab/kernel_lab.hip,
-    // "allocation mode", 6-set ring). With cold inputs streamed from HBM the layout makes no difference.
-    uint8_t*                        s_slab = nullptr;
-    std::vector<uint16_t*>          s_depth;
-    std::vector<uint8_t*>           s_color;
-    int16_t*                        s_payload = nullptr;  size_t s_payload_cap = 0;   // bytes
-    float*                          s_vertices = nullptr; size_t s_vertices_cap = 0;
-    float*                          s_texcoords = nullptr; size_t s_texcoords_cap = 0;
-    void*                           s_voxel_ws = nullptr; size_t s_voxel_ws_cap = 0;
-    VoxelWsState                    vox_state;          // which control block of s_voxel_ws the next voxel call uses
-    bool                            sink_open = false;  // pcs_voxel_sink_begin without its pcs_voxel_sink_finish yet
-    int                             voxel_reruns = 0;   // calls that ended flagged (-1) and latched the LSD tail (pcs_voxel_tail_reruns)
-    int16_t*                        s_voxel_in = nullptr; size_t s_voxel_in_cap = 0;
-    int16_t*                        s_voxel_out = nullptr; size_t s_voxel_out_cap = 0;
-    uint32_t*                       s_pack_counts = nullptr; uint32_t* s_pack_prefix = nullptr; size_t s_pack_tiles = 0;
-
-    // pcs_submit_frames / pcs_collect_frames: device slots, download stream
-    struct PipeSlot {
-        uint8_t*               slab = nullptr;
-        std::vector<uint16_t*> depth;
-        std::vector<uint8_t*>  color;
-        int16_t*               payload = nullptr;
-        int32_t*               counts = nullptr;       // device, n_streams + 1
-        hipEvent_t             done = nullptr;
-        bool                   busy = false;
-        int                    ticket = -1;
-    };
-    PipeSlot                        pipe[PCS_PIPELINE_DEPTH];
-    hipStream_t                     dl_stream = nullptr;
-    int                             next_ticket = 0, next_collect = 0;
-
-    struct ZcEntry { const void* host; size_t bytes; void* dev; int verdict; };
-    std::vector<ZcEntry>            zc_cache;                  // zero-copy eligibility verdicts (host_device_view)
-
-    std::string                     err;
-};
-
-namespace {
+namespace pcs_host {
 
 thread_local std::string g_create_err;
 
@@ -126,12 +35,9 @@ int fail(pcs_ctx* c, int status, const char* fmt, ...)
     return status;
 }
 
-#define HIPCHK(c, expr)                                                                     \
-    do {                                                                                    \
-        hipError_t _e = (expr);                                                             \
-        if (_e != hipSuccess)                                                               \
-            return fail((c), PCS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));   \
-    } while (0)
+}  // namespace pcs_host
+
+namespace {
 
 bool coeffs_nonzero(const pcs_intrinsics& in)
 {
@@ -343,20 +249,6 @@ uint32_t cutoff_dmax(const pcs_stream_config& s, const StreamParams& p, const st
 }
 
 inline uint32_t tiles_of(uint32_t n) { return (n + kTilePoints - 1) / kTilePoints; }
-inline bool has_pred(uint32_t flags) { return (flags & (PCS_FLAG_CUTOFF | PCS_FLAG_DROP_INVALID)) != 0; }
-
-template <class T>
-int ensure(pcs_ctx* c, T*& p, size_t& cap, size_t bytes)
-{
-    if (bytes <= cap && p) return PCS_OK;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 256));
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, PCS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
-    p = static_cast<T*>(q);
-    cap = std::max<size_t>(bytes, 256);
-    return PCS_OK;
-}
 
 // One slab for all streams' rasters, carved at 256-byte granularity (see the comment at s_slab).
 int alloc_raster_slab(pcs_ctx* c, uint8_t*& slab, std::vector<uint16_t*>& depth, std::vector<uint8_t*>& color)
@@ -387,6 +279,10 @@ int ensure_rasters(pcs_ctx* c)
     return alloc_raster_slab(c, c->s_slab, c->s_depth, c->s_color);
 }
 
+}  // namespace
+
+namespace pcs_host {
+
 // The voxel workspace. Growing it means: wait for the stream (the old one may be in use), free, allocate — a device-wide stall.
 // A caller whose sizes creep upwards (the node's root reduces a different number of partials every frame-set) must not pay that
 // at every new maximum: a workspace that has to grow takes a quarter more than asked.
@@ -405,12 +301,6 @@ int ensure_voxel_ws(pcs_ctx* c, size_t need)
     return rc;
 }
 
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-
 int acquire_event_pair(pcs_ctx* c, std::pair<hipEvent_t, hipEvent_t>& pr)
 {
     if (!c->ev_free.empty()) { pr = c->ev_free.back(); c->ev_free.pop_back(); return PCS_OK; }
@@ -421,8 +311,8 @@ int acquire_event_pair(pcs_ctx* c, std::pair<hipEvent_t, hipEvent_t>& pr)
 
 // The fused path for device-resident rasters. Counts end up in d_counts (if non-null).
 int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
-                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts, bool force_three_pass = false,
-                     const uint32_t* d_tile_kept = nullptr)
+                     int16_t* d_payload, size_t payload_shorts, int32_t* d_counts, bool force_three_pass,
+                     const uint32_t* d_tile_kept)
 {
     if (payload_shorts < c->max_payload_points * PCS_POINT_SHORTS && !has_pred(c->flags))
         return fail(c, PCS_ERR_CAPACITY, "payload buffer holds %zu shorts, %zu needed", payload_shorts,
@@ -532,6 +422,10 @@ int run_fused_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* 
     }
     return PCS_OK;
 }
+
+}  // namespace pcs_host
+
+namespace {
 
 // Reads (and clears) the single-pass compaction's time-out word. Returns 1 if it was set.
 int take_compact_error(pcs_ctx* c, bool& was_set)
@@ -1568,352 +1462,6 @@ int pcs_transform_payloads_device(pcs_ctx* c, int n_cams, const pcs_payload_desc
     }
     if (points_per_cam) for (int i = 0; i < n_cams; i++) points_per_cam[i] = (int)kept[i];
     if (total_points) *total_points = (int)need;
-    return PCS_OK;
-}
-
-// ---- voxel-grid downsample (not in the reference; defined in pcs_voxel.hip / DESIGN.md) ----------
-static int voxel_grid_device_impl(pcs_ctx* c, const int16_t* d_payload, int n_points, const int32_t* d_n_points, int leaf_mm,
-                                  int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
-{
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
-    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
-    if (n_points > 0 && (!d_payload || !d_out)) return fail(c, PCS_ERR_INVALID_ARG, "NULL device pointer");
-    if (out_shorts < (size_t)n_points * PCS_POINT_SHORTS)
-        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every point its own voxel) needs %zu",
-                    out_shorts, (size_t)n_points * PCS_POINT_SHORTS);
-    DeviceGuard guard(c->device);
-    const size_t need = voxel_workspace_bytes((uint32_t)n_points, voxel_workspace_level((uint32_t)n_points, leaf_mm, c->vox_state, false));
-    int rc = ensure_voxel_ws(c, need);
-    if (rc) return rc;
-    HIPCHK(c, launch_voxel_grid(d_payload, (uint32_t)n_points, d_n_points, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out,
-                                d_out_points, c->stream));
-    return PCS_OK;
-}
-
-int pcs_set_voxel_tail(pcs_ctx* c, int tail)
-{
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (tail != PCS_VOXEL_TAIL_AUTO && tail != PCS_VOXEL_TAIL_BUCKET && tail != PCS_VOXEL_TAIL_LSD && tail != PCS_VOXEL_TAIL_LSD_LATCHED)
-        return fail(c, PCS_ERR_INVALID_ARG, "unknown voxel tail %d", tail);
-    if (tail == PCS_VOXEL_TAIL_LSD_LATCHED) {
-        // (the flagged call's control block is cleared by the next call as any other's; clearing both costs one memset, once)
-        c->vox_state.stalled = true; c->vox_state.clean = false; c->vox_state.spl_leaf = 0;
-        c->voxel_reruns++;
-        return PCS_OK;
-    }
-    c->vox_state.tail_pref = tail;
-    c->vox_state.stalled = false;
-    return PCS_OK;
-}
-
-int pcs_voxel_tail_reruns(const pcs_ctx* c) { return c ? c->voxel_reruns : 0; }
-
-int pcs_inject_voxel_stall(int launches)
-{
-    pcs::inject_voxel_stall(launches);
-    return PCS_OK;
-}
-
-int pcs_voxel_grid_device(pcs_ctx* c, const int16_t* d_payload, int n_points, int leaf_mm, int16_t* d_out,
-                          size_t out_shorts, int32_t* d_out_points)
-{
-    return voxel_grid_device_impl(c, d_payload, n_points, nullptr, leaf_mm, d_out, out_shorts, d_out_points);
-}
-
-int pcs_voxel_grid_device_counted(pcs_ctx* c, const int16_t* d_payload, const int32_t* d_n_points, int max_points, int leaf_mm,
-                                  int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
-{
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (!d_n_points) return fail(c, PCS_ERR_INVALID_ARG, "d_n_points is NULL");
-    return voxel_grid_device_impl(c, d_payload, max_points, d_n_points, leaf_mm, d_out, out_shorts, d_out_points);
-}
-
-int pcs_process_frames_voxel_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm,
-                                    int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
-try {
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (!d_depth || !d_color || !d_out) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
-    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
-    const int S = c->n_streams;
-    for (int s = 0; s < S; s++) {
-        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
-        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
-    }
-    const size_t cap = c->max_payload_points;          // every pixel kept, no stride
-    if (out_shorts < cap * PCS_POINT_SHORTS)
-        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every pixel its own voxel) needs %zu",
-                    out_shorts, cap * PCS_POINT_SHORTS);
-    DeviceGuard guard(c->device);
-    // Rasters whose width is a multiple of 8 are read in square patches and the direct route wins at every leaf
-    // (16 x 1080p: 0.26 vs 0.46 ms at 50 mm, 0.52 vs 0.91 ms at 25 mm, 1.64 vs 2.57 ms at 10 mm). Other rasters are read
-    // in runs of 4096 consecutive pixels; below ~36 mm (on the synthetic scene) such a run holds more voxels than a
-    // workgroup's LDS table takes gracefully and the payload reader, fed by the ordered compaction, is the faster route
-    // (25 mm: 0.93 vs 1.11 ms). Same result either way. PCS_VOXEL_FUSED=0/1 forces one or the other.
-    static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
-    bool all_patch = true;
-    for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
-    const bool fused = fused_env >= 0 ? fused_env != 0 : (all_patch || leaf_mm >= 36);
-    if (c->downsample != 1 || !fused) {
-        // (the stride is defined on the ORDER of the kept points: build the stitched cloud, then its voxel grid)
-        int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
-        if (rc) return rc;
-        rc = run_fused_device(c, d_depth, d_color, c->s_payload, cap * PCS_POINT_SHORTS, c->d_counts, true);
-        if (rc) return rc;
-        return voxel_grid_device_impl(c, c->s_payload, (int)cap, c->d_counts + S, leaf_mm, d_out, out_shorts, d_out_points);
-    }
-    const size_t need = voxel_workspace_bytes((uint32_t)cap, voxel_workspace_level((uint32_t)cap, leaf_mm, c->vox_state, false));
-    int rc = ensure_voxel_ws(c, need);
-    if (rc) return rc;
-    std::pair<hipEvent_t, hipEvent_t> ev{};
-    if (c->kernel_timing) {
-        rc = acquire_event_pair(c, ev);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(ev.first, c->stream));
-    }
-    VoxelStage vs{};
-    HIPCHK(c, voxel_begin((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, &vs, c->stream));
-    for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
-        const int nl = std::min(kLaunchStreams, S - s0);
-        FramePtrs fp{};
-        uint32_t mp = 0, mw = 0, mh = 0;
-        bool fast = true, ident = true, rowc = true, patch_ok = true;
-        for (int k = 0; k < nl; k++) {
-            const StreamParams& q = c->h_params[s0 + k];
-            fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
-            mp = std::max(mp, q.n_points);
-            mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
-            patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
-            fast &= q.cert_fast != 0; ident &= q.ident_r != 0; rowc &= q.ident_r == 2;
-        }
-        const MathSel sel = !fast ? MathSel::Ieee : (ident ? (rowc ? MathSel::CertRowConst : MathSel::CertIdentR) : MathSel::Cert);
-        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
-    }
-    HIPCHK(c, voxel_finish((uint32_t)cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
-    if (c->kernel_timing) {
-        HIPCHK(c, hipEventRecord(ev.second, c->stream));
-        c->ev_pool.push_back(ev);
-    }
-    return PCS_OK;
-} catch (const std::exception& ex) {
-    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_device: host allocation failed (%s)", ex.what());
-}
-
-// The pre-aggregation of this context's streams under its flags into `vs`: a caller's arrays (exchange format), or the workspace of a
-// context of this device — its own, or another one's (a voxel sink, below). Fused from the rasters where that is the faster route
-// (as pcs_process_frames_voxel_device decides), else through this context's own stitched cloud.
-static int run_voxel_frontend(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color, int leaf_mm, const VoxelStage& vs)
-{
-    const int S = c->n_streams;
-    const size_t cap = c->max_payload_points;
-    static const int fused_env = [] { const char* v = getenv("PCS_VOXEL_FUSED"); return v ? atoi(v) : -1; }();
-    bool all_patch = true;
-    for (int s = 0; s < S; s++) all_patch &= (c->h_params[s].W & 7) == 0 && ((uintptr_t)d_depth[s] & 15u) == 0;
-    const bool fused = fused_env >= 0 ? fused_env != 0 : (all_patch || leaf_mm >= 36);      // as pcs_process_frames_voxel_device
-    if (c->downsample != 1 || !fused) {
-        // the stride is defined on the ORDER of the kept points: build this GPU's stitched cloud, pre-aggregate that
-        int rc = ensure(c, c->s_payload, c->s_payload_cap, cap * PCS_POINT_BYTES + 16);
-        if (rc) return rc;
-        rc = run_fused_device(c, d_depth, d_color, c->s_payload, cap * PCS_POINT_SHORTS, c->d_counts, true);
-        if (rc) return rc;
-        if (cap) HIPCHK(c, launch_payload_voxel_partials(c->s_payload, (uint32_t)cap, c->d_counts + S, vs, c->stream));
-        return PCS_OK;
-    }
-    for (int s0 = 0; s0 < S; s0 += kLaunchStreams) {
-        const int nl = std::min(kLaunchStreams, S - s0);
-        FramePtrs fp{};
-        uint32_t mp = 0, mw = 0, mh = 0;
-        bool fast = true, ident = true, rowc = true, patch_ok = true;
-        for (int k = 0; k < nl; k++) {
-            const StreamParams& q = c->h_params[s0 + k];
-            fp.depth[k] = d_depth[s0 + k]; fp.color[k] = d_color[s0 + k];
-            mp = std::max(mp, q.n_points);
-            mw = std::max(mw, (uint32_t)q.W); mh = std::max(mh, q.n_points / (uint32_t)q.W);
-            patch_ok &= (q.W & 7) == 0 && ((uintptr_t)d_depth[s0 + k] & 15u) == 0;
-            fast &= q.cert_fast != 0; ident &= q.ident_r != 0; rowc &= q.ident_r == 2;
-        }
-        const MathSel sel = !fast ? MathSel::Ieee : (ident ? (rowc ? MathSel::CertRowConst : MathSel::CertIdentR) : MathSel::Cert);
-        HIPCHK(c, launch_fused_voxel_partials(c->d_params, s0, nl, mp, mw, mh, patch_ok, c->any_ddist || c->any_cdist, c->flags, sel, fp, vs, c->stream));
-    }
-    return PCS_OK;
-}
-
-// ---- voxel partials (exchange format of the multi-GPU voxel grid) ------------------------------------
-int pcs_process_frames_voxel_partials_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
-                                             int leaf_mm, uint64_t* d_keys, pcs_voxel_partial* d_partials, size_t capacity,
-                                             int32_t* d_n_partials)
-try {
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (!d_depth || !d_color || !d_keys || !d_partials || !d_n_partials) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
-    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
-    if (((uintptr_t)d_keys & 7u) || ((uintptr_t)d_partials & 31u))
-        return fail(c, PCS_ERR_INVALID_ARG, "d_keys must be 8-byte and d_partials 32-byte aligned");
-    const int S = c->n_streams;
-    for (int s = 0; s < S; s++) {
-        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
-        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
-    }
-    const size_t cap = c->max_payload_points;
-    if (capacity < cap)
-        return fail(c, PCS_ERR_CAPACITY, "partial arrays hold %zu entries; the worst case (every kept point its own partial) needs %zu",
-                    capacity, cap);
-    DeviceGuard guard(c->device);
-    static_assert(sizeof(pcs_voxel_partial) == 32, "pcs_voxel_partial is the kernels' 32-byte VoxelPartial");
-    // the caller's count word IS the append counter of the pre-aggregation (cleared here, complete when the kernels are)
-    VoxelStage vs{};
-    HIPCHK(c, voxel_partials_stage(leaf_mm, reinterpret_cast<unsigned long long*>(d_keys), d_partials,
-                                   reinterpret_cast<unsigned int*>(d_n_partials), &vs, c->stream));
-    const int rc = run_voxel_frontend(c, d_depth, d_color, leaf_mm, vs);
-    if (rc) return rc;
-    return PCS_OK;
-} catch (const std::exception& ex) {
-    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_partials_device: host allocation failed (%s)", ex.what());
-}
-
-int pcs_voxel_grid_from_partials_device(pcs_ctx* c, const uint64_t* d_keys, const pcs_voxel_partial* d_partials, int n_partials,
-                                        const int32_t* d_n_partials, int leaf_mm, int16_t* d_out, size_t out_shorts,
-                                        int32_t* d_out_points)
-try {
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (n_partials < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_partials %d < 0", n_partials);
-    if (((uintptr_t)d_n_partials & 3u) || ((uintptr_t)d_out_points & 3u))
-        return fail(c, PCS_ERR_INVALID_ARG, "d_n_partials / d_out_points must be 4-byte aligned");
-    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
-    if (n_partials > 0 && (!d_keys || !d_partials || !d_out)) return fail(c, PCS_ERR_INVALID_ARG, "NULL device pointer");
-    if (((uintptr_t)d_keys & 7u) || ((uintptr_t)d_partials & 31u))
-        return fail(c, PCS_ERR_INVALID_ARG, "d_keys must be 8-byte and d_partials 32-byte aligned");
-    if (out_shorts < (size_t)n_partials * PCS_POINT_SHORTS)
-        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every partial its own voxel) needs %zu",
-                    out_shorts, (size_t)n_partials * PCS_POINT_SHORTS);
-    DeviceGuard guard(c->device);
-    // (a quarter more than this call's count + 64 Ki: the regions a warm call fills were sized by the PREVIOUS call's count, and a root's
-    // count moves from frame-set to frame-set — launch_voxel_from_partials carves the workspace for what it holds)
-    const uint32_t n_size = (uint32_t)std::min<uint64_t>((uint64_t)n_partials + (uint64_t)n_partials / 4u + 65536u,
-                                                         (uint32_t)n_partials < (1u << 26) ? (1u << 26) - 1u : 0xFFFFFFF0u);
-    const size_t need = voxel_workspace_bytes(n_size, voxel_workspace_level((uint32_t)n_partials, leaf_mm, c->vox_state, true));
-    int rc = ensure_voxel_ws(c, need);
-    if (rc) return rc;
-    HIPCHK(c, launch_voxel_from_partials(reinterpret_cast<const unsigned long long*>(d_keys), d_partials, (uint32_t)n_partials,
-                                         d_n_partials, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
-    return PCS_OK;
-} catch (const std::exception& ex) {
-    return fail(c, PCS_ERR_NOMEM, "pcs_voxel_grid_from_partials_device: host allocation failed (%s)", ex.what());
-}
-
-// ---- voxel SINK: one context's workspace filled by the pre-aggregations of several contexts of the same device ---------
-namespace {
-struct SinkBlob {
-    VoxelStage vs;
-    uint32_t   capacity;
-    int32_t    leaf, device;
-    uint32_t   magic;
-};
-static_assert(sizeof(SinkBlob) <= sizeof(((pcs_voxel_sink*)nullptr)->opaque), "pcs_voxel_sink (include/pcs_hip.h) must hold a VoxelStage");
-constexpr uint32_t kSinkMagic = 0x50435356u;      // "PCSV"
-}  // namespace
-
-int pcs_voxel_sink_begin(pcs_ctx* c, size_t capacity_points, int leaf_mm, pcs_voxel_sink* sink)
-{
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (!sink) return fail(c, PCS_ERR_INVALID_ARG, "sink is NULL");
-    if (leaf_mm < 1 || leaf_mm > 32767) return fail(c, PCS_ERR_INVALID_ARG, "leaf_mm %d outside 1..32767", leaf_mm);
-    if (capacity_points < 1 || capacity_points > 0xFFFFFFF0ull)
-        return fail(c, PCS_ERR_INVALID_ARG, "capacity_points %zu outside 1..2^32-16", capacity_points);
-    // (a sink that was opened and never finished — a pre-aggregation failed in between — is abandoned here: voxel_begin left the
-    // workspace marked unclean, so this call clears its control blocks again)
-    DeviceGuard guard(c->device);
-    const uint32_t cap = (uint32_t)capacity_points;
-    const size_t need = voxel_workspace_bytes(cap, voxel_workspace_level(cap, leaf_mm, c->vox_state, false));
-    const int rc = ensure_voxel_ws(c, need);
-    if (rc) return rc;
-    SinkBlob b{};
-    // (voxel_begin clears the control blocks of a workspace it has not seen, or whose last call was not enqueued completely, with a
-    // memset on this stream: the only work a begin ever enqueues)
-    const bool clears = !c->vox_state.clean || c->vox_state.base != c->s_voxel_ws;
-    HIPCHK(c, voxel_begin(cap, leaf_mm, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, &b.vs, c->stream));
-    b.capacity = cap; b.leaf = leaf_mm; b.device = c->device; b.magic = kSinkMagic;
-    std::memset(sink, 0, sizeof *sink);
-    std::memcpy(sink->opaque, &b, sizeof b);
-    sink->work_enqueued = clears ? 1u : 0u;
-    c->sink_open = true;
-    return PCS_OK;
-}
-
-int pcs_process_frames_voxel_into_sink_device(pcs_ctx* c, const uint16_t* const* d_depth, const uint8_t* const* d_color,
-                                              const pcs_voxel_sink* sink)
-try {
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (!d_depth || !d_color || !sink) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
-    SinkBlob b;
-    std::memcpy(&b, sink->opaque, sizeof b);
-    if (b.magic != kSinkMagic) return fail(c, PCS_ERR_INVALID_ARG, "not a sink pcs_voxel_sink_begin filled");
-    if (b.device != c->device)
-        return fail(c, PCS_ERR_INVALID_ARG, "the sink lives on device %d, this context on device %d: a sink takes contexts of its own device only "
-                    "(the pre-aggregation's atomics are device-scope; other GPUs exchange partials)", b.device, c->device);
-    const int S = c->n_streams;
-    for (int s = 0; s < S; s++) {
-        if (!d_depth[s] || !d_color[s]) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: NULL raster pointer", s);
-        if ((uintptr_t)d_depth[s] & 1u) return fail(c, PCS_ERR_INVALID_ARG, "stream %d: depth pointer not 2-byte aligned", s);
-    }
-    if (c->max_payload_points > b.capacity)
-        return fail(c, PCS_ERR_CAPACITY, "the sink was opened for %u points; this context alone can produce %zu", b.capacity, c->max_payload_points);
-    DeviceGuard guard(c->device);
-    return run_voxel_frontend(c, d_depth, d_color, b.leaf, b.vs);
-} catch (const std::exception& ex) {
-    return fail(c, PCS_ERR_NOMEM, "pcs_process_frames_voxel_into_sink_device: host allocation failed (%s)", ex.what());
-}
-
-int pcs_voxel_sink_finish(pcs_ctx* c, const pcs_voxel_sink* sink, int16_t* d_out, size_t out_shorts, int32_t* d_out_points)
-{
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (!sink || !d_out) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
-    if ((uintptr_t)d_out_points & 3u) return fail(c, PCS_ERR_INVALID_ARG, "d_out_points must be 4-byte aligned");
-    SinkBlob b;
-    std::memcpy(&b, sink->opaque, sizeof b);
-    if (b.magic != kSinkMagic || !c->sink_open || b.device != c->device)
-        return fail(c, PCS_ERR_INVALID_ARG, "not the sink this context has open");
-    if (out_shorts < (size_t)b.capacity * PCS_POINT_SHORTS)
-        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts; the worst case (every point its own voxel) needs %zu",
-                    out_shorts, (size_t)b.capacity * PCS_POINT_SHORTS);
-    DeviceGuard guard(c->device);
-    c->sink_open = false;
-    HIPCHK(c, voxel_finish(b.capacity, b.leaf, c->s_voxel_ws, c->s_voxel_ws_cap, &c->vox_state, d_out, d_out_points, c->stream));
-    return PCS_OK;
-}
-
-int pcs_voxel_grid(pcs_ctx* c, const int16_t* payload, int n_points, int leaf_mm, int16_t* out, size_t out_shorts,
-                   int* out_points)
-{
-    if (!c) return PCS_ERR_INVALID_ARG;
-    if (n_points < 0) return fail(c, PCS_ERR_INVALID_ARG, "n_points %d < 0", n_points);
-    if (n_points == 0) { if (out_points) *out_points = 0; return PCS_OK; }
-    if (!payload || !out) return fail(c, PCS_ERR_INVALID_ARG, "NULL pointer");
-    DeviceGuard guard(c->device);
-    const size_t bytes = (size_t)n_points * PCS_POINT_BYTES;
-    int rc;
-    if ((rc = ensure(c, c->s_voxel_in, c->s_voxel_in_cap, bytes))) return rc;
-    if ((rc = ensure(c, c->s_voxel_out, c->s_voxel_out_cap, bytes))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->s_voxel_in, payload, bytes, hipMemcpyHostToDevice, c->stream));
-    rc = pcs_voxel_grid_device(c, c->s_voxel_in, n_points, leaf_mm, c->s_voxel_out, (size_t)n_points * PCS_POINT_SHORTS, c->d_counts);
-    if (rc) return rc;
-    int32_t nv = 0;
-    HIPCHK(c, hipMemcpyAsync(&nv, c->d_counts, sizeof nv, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (nv < 0) {
-        // the bucket tail gave up waiting for one of its own workgroups (the device forms report the -1 as it is; see
-        // include/pcs_hip.h): the input is still in s_voxel_in — once more on the LSD tail, which waits for nobody, and LSD for
-        // this context from here on
-        if ((rc = pcs_set_voxel_tail(c, PCS_VOXEL_TAIL_LSD_LATCHED))) return rc;
-        rc = pcs_voxel_grid_device(c, c->s_voxel_in, n_points, leaf_mm, c->s_voxel_out, (size_t)n_points * PCS_POINT_SHORTS, c->d_counts);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(&nv, c->d_counts, sizeof nv, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (nv < 0) return fail(c, PCS_ERR_HIP, "the voxel pipeline reported a negative count on the LSD tail");
-    }
-    if (out_shorts < (size_t)nv * PCS_POINT_SHORTS)
-        return fail(c, PCS_ERR_CAPACITY, "output holds %zu shorts, %zu needed", out_shorts, (size_t)nv * PCS_POINT_SHORTS);
-    if (nv) HIPCHK(c, hipMemcpy(out, c->s_voxel_out, (size_t)nv * PCS_POINT_BYTES, hipMemcpyDeviceToHost));
-    if (out_points) *out_points = nv;
     return PCS_OK;
 }
 

@@ -1188,7 +1188,7 @@ __device__ __forceinline__ void bkt_hash(unsigned long long key, unsigned int& f
 // generation: nobody clears the words) as soon as they know them. Waiting on LOWER-numbered workgroups only is safe on hardware
 // that starts workgroups in order (what rocPRIM's look-back scan relies on too); the wait is bounded all the same: after ~0.5 s
 // the workgroup gives up, flags the call (ctl[3] -> *out_points = -1) and carries on, so a launch can end wrong but never hang.
-// The host forms that read the count re-run a flagged call on the LSD tail (pcs_capi.cpp, pcs_node.cpp). `bound`: the wait in
+// The host forms that read the count re-run a flagged call on the LSD tail (pcs_capi_voxel.cpp, pcs_node.cpp). `bound`: the wait in
 // 100 MHz ticks (kBktWaitTicks; a launch with an injected stall, pcs_inject_voxel_stall, waits 20 us only).
 constexpr long long kBktWaitTicks = 50000000ll, kBktStallWaitTicks = 2000ll, kBktStallTicks = 40000ll;
 __device__ __forceinline__ unsigned int bkt_base(const unsigned int* pub, unsigned int b, unsigned int gen, unsigned int* ctl, unsigned int* wsum,
@@ -2147,7 +2147,7 @@ hipError_t launch_voxel_from_partials(const unsigned long long* d_keys, const vo
     }
     // The workspace is carved for as many partials as it HOLDS, not for this call's count: a root's count moves a little from frame-set
     // to frame-set, and regions sized by the previous call's (2 m' + 64 Ki slots) must fit the capacity this call carves (the owner
-    // sizes the workspace with headroom: pcs_capi.cpp). Nothing below reads more than n_partials elements.
+    // sizes the workspace with headroom: pcs_capi_voxel.cpp). Nothing below reads more than n_partials elements.
     uint32_t n_carve = n_partials;
     {
         const int level = voxel_workspace_level(n_partials, leaf_mm, *ws, true);

@@ -12,6 +12,6 @@ while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
       -Wno-unused-parameter -mllvm -amdgpu-kernarg-preload-count=16 -DPCS_TU_VOXEL=1 -Wno-unused -Wno-unneeded-internal-declaration \
       $defs -c pcs_kernels.hip -o /tmp/pcs_kernels_voxel_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/lab/libpcs_hip_$name.so pcs_kernels.o /tmp/pcs_kernels_voxel_$name.o pcs_voxel.o pcs_capi.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/lab/libpcs_hip_$name.so pcs_kernels.o /tmp/pcs_kernels_voxel_$name.o pcs_voxel.o pcs_capi.o pcs_capi_voxel.o
   ls -la ../lib/lab/libpcs_hip_$name.so
 done
