@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of pcs_process_frames_voxel_device (rasters -> voxel grid, no stitched cloud) and of the partials exchange
-format (cameras split over several contexts, partials merged on one) against the oracle's voxel grid over the oracle's
-stitched cloud.   tools/voxel_raster_soak.py [seconds] [seed]"""
+format (cameras split over several contexts, partials merged on one, or pre-aggregated into one context's voxel sink) against
+the oracle's voxel grid over the oracle's stitched cloud.   tools/voxel_raster_soak.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ from tests.test_gpu_parity import _random_config                                
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
-runs = patch_runs = shard_runs = bad = 0
+runs = patch_runs = shard_runs = sink_runs = bad = 0
 while time.time() - t0 < budget:
     n = int(rng.integers(1, 5))
     shapes = []
@@ -133,9 +133,42 @@ while time.time() - t0 < budget:
             if got.shape != want.shape or (got != want).any():
                 bad += 1
                 print("MISMATCH (sharded partials)", shapes, flags, stride, leaf, bounds, got.shape, want.shape, flush=True)
+            # the same shards into a voxel SINK (pcs_voxel_sink_*): one more context owns the workspace and the tail, the shards
+            # pre-aggregate into it in a random order; two or three calls on the sink (cold, then warm), sometimes another leaf between
+            with PcsContext(cfgs[:1]) as sink_ctx:
+                total = sum(caps)
+                d_so = sink_ctx.device_malloc(total * 10 + 64); d_sn = sink_ctx.device_malloc(64)
+                up = []
+                for r, c in enumerate(ctxs):
+                    a, b = bounds[r], bounds[r + 1]
+                    dd = [c.device_malloc(max(d.nbytes, 16)) for d in depth[a:b]]
+                    dc = [c.device_malloc(max(x.nbytes, 16)) for x in color[a:b]]
+                    for ptr, arr in zip(dd + dc, depth[a:b] + color[a:b]):
+                        c.memcpy_h2d(ptr, arr)
+                    up.append((dd, dc))
+                leaves = [leaf] * int(rng.integers(2, 4))
+                if rng.random() < 0.3:
+                    leaves.insert(1, int(rng.choice([3, 40, 64, 900])))
+                for lf in leaves:
+                    sink = sink_ctx.voxel_sink_begin(total, lf)
+                    sink_ctx.synchronize()
+                    for r in rng.permutation(len(ctxs)):
+                        ctxs[r].process_frames_voxel_into_sink_device(up[r][0], up[r][1], sink)
+                    for c in ctxs:
+                        c.synchronize()
+                    sink_ctx.voxel_sink_finish(sink, d_so, total * 5, d_sn)
+                    sink_ctx.synchronize()
+                    nv = np.empty(1, np.int32); sink_ctx.memcpy_d2h(nv, d_sn)
+                    got = np.empty(max(int(nv[0]), 1) * 5, np.int16); sink_ctx.memcpy_d2h(got, d_so)
+                    got = got[:max(int(nv[0]), 0) * 5].reshape(-1, 5)
+                    want_s = want if lf == leaf else O.voxel_grid(stitched, lf)
+                    sink_runs += 1
+                    if int(nv[0]) < 0 or got.shape != want_s.shape or (got != want_s).any():
+                        bad += 1
+                        print("MISMATCH (sink)", shapes, flags, stride, lf, bounds, int(nv[0]), want_s.shape, flush=True)
         finally:
             for c in ctxs:
                 c.close()
-print(f"{runs} raster->voxel calls ({patch_runs} through the square-patch reader), {shard_runs} sharded partial merges, "
+print(f"{runs} raster->voxel calls ({patch_runs} through the square-patch reader), {shard_runs} sharded partial merges, {sink_runs} sink calls, "
       f"{bad} mismatches in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
