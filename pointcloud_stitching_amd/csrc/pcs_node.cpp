@@ -584,6 +584,7 @@ void pcs_node_destroy(pcs_node* n)
     }
     if (n->alt_ctx) { if (!n->peers.empty()) (void)hipSetDevice(n->peers[0].dev); (void)pcs_synchronize(n->alt_ctx); pcs_destroy(n->alt_ctx);
                       if (n->alt_stream) (void)hipStreamDestroy(n->alt_stream); }
+    (void)unshare_streams(n);              // (a context must not be destroyed while it runs on the stream of one destroyed before it)
     for (Peer& p : n->peers) if (p.ctx) pcs_destroy(p.ctx);
     delete n;
 }
