@@ -179,6 +179,35 @@ def test_pipelined_voxel_route_keeps_two_frame_sets_in_flight(oracle, flags, dev
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0], "two peers, exchange", "one peer, partials pipeline"])
+def test_voxel_ticket_of_a_frame_set_with_nothing_kept(oracle, devices, monkeypatch):
+    """Every depth pixel invalid under PCS_FLAG_DROP_INVALID: no point, no partial, no voxel — the count the wait returns is 0 (written by the
+    tail, or by the memset that stands in for a tail with nothing to do), and the next frame-set on the same slots is whole again."""
+    from pointcloud_stitching_amd.node import PcsNode
+    if devices == "two peers, exchange":
+        monkeypatch.setenv("PCS_NODE_VOXEL_SINK", "0"); devices = [0, 0]
+    elif isinstance(devices, str):
+        monkeypatch.setenv("PCS_NODE_ONE_CALL", "0"); devices = [0]
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    empty = [np.zeros_like(d) for d in depth]
+    want = oracle.voxel_grid(oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID, 1)[0], 50)
+    with PcsNode(cfgs, devices=devices, flags=FLAG_DROP_INVALID) as node, PcsContext(cfgs[:1]) as mem:
+        cap = node.max_payload_shorts
+        full, none = _upload(mem, depth, color), _upload(mem, empty, color)
+        vox = [mem.device_malloc(cap * 2 + 64) for _ in range(2)]
+        order = [full, none, none, full, none, full]
+        t = node.submit_voxel_device(*order[0], 50, vox[0], cap)
+        for k in range(1, len(order) + 1):
+            t2 = node.submit_voxel_device(*order[k], 50, vox[k & 1], cap) if k < len(order) else None
+            nv = node.wait_voxel(t)
+            if order[k - 1] is none:
+                assert nv == 0, k - 1
+            else:
+                assert nv == want.shape[0] and (_fetch(mem, vox[(k - 1) & 1], nv) == want).all(), k - 1
+            t = t2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices", [[0], [0] * 8, "one peer, partials pipeline", "one peer, one context", "eight peers, exchange"])
 def test_config5_full_size_two_frame_sets_in_flight_match_the_digests(devices, monkeypatch):
     """BASELINE configs[4] at full size — 16 x 1920x1080, invalid-depth compaction, 50 mm voxel grid — through the pipelined node
