@@ -452,6 +452,7 @@ def test_two_physical_gpus_voxel_partials_exchange(oracle, route):
         nv, stats = node.process_voxel_device(*dev_sets[1], leaf, vox[0], cap, VOXEL_PARTIALS if route == "partials" else VOXEL_PAYLOADS)
         assert nv == want[1].shape[0] and (_fetch(mem0, vox[0], nv) == want[1]).all()
         assert stats["exchanged_bytes"] > 0
+        assert node.voxel_sink is False          # two GPUs: the partials travel; sinks are for peers of ONE device
     if route == "partials":                     # the configuration's own size against the digest
         W, H, N = 1920, 1080, 16
         cfg5 = [S.synth_stream_config(W, H, s) for s in range(N)]
@@ -460,6 +461,26 @@ def test_two_physical_gpus_voxel_partials_exchange(oracle, route):
         with PcsNode(cfg5, devices=[0, 1], flags=FLAG_DROP_INVALID) as node:
             got, stats = node.process_voxel(d5, c5, 50)
             assert got.shape[0] == gold["voxels"] and hashlib.sha256(got.tobytes()).hexdigest() == gold["sha256"]
+
+
+@pytest.mark.gpu
+def test_two_physical_gpus_a_sink_refuses_a_context_of_the_other_device(oracle):
+    """A voxel sink takes contexts of its own device only (the pre-aggregation's atomics are device-scope); a mixed node — two peers on
+    GPU 0, two on GPU 1 — therefore exchanges partials and still ends on the oracle's bytes. Skips with a reason on a one-GPU box."""
+    _two_gpus_or_skip()
+    from pointcloud_stitching_amd.node import PcsNode
+    cfgs, depth, color = S.synth_frame_set(4, 160, 120)
+    with PcsContext(cfgs[:2], device=0) as sink_ctx, PcsContext(cfgs[2:], device=1) as other:
+        sink = sink_ctx.voxel_sink_begin(4 * 160 * 120, 50)
+        dd, dc = _upload(other, depth[2:], color[2:])
+        with pytest.raises(PcsError) as e:
+            other.process_frames_voxel_into_sink_device(dd, dc, sink)
+        assert e.value.status == -1 and "device" in str(e.value)
+    want = oracle.voxel_grid(oracle.process_frames(cfgs, depth, color, FLAG_DROP_INVALID, 1)[0], 50)
+    with PcsNode(cfgs, devices=[0, 0, 1, 1], flags=FLAG_DROP_INVALID) as node:
+        assert node.voxel_sink is False
+        got, stats = node.process_voxel(depth, color, 50)
+        assert got.shape == want.shape and (got == want).all() and stats["exchanged_bytes"] > 0
 
 
 @pytest.mark.gpu
