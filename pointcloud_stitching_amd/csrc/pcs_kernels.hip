@@ -593,6 +593,43 @@ struct DepthSource {
         }
     }
 
+    // The same with the lane's eight Z16 values already in registers (requested a round earlier: fast(P) rasters only).
+    __device__ __forceinline__ Raw fetch_luts(const StreamParams& P, uint32_t i0, const uint4& dv) const
+    {
+        const uint32_t r = P.w_magic ? (__umulhi(i0, P.w_magic) >> P.w_shift) : i0 / (uint32_t)P.W;
+        const uint32_t c0 = i0 - r * (uint32_t)P.W;
+        Raw q;
+        q.dv = dv;
+        const gptr<float> lut_x = as_global(P.mx);
+        q.ma = *reinterpret_cast<gptr<f32x4>>(lut_x + c0);
+        q.mb = *reinterpret_cast<gptr<f32x4>>(lut_x + c0 + 4);
+        q.my = as_global(P.my)[r];
+        return q;
+    }
+    __device__ __forceinline__ void load8_pre(const StreamParams& P, uint32_t i0, uint32_t n, const uint4& dv, PointIn (&p)[8]) const
+    {
+        if (i0 >= n) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) p[k] = PointIn{0, 0, 0, 0, 0};
+            return;
+        }
+        const Raw q = fetch_luts(P, i0, dv);
+        if constexpr (Mth::kRowConst) {
+            const uint32_t r = P.w_magic ? (__umulhi(i0, P.w_magic) >> P.w_shift) : i0 / (uint32_t)P.W;
+            const int crow = __float_as_int(as_global(P.my)[(uint32_t)P.H + r]);
+            const uint32_t dw[4] = {q.dv.x, q.dv.y, q.dv.z, q.dv.w};
+            const float mxs[8] = {q.ma.x, q.ma.y, q.ma.z, q.ma.w, q.mb.x, q.mb.y, q.mb.z, q.mb.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t d = (k & 1) ? (dw[k >> 1] >> 16) : (dw[k >> 1] & 0xFFFFu);
+                p[k] = deproject_pixel_rowc<Mth>(P, d, mxs[k], q.my, crow);
+            }
+        } else {
+            if ((DDIST || CDIST) && (P.ddist | P.cdist | P.tex_half)) deproject<DDIST, CDIST>(P, q, p);
+            else deproject<false, false>(P, q, p);
+        }
+    }
+
     __device__ __forceinline__ void load8(const StreamParams& P, uint32_t i0, uint32_t n, PointIn (&p)[8]) const
     {
         if (i0 >= n) {
@@ -1339,6 +1376,9 @@ void pcs_scan_batch_kernel(const StreamParams* __restrict__ params, const uint32
 #ifndef PCS_VOX_SLOTS
 #define PCS_VOX_SLOTS 2048
 #endif
+#ifndef PCS_VOX_PREFETCH
+#define PCS_VOX_PREFETCH 1
+#endif
 // Workgroup shape of the raster / payload readers: 512 lanes (8 wavefronts) and a 2048-slot table (72 KiB): two workgroups per
 // CU, 4 wavefronts per SIMD at 120 - 126 VGPRs (~105 when these measurements were taken, with packed records). Round 5 measured the two ways to a FIFTH wavefront per SIMD (<= 96 VGPRs), 16 x 1080p
 // at 50 mm, one call, A/B on one box:
@@ -1796,28 +1836,37 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
     if (tl.rx ? (sq_y0 * kVoxRows >= Hh || sq_x0 * 64u >= W) : (tile0 >= n)) return;      // (a smaller raster than the launch's largest)
     const uint8_t* __restrict__ color = fp.color[s];
     DepthSource<DD, CD, Mth> src{fp.depth[s]};
-    vox_table_init(T);
 
-    for (uint32_t yy = 0; yy < nry; yy++) {
+    // The rounds of this workgroup, in the order (yy, xx) of its patch. A square-row below the raster ends the workgroup, a square
+    // beside the raster ends its square-row — uniform over the workgroup, so the barriers of a crowded round stay matched. Where a
+    // round has no barrier, a WAVEFRONT whose 8 rows lie below the raster (the last 8 of 1080 = 16 x 64 + 56) passes too.
+    // PCS_VOX_PREFETCH: the lane's Z16 quad of the NEXT round is requested before this round's deprojection and table phase (rasters
+    // read in 16-byte quads only): the one load of a round that comes from HBM then has a whole round to arrive in.
+    auto lane_index = [&](uint32_t yy, uint32_t xx) -> uint32_t {         // this lane's first pixel of round (yy, xx); n: nothing to read
+        if (!tl.rx) return tile0 + yy * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
+        const uint32_t row = (sq_y0 + yy) * kVoxRows + (threadIdx.x >> 3);
+        const uint32_t col = (sq_x0 + xx) * 64u + (threadIdx.x & 7u) * 8u;
+        return (row < Hh && col < W) ? row * W + col : n;                // W % 8 == 0: a lane is inside the row or outside it
+    };
+    const bool prefetch = PCS_VOX_PREFETCH != 0 && src.fast(P);          // uniform over the launch's stream
+    uint32_t yy = 0, xx = 0;
+    bool have = nry > 0u && nrx > 0u && !(tl.rx && (sq_y0 * kVoxRows >= Hh || sq_x0 * 64u >= W));
+    uint32_t i0 = have ? lane_index(0u, 0u) : n;
+    uint4 dv = make_uint4(0u, 0u, 0u, 0u);
+    if (prefetch && i0 < n) dv = *reinterpret_cast<const uint4*>(fp.depth[s] + i0);      // (on its way while the table is cleared)
+    vox_table_init(T);
+    while (have) {
+        uint32_t ny = yy, nx = xx + 1u;
+        if (nx >= nrx || (tl.rx && (sq_x0 + nx) * 64u >= W)) { nx = 0u; ny = yy + 1u; }
+        const bool have_next = ny < nry && !(tl.rx && (sq_y0 + ny) * kVoxRows >= Hh);
+        const uint32_t i0n = have_next ? lane_index(ny, nx) : n;
+        uint4 dvn = make_uint4(0u, 0u, 0u, 0u);
+        if (prefetch && i0n < n) dvn = *reinterpret_cast<const uint4*>(fp.depth[s] + i0n);
         const uint32_t row0 = (sq_y0 + yy) * kVoxRows;
-        // A square-row below the raster ends the workgroup, a square beside the raster is passed over — uniform over the
-        // workgroup, so the barriers of a crowded round stay matched. Where a round has no barrier, a WAVEFRONT whose 8 rows
-        // lie below the raster (the last 8 of 1080 = 16 x 64 + 56) passes too.
-        if (tl.rx && row0 >= Hh) break;
-        for (uint32_t xx = 0; xx < nrx; xx++) {
-            uint32_t i0;
-            if (tl.rx) {
-                const uint32_t col0 = (sq_x0 + xx) * 64u;
-                if (col0 >= W) break;
-                if (!crowded && row0 + ((threadIdx.x >> 6) << 3) >= Hh) continue;
-                const uint32_t row = row0 + (threadIdx.x >> 3);
-                const uint32_t col = col0 + (threadIdx.x & 7u) * 8u;
-                i0 = (row < Hh && col < W) ? row * W + col : n;        // W % 8 == 0: a lane is inside the row or outside it
-            } else {
-                i0 = tile0 + yy * kVoxRoundPoints + threadIdx.x * kPointsPerLane;
-            }
+        if (!(tl.rx && !crowded && row0 + ((threadIdx.x >> 6) << 3) >= Hh)) {
             PointIn p[8];
-            src.load8(P, i0, n, p);
+            if (prefetch) src.load8_pre(P, i0, n, dv, p);
+            else src.load8(P, i0, n, p);
             const KeepBits keep{keep_mask8(p, i0, n, flags)};
 
             VoxPoint rec[8];
@@ -1839,6 +1888,7 @@ void pcs_fused_voxel_partials_kernel(const StreamParams* __restrict__ params, in
             }
             vox_table_round(T, vs, rec, keep, crowded != 0, key_or, key_orn);
         }
+        yy = ny; xx = nx; i0 = i0n; dv = dvn; have = have_next;
     }
     vox_table_flush(T, vs, key_or, key_orn);
 }
