@@ -422,7 +422,7 @@ int pcs_voxel_sink_finish(pcs_ctx* sink_ctx, const pcs_voxel_sink* sink, int16_t
 int   pcs_set_stream(pcs_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL = own stream) */
 void* pcs_get_stream(pcs_ctx* ctx);
 /* Two contexts of one device used IN TURN overlap — the tail of one call beside the head of the next (BASELINE configs[4]: the voxel
- * pipeline's bucket tail beside the next frame-set's pre-aggregation, 0.169 -> 0.153 ms per 16 x 1080p frame-set) — only if their streams
+ * pipeline's bucket tail beside the next frame-set's pre-aggregation, 0.169 -> 0.152 ms per 16 x 1080p frame-set) — only if their streams
  * sit on different hardware queues; the runtime deals streams onto a few queues round robin, so that is luck. pcs_use_stream_beside
  * replaces ctx's OWN stream by one that is SEEN to run beside other's current stream (a no-op must finish while a 300 us spin occupies
  * the other; up to six candidates; ~2 ms, once). Returns 1 when such a stream was found and taken, 0 when none was (ctx keeps its
